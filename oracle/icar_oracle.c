@@ -1,0 +1,514 @@
+/* oracle/icar_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Plain-C CPU restatement of the reference's per-timestep hot path (advection + mp_simple),
+ * written from the reference's algorithm with the reference's operation order so that it is
+ * BIT-EXACT against the compiled reference (oracle/_ref, see tests/test_oracle_vs_ref.py and
+ * the committed fixtures under tests/golden/).  Compile with -ffp-contract=off.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
+ *
+ * Layout: Fortran (i,k,j), i fastest:  idx = i + nx*(k + nz*j), 0-based here
+ * (reference index = this + 1 when ims=kms=jms=1).
+ *   U_m is stored on an nx-wide grid: U[i] = Courant number on the face between cells i-1 and i
+ *   (reference U_m(ims+1:ime) -> our i=1..nx-1; U[0] unused).  V likewise in j.  W[k] is the
+ *   face ABOVE level k.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IDX(i,k,j) ((size_t)(i) + (size_t)nx*((size_t)(k) + (size_t)nz*(size_t)(j)))
+
+/* A1: src/physics/advect.f90:345-348 (scheme 1) / src/physics/adv_mpdata.f90:500-506 (scheme 2).
+ * u is (nx+1,nz,ny), v is (nx,nz,ny+1); jaco_u/jaco_v staggered the same way. */
+void orc_setup_winds(int scheme, int nx, int nz, int ny,
+                     const float *u, const float *v, const float *w, const float *rho_in,
+                     const float *jaco_u, const float *jaco_v, const float *jaco_w,
+                     float dx, float dt, int advect_density, float *U, float *V, float *W)
+{
+    const int nxu = nx + 1;
+    for (int j = 0; j < ny; ++j)
+        for (int k = 0; k < nz; ++k)
+            for (int i = 0; i < nx; ++i) {
+                const size_t c = IDX(i, k, j);
+                const float r0 = advect_density ? rho_in[c] : 1.0f;
+                if (i >= 1) {
+                    const float rl = advect_density ? rho_in[IDX(i - 1, k, j)] : 1.0f;
+                    const size_t cu = (size_t)i + (size_t)nxu * ((size_t)k + (size_t)nz * j);
+                    if (scheme == 1)
+                        U[c] = u[cu] * dt * jaco_u[cu] * (r0 + rl) * 0.5f / dx;
+                    else
+                        U[c] = u[cu] * dt * (r0 + rl) * 0.5f * jaco_u[cu] / dx;
+                } else U[c] = 0.0f;
+                if (j >= 1) {
+                    const float rl = advect_density ? rho_in[IDX(i, k, j - 1)] : 1.0f;
+                    if (scheme == 1)
+                        V[c] = v[c] * dt * jaco_v[c] * (r0 + rl) * 0.5f / dx;
+                    else
+                        V[c] = v[c] * dt * (r0 + rl) * 0.5f * jaco_v[c] / dx;
+                } else V[c] = 0.0f;
+                if (k < nz - 1) {
+                    const float ru = advect_density ? rho_in[IDX(i, k + 1, j)] : 1.0f;
+                    W[c] = w[c] * dt * jaco_w[c] * (ru + r0) * 0.5f;
+                } else
+                    W[c] = w[c] * dt * jaco_w[c] * r0;
+            }
+}
+
+static inline float flux1(float l, float r, float U)
+{   /* src/physics/adv_mpdata.f90:40 */
+    return ((U + fabsf(U)) * l + (U - fabsf(U)) * r) / 2;
+}
+
+/* A2: donor-cell pass. src/physics/advect.f90:139-175 == src/physics/adv_mpdata.f90:44-105.
+ * q := qin everywhere, then interior cells updated.  rho==NULL means rho=1. */
+void orc_upwind_pass(int nx, int nz, int ny, const float *qin,
+                     const float *U, const float *V, const float *W,
+                     const float *rho, const float *jaco, const float *dz, float *q)
+{
+    if (q != qin) memcpy(q, qin, sizeof(float) * (size_t)nx * nz * ny);
+    float *out = q;
+    float *tmp = NULL;
+    if (q == qin) { tmp = (float *)malloc(sizeof(float) * (size_t)nx * nz * ny); memcpy(tmp, qin, sizeof(float) * (size_t)nx * nz * ny); qin = tmp; }
+    for (int j = 1; j < ny - 1; ++j)
+        for (int k = 0; k < nz; ++k)
+            for (int i = 1; i < nx - 1; ++i) {
+                const size_t c = IDX(i, k, j);
+                const float r = rho ? rho[c] : 1.0f;
+                const float f1r = flux1(qin[c], qin[IDX(i + 1, k, j)], U[IDX(i + 1, k, j)]);
+                const float f1l = flux1(qin[IDX(i - 1, k, j)], qin[c], U[c]);
+                const float f3 = flux1(qin[c], qin[IDX(i, k, j + 1)], V[IDX(i, k, j + 1)]);
+                const float f4 = flux1(qin[IDX(i, k, j - 1)], qin[c], V[c]);
+                float qq = qin[c] - ((f1r - f1l) + (f3 - f4)) / (jaco[c] * r);
+                const float den = dz[c] * jaco[c] * r;
+                if (k == 0) {
+                    const float f5 = flux1(qin[c], qin[IDX(i, 1, j)], W[c]);
+                    qq = qq - f5 / den;
+                } else if (k == nz - 1) {
+                    const float f5b = flux1(qin[IDX(i, k - 1, j)], qin[c], W[IDX(i, k - 1, j)]);
+                    qq = qq - (qin[c] * W[c] - f5b) / den;
+                } else {
+                    const float f5t = flux1(qin[c], qin[IDX(i, k + 1, j)], W[c]);
+                    const float f5b = flux1(qin[IDX(i, k - 1, j)], qin[c], W[IDX(i, k - 1, j)]);
+                    qq = qq - (f5t - f5b) / den;
+                }
+                out[c] = qq;
+            }
+    free(tmp);
+}
+
+/* A3: anti-diffusive pseudo-velocities. src/physics/adv_mpdata.f90:107-255.
+ * w here is W_m/dz, G = jaco*rho.  u2,v2,w2 use the U/V/W staggering described above. */
+void orc_mpdata_fluxes(int nx, int nz, int ny, const float *q,
+                       const float *u, const float *v, const float *w, const float *G,
+                       float *u2, float *v2, float *w2)
+{
+    const size_t n = (size_t)nx * nz * ny;
+    memset(u2, 0, n * sizeof(float));
+    memset(v2, 0, n * sizeof(float));
+    memset(w2, 0, n * sizeof(float));
+#define Q(i,k,j) q[IDX(i,k,j)]
+    for (int j = 0; j < ny; ++j)
+        for (int k = 0; k < nz; ++k) {
+            /* U component: faces i=1..nx-1 (":134 if (i>0)" is always true) */
+            for (int i = 1; i < nx; ++i) {
+                const size_t c = IDX(i, k, j);
+                const float rx = Q(i, k, j), lx = Q(i - 1, k, j);
+                const float denomx = (rx + lx + 1e-10f);
+                const float Gs = G[c] + G[IDX(i - 1, k, j)];
+                float val = fabsf(u[c]) * (1 - fabsf(u[c]) / (0.5f * Gs));
+                val = val * (rx - lx) / denomx;
+                if (j > 0 && j < ny - 1) {   /* UxV :148-155 */
+                    const float eq = (Q(i, k, j + 1) - Q(i, k, j - 1) + Q(i - 1, k, j + 1) - Q(i - 1, k, j - 1)) /
+                                     (Q(i, k, j + 1) + Q(i, k, j - 1) + Q(i - 1, k, j + 1) + Q(i - 1, k, j - 1) + 1e-10f);
+                    const float ev = (1 / 4.0f) * (v[c] + v[IDX(i, k, j + 1)] + v[IDX(i - 1, k, j)] + v[IDX(i - 1, k, j + 1)]);
+                    val = val - 0.5f * u[c] * ev * eq / Gs;
+                }
+                if (k > 0 && k < nz - 1) {   /* UxW :160-167 */
+                    const float eq = (Q(i, k + 1, j) - Q(i, k - 1, j) + Q(i - 1, k + 1, j) - Q(i - 1, k - 1, j)) /
+                                     (Q(i, k + 1, j) + Q(i, k - 1, j) + Q(i - 1, k + 1, j) + Q(i - 1, k - 1, j) + 1e-10f);
+                    const float ev = (1 / 4.0f) * (w[c] + w[IDX(i, k - 1, j)] + w[IDX(i - 1, k, j)] + w[IDX(i - 1, k - 1, j)]);
+                    val = val - 0.5f * u[c] * ev * eq / Gs;
+                }
+                u2[c] = val;
+            }
+            /* V component :172-208 */
+            if (j > 0)
+                for (int i = 0; i < nx; ++i) {
+                    const size_t c = IDX(i, k, j);
+                    const float r = Q(i, k, j), l = Q(i, k, j - 1);
+                    const float denom = (r + l + 1e-10f);
+                    const float Gs = G[c] + G[IDX(i, k, j - 1)];
+                    float val = fabsf(v[c]) * (1 - fabsf(v[c]) / (0.5f * Gs));
+                    val = val * (r - l) / denom;
+                    {   /* VxU :189-195 (edge_q/edge_v are zero at i=0 and i=nx-1) */
+                        float eq = 0, ev = 0;
+                        if (i > 0 && i < nx - 1) {
+                            eq = (Q(i + 1, k, j - 1) - Q(i - 1, k, j) + Q(i + 1, k, j) - Q(i - 1, k, j - 1)) /
+                                 (Q(i + 1, k, j) + Q(i + 1, k, j - 1) + Q(i - 1, k, j) + Q(i - 1, k, j - 1) + 1e-10f);
+                            ev = (1 / 4.0f) * (u[IDX(i + 1, k, j)] + u[IDX(i + 1, k, j - 1)] + u[c] + u[IDX(i, k, j - 1)]);
+                        }
+                        val = val - 0.5f * v[c] * ev * eq / Gs;
+                    }
+                    if (k > 0 && k < nz - 1) {   /* VxW :200-207 */
+                        const float eq = (Q(i, k + 1, j - 1) - Q(i, k - 1, j) + Q(i, k + 1, j) - Q(i, k - 1, j - 1)) /
+                                         (Q(i, k + 1, j - 1) + Q(i, k - 1, j) + Q(i, k + 1, j) + Q(i, k - 1, j - 1) + 1e-10f);
+                        const float ev = (1 / 4.0f) * (w[c] + w[IDX(i, k - 1, j)] + w[IDX(i, k, j - 1)] + w[IDX(i, k - 1, j - 1)]);
+                        val = val - 0.5f * v[c] * ev * eq / Gs;
+                    }
+                    v2[c] = val;
+                }
+            /* W component :214-249 */
+            if (k == nz - 1) {
+                for (int i = 0; i < nx; ++i) w2[IDX(i, k, j)] = 0;
+            } else
+                for (int i = 0; i < nx; ++i) {
+                    const size_t c = IDX(i, k, j);
+                    const float r = Q(i, k + 1, j), l = Q(i, k, j);
+                    const float denom = (r + l + 1e-10f);
+                    const float Gs = G[IDX(i, k + 1, j)] + G[c];
+                    float val = fabsf(w[c]) * (1 - fabsf(w[c]) / (0.5f * Gs));
+                    val = val * (r - l) / denom;
+                    {   /* WxU :230-236 */
+                        float eq = 0, ev = 0;
+                        if (i > 0 && i < nx - 1) {
+                            eq = (Q(i + 1, k + 1, j) - Q(i - 1, k, j) + Q(i + 1, k, j) - Q(i - 1, k + 1, j)) /
+                                 (Q(i + 1, k, j) + Q(i + 1, k + 1, j) + Q(i - 1, k, j) + Q(i - 1, k + 1, j) + 1e-10f);
+                            ev = (1 / 4.0f) * (u[IDX(i + 1, k, j)] + u[IDX(i + 1, k + 1, j)] + u[c] + u[IDX(i, k + 1, j)]);
+                        }
+                        val = val - 0.5f * w[c] * ev * eq / Gs;
+                    }
+                    if (j > 0 && j < ny - 1) {   /* WxV :241-248 */
+                        const float eq = (Q(i, k + 1, j + 1) - Q(i, k, j - 1) + Q(i, k, j + 1) - Q(i, k + 1, j - 1)) /
+                                         (Q(i, k, j + 1) + Q(i, k + 1, j - 1) + Q(i, k + 1, j + 1) + Q(i, k, j - 1) + 1e-10f);
+                        const float ev = (1 / 4.0f) * (v[c] + v[IDX(i, k + 1, j)] + v[IDX(i, k, j + 1)] + v[IDX(i, k + 1, j + 1)]);
+                        val = val - 0.5f * w[c] * ev * eq / Gs;
+                    }
+                    w2[c] = val;
+                }
+        }
+#undef Q
+}
+
+static inline float max4(float a, float b, float c, float d) { return fmaxf(fmaxf(fmaxf(a, b), c), d); }
+static inline float min4(float a, float b, float c, float d) { return fminf(fminf(fminf(a, b), c), d); }
+
+/* A4 core: one 1-D line. src/physics/adv_mpdata_FCT_core.f90:47-116 (sequential, with the
+ * reference's carried variables).  q1[n], l[n]; U2[n-1]: face i between cells i and i+1. */
+static void fct_line(int n, const float *q1, const float *l, float *U2, float *f, int flux_is_w)
+{
+    float qmax_i = 0, qmin_i = 0, qmax_i2 = 0, qmin_i2 = 0;
+    float fin_i = 0, fout_i = 0, fin_i2 = 0, fout_i2 = 0;
+    for (int i = 0; i < n - 1; ++i) f[i] = flux1(q1[i], q1[i + 1], U2[i]);
+    for (int i = 0; i < n - 1; ++i) {
+        if (i == 0) {
+            qmax_i = max4(q1[i], q1[i + 1], l[i], l[i + 1]);
+            qmin_i = min4(q1[i], q1[i + 1], l[i], l[i + 1]);
+            qmax_i2 = fmaxf(max4(q1[i], q1[i + 1], q1[i + 2], l[i]), fmaxf(l[i + 1], l[i + 2]));
+            qmin_i2 = fminf(min4(q1[i], q1[i + 1], q1[i + 2], l[i]), fminf(l[i + 1], l[i + 2]));
+        } else if (i != n - 2) {
+            qmax_i = qmax_i2; qmin_i = qmin_i2;
+            qmax_i2 = fmaxf(max4(q1[i], q1[i + 1], q1[i + 2], l[i]), fmaxf(l[i + 1], l[i + 2]));
+            qmin_i2 = fminf(min4(q1[i], q1[i + 1], q1[i + 2], l[i]), fminf(l[i + 1], l[i + 2]));
+        } else {
+            qmax_i = qmax_i2; qmin_i = qmin_i2;
+            qmax_i2 = fmaxf(fmaxf(q1[i], q1[i + 1]), l[i]);
+            qmin_i2 = fminf(fminf(q1[i], q1[i + 1]), l[i]);
+        }
+        if (i != 0) { fin_i = fin_i2; fout_i = fout_i2; }
+        else if (flux_is_w) { fin_i = 0.f - fminf(0.f, f[i]); fout_i = fmaxf(0.f, f[i]); }
+        else { fin_i = 0; fout_i = 0; }
+        if (i != n - 2) {
+            fin_i2 = fmaxf(0.f, f[i]) - fminf(0.f, f[i + 1]);
+            fout_i2 = fmaxf(0.f, f[i + 1]) - fminf(0.f, f[i]);
+        } else if (flux_is_w) {
+            fin_i2 = fmaxf(0.f, f[i]) - fminf(0.f, f[i]);
+            fout_i2 = fmaxf(0.f, f[i]) - fminf(0.f, f[i]);
+        } else { fin_i2 = 0; fout_i2 = 0; }
+        if (U2[i] > 0) {
+            const float beta_out_i = (q1[i] - qmin_i) / (fout_i + 1e-15f);
+            const float beta_in_i2 = (qmax_i2 - q1[i + 1]) / (fin_i2 + 1e-15f);
+            U2[i] = fminf(fminf(1.f, beta_in_i2), beta_out_i) * U2[i];
+        } else if (U2[i] < 0) {
+            const float beta_in_i = (qmax_i - q1[i]) / (fin_i + 1e-15f);
+            const float beta_out_i2 = (q1[i + 1] - qmin_i2) / (fout_i2 + 1e-15f);
+            U2[i] = fminf(fminf(1.f, beta_in_i), beta_out_i2) * U2[i];
+        }
+    }
+}
+
+/* A4: src/physics/adv_mpdata.f90:257-354.  q = field before pass 1 ("l"), q2 = after pass 1. */
+void orc_flux_limiter(int nx, int nz, int ny, const float *q, const float *q2,
+                      float *u2, float *v2, float *w2)
+{
+    int nmax = nx > ny ? nx : ny; if (nz > nmax) nmax = nz;
+    float *q1 = (float *)malloc(sizeof(float) * nmax * 4);
+    float *l = q1 + nmax, *U2 = l + nmax, *f = U2 + nmax;
+    for (int j = 1; j < ny - 1; ++j) {
+        for (int k = 0; k < nz; ++k) {            /* x-lines :295-304 */
+            for (int i = 0; i < nx; ++i) { q1[i] = q2[IDX(i, k, j)]; l[i] = q[IDX(i, k, j)]; }
+            for (int i = 0; i < nx - 1; ++i) U2[i] = u2[IDX(i + 1, k, j)];
+            fct_line(nx, q1, l, U2, f, 0);
+            for (int i = 0; i < nx - 1; ++i) u2[IDX(i + 1, k, j)] = U2[i];
+        }
+        for (int i = 1; i < nx - 1; ++i) {        /* z-lines :313-323 */
+            for (int k = 0; k < nz; ++k) { q1[k] = q2[IDX(i, k, j)]; l[k] = q[IDX(i, k, j)]; }
+            for (int k = 0; k < nz - 1; ++k) U2[k] = w2[IDX(i, k, j)];
+            fct_line(nz, q1, l, U2, f, 1);
+            for (int k = 0; k < nz - 1; ++k) w2[IDX(i, k, j)] = U2[k];
+            w2[IDX(i, nz - 1, j)] = 0;
+        }
+    }
+    for (int i = 0; i < nx; ++i)                  /* y-lines :340-350, all i,k */
+        for (int k = 0; k < nz; ++k) {
+            for (int j = 0; j < ny; ++j) { q1[j] = q2[IDX(i, k, j)]; l[j] = q[IDX(i, k, j)]; }
+            for (int j = 0; j < ny - 1; ++j) U2[j] = v2[IDX(i, k, j + 1)];
+            fct_line(ny, q1, l, U2, f, 0);
+            for (int j = 0; j < ny - 1; ++j) v2[IDX(i, k, j + 1)] = U2[j];
+        }
+    free(q1);
+}
+
+/* A5: src/physics/adv_mpdata.f90:356-418 (order 1 or 2).  rho==NULL means rho=1. */
+void orc_advect3d_mpdata(int nx, int nz, int ny, float *q, const float *U, const float *V, const float *W,
+                         const float *rho, const float *jaco, const float *dz, int order, int fct)
+{
+    const size_t n = (size_t)nx * nz * ny;
+    float *q2 = (float *)malloc(n * sizeof(float) * 7);
+    float *u2 = q2 + n, *v2 = u2 + n, *w2 = v2 + n, *wdz = w2 + n, *G = wdz + n, *qnew = G + n;
+    orc_upwind_pass(nx, nz, ny, q, U, V, W, rho, jaco, dz, q2);
+    if (order < 2) { memcpy(q, q2, n * sizeof(float)); free(q2); return; }
+    for (size_t c = 0; c < n; ++c) { wdz[c] = W[c] / dz[c]; G[c] = jaco[c] * (rho ? rho[c] : 1.0f); }
+    orc_mpdata_fluxes(nx, nz, ny, q2, U, V, wdz, G, u2, v2, w2);
+    for (size_t c = 0; c < n; ++c) { u2[c] = u2[c] * 0.5f; v2[c] = v2[c] * 0.5f; w2[c] = w2[c] * 0.5f * dz[c]; }
+    if (fct) orc_flux_limiter(nx, nz, ny, q, q2, u2, v2, w2);
+    orc_upwind_pass(nx, nz, ny, q2, u2, v2, w2, rho, jaco, dz, qnew);
+    memcpy(q, qnew, n * sizeof(float));
+    free(q2);
+}
+
+/* Same call shape as oracle/ref_shim.f90:ref_advect (drivers upwind :380 / mpdata :463). */
+void orc_advect(int scheme, int nx, int nz, int ny, int nvars, float *q,
+                const float *u, const float *v, const float *w, const float *rho,
+                const float *jaco, const float *jaco_u, const float *jaco_v, const float *jaco_w,
+                const float *dz3d, float dx, float dt, int advect_density, int mpdata_order, int fct, int nsteps)
+{
+    const size_t n = (size_t)nx * nz * ny;
+    float *U = (float *)malloc(n * sizeof(float) * 3), *V = U + n, *W = V + n;
+    const float *r = advect_density ? rho : NULL;
+    for (int s = 0; s < nsteps; ++s) {
+        orc_setup_winds(scheme, nx, nz, ny, u, v, w, rho, jaco_u, jaco_v, jaco_w, dx, dt, advect_density, U, V, W);
+        for (int m = 0; m < nvars; ++m) {
+            float *qm = q + (size_t)m * n;
+            if (scheme == 1) orc_upwind_pass(nx, nz, ny, qm, U, V, W, r, jaco, dz3d, qm);
+            else orc_advect3d_mpdata(nx, nz, ny, qm, U, V, W, r, jaco, dz3d, mpdata_order, fct);
+        }
+    }
+    free(U);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * M1: mp_simple (SB04 "simple" scheme).  src/physics/mp_simple.f90
+ * ------------------------------------------------------------------------------------------ */
+#define LH_vapor 2.26E6f
+#define dLHvdt 2400.0f
+#define LH_liquid 3.34E5f
+#define heat_capacity 1006.0f
+#define SMALL_VALUE 1E-30f
+#define freezing_threshold 273.15f
+#define snow_fall_rate 1.5f
+#define rain_fall_rate 10.0f
+#define snow_cloud_init 0.0001f
+#define rain_cloud_init 0.0001f
+
+typedef struct { float cloud2rain, cloud2snow; int err; } mps_consts;
+
+static float sat_mr(float temperature, float pressure)
+{   /* :146-182 */
+    float a, b;
+    if (temperature < freezing_threshold) { a = 21.8745584f; b = 7.66f; }
+    else { a = 17.2693882f; b = 35.86f; }
+    float e_s = 610.78f * expf(a * (temperature - 273.16f) / (temperature - b));
+    if ((pressure - e_s) <= 0) e_s = pressure * 0.99999f;
+    return 0.6219907f * e_s / (pressure - e_s);
+}
+
+static void cloud_conversion(float pressure, float *temperature, float *qv, float *qc, float *qvsat)
+{   /* :198-280 */
+    const float maxerr = 1e-4f;
+    int iteration = 0;
+    float lastqv = *qv + maxerr * 2;
+    const float vapor2temp = (LH_vapor + (373.15f - *temperature) * dLHvdt) / heat_capacity;
+    const float pre_qc = *qc, pre_t = *temperature;
+    float excess = 0;
+    while ((fabsf(lastqv - *qv) > maxerr) && (iteration < 15)) {
+        iteration = iteration + 1;
+        lastqv = *qv;
+        *qvsat = sat_mr(*temperature, pressure);
+        if (*qv > *qvsat) {
+            excess = (*qv - *qvsat) * 0.5f;
+            *temperature = *temperature + (excess * vapor2temp);
+            *qv = *qv - excess;
+            *qc = *qc + excess;
+        } else if (*qc > 0) {
+            excess = (*qvsat - *qv) * 0.5f;
+            if (excess < *qc) {
+                *temperature = *temperature - (excess * vapor2temp);
+                *qv = *qv + excess;
+                *qc = *qc - excess;
+            } else {
+                *qv = *qv + *qc;
+                *temperature = *temperature - (*qc * vapor2temp);
+                excess = *qc;
+                *qc = 0.f;
+            }
+        }
+    }
+    if (iteration == 15) {
+        *qv = sat_mr(pre_t, pressure);
+        *temperature = pre_t;
+        *qc = pre_qc;
+    }
+    *qc = fmaxf(*qc, 0.f);
+}
+
+static void cloud2hydrometeor(float *qc, float *q, float conversion, float qcmin)
+{   /* :295-315 */
+    float delta;
+    if (*qc > qcmin) delta = *qc - (*qc * conversion); else delta = 0;
+    if (delta < *qc) { *qc = *qc - delta; *q = *q + delta; }
+    else { *q = *q + *qc; *qc = 0.f; }
+    *qc = fmaxf(*qc, 0.f);
+}
+
+static void phase_change(float *temperature, float *q1, float qmax, float *q2, float Lheat, float change_rate, int *err)
+{   /* :333-362 */
+    const float mass2temp = Lheat / heat_capacity;
+    float delta = (qmax - *q2) * change_rate;
+    if (delta > *q1) delta = *q1;
+    if (delta > ((qmax - *q2) * 0.99f)) delta = (qmax - *q2) * 0.99f;
+    *q1 = *q1 - delta;
+    if (*q1 < 0) {
+        if ((*q1 + SMALL_VALUE) < 0) *q1 = 0;
+        else *err = 1;          /* the reference prints and STOPs here */
+    }
+    *q2 = *q2 + delta;
+    *temperature = *temperature + delta * mass2temp;
+}
+
+static void mp_conversions(float pressure, float *temperature, float *qv, float *qc, float *qr, float *qs, mps_consts *C)
+{   /* :381-420 */
+    float qvsat = 0;
+    const float L_melt = -1 * LH_liquid;
+    const float L_evap = -1 * (LH_vapor + (373.15f - *temperature) * dLHvdt);
+    const float L_subl = L_melt + L_evap;
+    cloud_conversion(pressure, temperature, qv, qc, &qvsat);
+    if ((*qc + *qr + *qs) > SMALL_VALUE) {
+        if (*qc > SMALL_VALUE) {
+            if (*temperature > freezing_threshold) {
+                cloud2hydrometeor(qc, qr, C->cloud2rain, rain_cloud_init);
+                if (*qs > SMALL_VALUE)
+                    phase_change(temperature, qs, 100.f, qr, L_melt, C->cloud2rain, &C->err);
+            } else
+                cloud2hydrometeor(qc, qs, C->cloud2snow, snow_cloud_init);
+        }
+        if (*qv < qvsat) {
+            if (*qr > SMALL_VALUE) phase_change(temperature, qr, qvsat, qv, L_evap, C->cloud2rain / 2, &C->err);
+            if (*qs > SMALL_VALUE) phase_change(temperature, qs, qvsat, qv, L_subl, C->cloud2snow / 2, &C->err);
+        }
+    }
+}
+
+static float sediment(float *q, const float *v, const float *rho, const float *dz, int nz, int kts, int kte, float *flux)
+{   /* :437-459, 0-based kts..kte inclusive; kme = nz-1 */
+    const float sed = v[kts] * q[kts] * rho[kts];
+    q[kts] = q[kts] - (sed / dz[kts] / rho[kts]);
+    const int top = (kte < nz - 2) ? kte : nz - 2;
+    for (int i = kts; i <= top; ++i) flux[i] = v[i + 1] * q[i + 1] * rho[i + 1];
+    for (int i = kts; i <= top; ++i) {
+        q[i] = q[i] + flux[i] / (rho[i] * dz[i]);
+        q[i + 1] = q[i + 1] - flux[i] / (rho[i + 1] * dz[i + 1]);
+    }
+    return sed;
+}
+
+static void mp_simple_column(float *pressure, float *temperature, float *rho, float *qv, float *qc, float *qr, float *qs,
+                             float *rain, float *snow, float dt, const float *dz, int nz, int kts, int kte, mps_consts *C,
+                             float *fall_rate, float *flux)
+{   /* :481-566 */
+    const float L_melt = -1 * LH_liquid;
+    for (int i = kts; i <= kte; ++i)
+        mp_conversions(pressure[i], &temperature[i], &qv[i], &qc[i], &qr[i], &qs[i], C);
+    float mx = qr[0];
+    for (int i = 1; i < nz; ++i) mx = fmaxf(mx, qr[i]);
+    if (mx > SMALL_VALUE) {
+        float m = dt / dz[0] * rain_fall_rate;
+        for (int i = 1; i < nz; ++i) m = fmaxf(m, dt / dz[i] * rain_fall_rate);
+        const float cfl = ceilf(m);
+        for (int i = 0; i < nz; ++i) fall_rate[i] = dt * rain_fall_rate / cfl;
+        const int ncfl = (int)lroundf(cfl);
+        for (int s = 1; s <= ncfl; ++s) {
+            *rain = *rain + sediment(qr, fall_rate, rho, dz, nz, kts, kte, flux);
+            for (int i = kts; i <= kte; ++i) {
+                const float L_evap = -1 * (LH_vapor + (373.15f - temperature[i]) * dLHvdt);
+                const float qvsat = sat_mr(temperature[i], pressure[i]);
+                if (qv[i] < qvsat)
+                    if (qr[i] > SMALL_VALUE)
+                        phase_change(&temperature[i], &qr[i], qvsat, &qv[i], L_evap, C->cloud2rain / (2 * ncfl), &C->err);
+            }
+        }
+    }
+    mx = qs[0];
+    for (int i = 1; i < nz; ++i) mx = fmaxf(mx, qs[i]);
+    if (mx > SMALL_VALUE) {
+        float m = dt / dz[0] * snow_fall_rate;
+        for (int i = 1; i < nz; ++i) m = fmaxf(m, dt / dz[i] * snow_fall_rate);
+        const float cfl = ceilf(m);
+        for (int i = 0; i < nz; ++i) fall_rate[i] = dt * snow_fall_rate / cfl;
+        const int ncfl = (int)lroundf(cfl);
+        for (int s = 1; s <= ncfl; ++s) {
+            const float snowfall = sediment(qs, fall_rate, rho, dz, nz, kts, kte, flux);
+            *snow = *snow + snowfall;
+            *rain = *rain + snowfall;
+            for (int i = kts; i <= kte; ++i) {
+                const float L_evap = -1 * (LH_vapor + (373.15f - temperature[i]) * dLHvdt);
+                const float L_subl = L_melt + L_evap;
+                const float qvsat = sat_mr(temperature[i], pressure[i]);
+                if (qv[i] < qvsat)
+                    if (qs[i] > SMALL_VALUE)
+                        phase_change(&temperature[i], &qs[i], qvsat, &qv[i], L_subl, C->cloud2snow / (2 * ncfl), &C->err);
+            }
+        }
+    }
+}
+
+/* mp_simple_driver :595-646.  Tile bounds are 1-based inclusive like the reference (ims=jms=kms=1).
+ * Returns nonzero if the reference would have hit its STOP in phase_change. */
+int orc_mp_simple(int nx, int nz, int ny, float *pressure, float *th, const float *pii, float *rho,
+                  float *qv, float *qc, float *qr, float *qs, float *rain, float *snow, float dt, const float *dz,
+                  int its, int ite, int jts, int jte, int kts, int kte)
+{
+    mps_consts C;
+    C.cloud2snow = expf(-1.0f * (1 / 2000.0f) * dt);
+    C.cloud2rain = expf(-1.0f * (1 / 500.0f) * dt);
+    C.err = 0;
+    float *col = (float *)malloc(sizeof(float) * nz * 10);
+    float *p1 = col, *t1 = p1 + nz, *r1 = t1 + nz, *v1 = r1 + nz, *c1 = v1 + nz, *rr1 = c1 + nz, *s1 = rr1 + nz,
+          *d1 = s1 + nz, *fall = d1 + nz, *flux = fall + nz;
+    for (int j = jts - 1; j <= jte - 1; ++j)
+        for (int i = its - 1; i <= ite - 1; ++i) {
+            for (int k = 0; k < nz; ++k) {
+                const size_t c = IDX(i, k, j);
+                p1[k] = pressure[c]; t1[k] = th[c] * pii[c]; r1[k] = rho[c]; v1[k] = qv[c]; c1[k] = qc[c];
+                rr1[k] = qr[c]; s1[k] = qs[c]; d1[k] = dz[c];
+            }
+            mp_simple_column(p1, t1, r1, v1, c1, rr1, s1, &rain[i + (size_t)nx * j], &snow[i + (size_t)nx * j], dt, d1,
+                             nz, kts - 1, kte - 1, &C, fall, flux);
+            for (int k = 0; k < nz; ++k) {
+                const size_t c = IDX(i, k, j);
+                th[c] = t1[k] / pii[c]; qv[c] = v1[k]; qc[c] = c1[k]; qr[c] = rr1[k]; qs[c] = s1[k];
+            }
+        }
+    free(col);
+    return C.err;
+}

@@ -1,0 +1,67 @@
+"""oracle/orc.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+ctypes front-end for oracle/liboracle.so (the plain-C CPU restatement, oracle/icar_oracle.c).
+Same call shapes as oracle/ref.py so tests can swap one for the other.
+Arrays: numpy float32, C-order (ny, nz, nx) == Fortran (i,k,j).
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return ctypes.c_void_p(0)
+    assert a.dtype in (np.float32, np.float64, np.int32) and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f(x):
+    return ctypes.c_float(float(x))
+
+
+def _i(x):
+    return ctypes.c_int(int(x))
+
+
+def setup_winds(scheme, u, v, w, rho, jaco_u, jaco_v, jaco_w, dx, dt, advect_density=False):
+    ny, nz, nx = w.shape
+    U = np.zeros((ny, nz, nx), np.float32); V = np.zeros_like(U); W = np.zeros_like(U)
+    lib().orc_setup_winds(_i(scheme), _i(nx), _i(nz), _i(ny), _p(u), _p(v), _p(w), _p(rho), _p(jaco_u),
+                          _p(jaco_v), _p(jaco_w), _f(dx), _f(dt), _i(advect_density), _p(U), _p(V), _p(W))
+    return U, V, W
+
+
+def advect(scheme, q, u, v, w, rho, jaco, jaco_u, jaco_v, jaco_w, dz3d, dz_levels, dx, dt,
+           advect_density=False, mpdata_order=2, fct=True, nsteps=1):
+    nvars, ny, nz, nx = q.shape
+    lib().orc_advect(_i(scheme), _i(nx), _i(nz), _i(ny), _i(nvars), _p(q), _p(u), _p(v), _p(w), _p(rho),
+                     _p(jaco), _p(jaco_u), _p(jaco_v), _p(jaco_w), _p(dz3d), _f(dx), _f(dt),
+                     _i(advect_density), _i(mpdata_order), _i(fct), _i(nsteps))
+    return q
+
+
+def mp_simple(pressure, th, pii, rho, qv, qc, qr, qs, rain, snow, dt, dz, its, ite, jts, jte, kts, kte):
+    ny, nz, nx = qv.shape
+    fn = lib().orc_mp_simple
+    fn.restype = ctypes.c_int
+    return fn(_i(nx), _i(nz), _i(ny), _p(pressure), _p(th), _p(pii), _p(rho), _p(qv), _p(qc), _p(qr),
+              _p(qs), _p(rain), _p(snow), _f(dt), _p(dz), _i(its), _i(ite), _i(jts), _i(jte), _i(kts), _i(kte))

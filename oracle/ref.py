@@ -1,0 +1,94 @@
+"""oracle/ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+ctypes front-end for oracle/_ref/libicar_ref.so: the *reference's own kernels*
+(/root/reference/src/physics/{adv_mpdata,advect,mp_simple,mp_thompson}.f90) compiled
+unmodified by oracle/build_ref.sh behind our bind(C) shim oracle/ref_shim.f90.
+
+Only tests/, tests/golden/make_golden.py, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this.  All arrays are numpy float32, Fortran (i,k,j) order
+expressed as C-order arrays of shape (ny, nz, nx)  [x fastest].
+
+The reference keeps module-level wind arrays sized at first call: one grid size per
+process for the advection entry points (use `run_isolated` for several sizes).
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_ref", "libicar_ref.so")
+_lib = None
+
+THOMPSON_DEFAULTS = np.array(
+    # Nt_c, TNO, am_s, rho_g, av_s, bv_s, fv_s, av_g, bv_g, av_i, Ef_si, Ef_rs, Ef_rg, Ef_ri,
+    # C_cubes, C_sqrd, mu_r, t_adjust      (src/objects/options_obj.f90:1259-1284)
+    [100.e6, 5.0, 0.069, 500.0, 40.0, 0.55, 100.0, 442.0, 0.89, 1847.5, 0.05, 0.95, 0.75, 0.95,
+     0.5, 0.3, 0.0, 0.0], dtype=np.float32)
+
+
+def available():
+    return os.path.exists(_LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libicar_ref.so not built (run oracle/build_ref.sh "
+                               "in the container that has /root/reference)")
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f(x):
+    return ctypes.c_float(float(x))
+
+
+def advect(scheme, q, u, v, w, rho, jaco, jaco_u, jaco_v, jaco_w, dz3d, dz_levels, dx, dt,
+           advect_density=False, mpdata_order=2, fct=True, nsteps=1):
+    """q: (nvars, ny, nz, nx) float32, advanced in place.  scheme 1=upwind 2=mpdata."""
+    nvars, ny, nz, nx = q.shape
+    assert u.shape == (ny, nz, nx + 1) and v.shape == (ny + 1, nz, nx) and w.shape == (ny, nz, nx)
+    lib().ref_advect(ctypes.c_int(scheme), ctypes.c_int(nx), ctypes.c_int(nz), ctypes.c_int(ny),
+                     ctypes.c_int(nvars), _p(q), _p(u), _p(v), _p(w), _p(rho), _p(jaco), _p(jaco_u),
+                     _p(jaco_v), _p(jaco_w), _p(dz3d), _p(np.ascontiguousarray(dz_levels, np.float32)),
+                     _f(dx), _f(dt), ctypes.c_int(int(advect_density)), ctypes.c_int(mpdata_order),
+                     ctypes.c_int(int(fct)), ctypes.c_int(nsteps))
+    return q
+
+
+def mp_simple(pressure, th, pii, rho, qv, qc, qr, qs, rain, snow, dt, dz, its, ite, jts, jte, kts, kte):
+    """All 3-D arrays (ny,nz,nx) float32 in place; rain/snow (ny,nx). 1-based inclusive tile bounds."""
+    ny, nz, nx = qv.shape
+    lib().ref_mp_simple(ctypes.c_int(nx), ctypes.c_int(nz), ctypes.c_int(ny), _p(pressure), _p(th),
+                        _p(pii), _p(rho), _p(qv), _p(qc), _p(qr), _p(qs), _p(rain), _p(snow), _f(dt),
+                        _p(dz), *[ctypes.c_int(int(x)) for x in (its, ite, jts, jte, kts, kte)])
+
+
+def thompson_init(params=None, flags=(0, 0), workdir=None):
+    """Runs the reference thompson_init; it caches its tables as *.dat in the CWD (56 s cold)."""
+    params = THOMPSON_DEFAULTS if params is None else np.asarray(params, np.float32)
+    fl = np.asarray(flags, np.int32)
+    cwd = os.getcwd()
+    if workdir:
+        os.makedirs(workdir, exist_ok=True)
+        os.chdir(workdir)
+    try:
+        lib().ref_thompson_init(_p(np.ascontiguousarray(params)), fl.ctypes.data_as(ctypes.c_void_p))
+    finally:
+        os.chdir(cwd)
+
+
+def thompson(qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, dt, rainnc, rainncv, snownc, graupelnc, sr,
+             ids, ide, jds, jde, kds, kde, its, ite, jts, jte, kts, kte):
+    ny, nz, nx = qv.shape
+    lib().ref_thompson(ctypes.c_int(nx), ctypes.c_int(nz), ctypes.c_int(ny),
+                       _p(qv), _p(qc), _p(qr), _p(qi), _p(qs), _p(qg), _p(ni), _p(nr), _p(th), _p(pii),
+                       _p(p), _p(dz), _f(dt), _p(rainnc), _p(rainncv), _p(snownc), _p(graupelnc), _p(sr),
+                       *[ctypes.c_int(int(x)) for x in (ids, ide, jds, jde, kds, kde,
+                                                        its, ite, jts, jte, kts, kte)])

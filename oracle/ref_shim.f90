@@ -1,0 +1,124 @@
+!> oracle/ref_shim.f90 -- TEST INFRASTRUCTURE, NOT PRODUCT.
+!!
+!! bind(C) entry points around the *unmodified reference kernels* compiled from
+!! /root/reference/src by oracle/build_ref.sh into oracle/_ref/libicar_ref.so.
+!! This file is our own code: it only fills a reference `domain_t`/`options_t`
+!! from plain C arrays and calls the reference's public procedures
+!!   mpdata(domain,options,dt)          src/physics/adv_mpdata.f90:463
+!!   upwind(domain,options,dt)          src/physics/advect.f90:380
+!!   mp_simple_driver(...)              src/physics/mp_simple.f90:595
+!!   thompson_init(mp_options)          src/physics/mp_thompson.f90:342
+!!   mp_gt_driver(...)                  src/physics/mp_thompson.f90:772
+!! All arrays are Fortran order (i,k,j), REAL(4), lower bound 1.
+!!
+!! NOTE (module SAVE state in the reference): adv_mpdata/adv_upwind keep private
+!! allocatable U_m,V_m,W_m sized on first call, so ONE grid size per process.
+module icar_ref_shim
+  use iso_c_binding
+  use icar_constants
+  use options_interface, only: options_t
+  use options_types,     only: mp_options_type
+  use domain_interface,  only: domain_t
+  use adv_mpdata,        only: mpdata
+  use adv_upwind,        only: upwind
+  use module_mp_simple,  only: mp_simple_driver
+  use module_mp_thompson,only: thompson_init, mp_gt_driver
+  implicit none
+  type(options_t), save :: options
+  type(domain_t), allocatable, save :: domain
+  integer, save :: cur_nx = -1, cur_nz = -1, cur_ny = -1
+contains
+
+  !> scheme: 1 = upwind (kADV_UPWIND), 2 = mpdata (kADV_MPDATA)
+  !! q is (nx,nz,ny,nvars): each variable is advected by pointing
+  !! domain%water_vapor%data_3d at it (every advected scalar goes through the same advect3d).
+  subroutine ref_advect(scheme, nx, nz, ny, nvars, q, u, v, w, rho, jaco, jaco_u, jaco_v, jaco_w, &
+                        dz3d, dz_levels, dx, dt, advect_density, mpdata_order, fct, nsteps) bind(C, name="ref_advect")
+    integer(c_int), value :: scheme, nx, nz, ny, nvars, advect_density, mpdata_order, fct, nsteps
+    real(c_float), value :: dx, dt
+    real(c_float), target, intent(inout) :: q(nx,nz,ny,nvars)
+    real(c_float), target, intent(in) :: u(nx+1,nz,ny), v(nx,nz,ny+1), w(nx,nz,ny), rho(nx,nz,ny)
+    real(c_float), intent(in) :: jaco(nx,nz,ny), jaco_u(nx+1,nz,ny), jaco_v(nx,nz,ny+1), jaco_w(nx,nz,ny)
+    real(c_float), intent(in) :: dz3d(nx,nz,ny), dz_levels(nz)
+    integer :: n, s
+
+    if (.not.allocated(domain)) allocate(domain)
+    if (cur_nx /= -1 .and. (cur_nx/=nx .or. cur_nz/=nz .or. cur_ny/=ny)) then
+       print *, "ref_advect: reference module state is sized for one grid per process"
+       error stop
+    endif
+    cur_nx = nx; cur_nz = nz; cur_ny = ny
+    domain%grid%ims=1; domain%grid%ime=nx; domain%grid%jms=1; domain%grid%jme=ny; domain%grid%kms=1; domain%grid%kme=nz
+    domain%ims=1; domain%ime=nx; domain%jms=1; domain%jme=ny; domain%kms=1; domain%kme=nz
+    domain%dx = dx
+    domain%u%data_3d => u
+    domain%v%data_3d => v
+    domain%w%data_3d => w
+    domain%density%data_3d => rho
+    if (.not.allocated(domain%jacobian)) then
+       allocate(domain%jacobian(nx,nz,ny), domain%jacobian_u(nx+1,nz,ny), domain%jacobian_v(nx,nz,ny+1), &
+                domain%jacobian_w(nx,nz,ny), domain%advection_dz(nx,nz,ny))
+    endif
+    domain%jacobian = jaco; domain%jacobian_u = jaco_u; domain%jacobian_v = jaco_v; domain%jacobian_w = jaco_w
+    domain%advection_dz = dz3d
+    options%parameters%dz_levels(1:nz) = dz_levels
+    options%parameters%advect_density = (advect_density /= 0)
+    options%parameters%debug = .false.
+    options%vars_to_advect = 0
+    options%vars_to_advect(kVARS%water_vapor) = 1
+    options%adv_options%mpdata_order = mpdata_order
+    options%adv_options%flux_corrected_transport = (fct /= 0)
+    do s = 1, nsteps
+      do n = 1, nvars
+        domain%water_vapor%data_3d => q(:,:,:,n)
+        if (scheme == 1) then
+          call upwind(domain, options, dt)
+        else
+          call mpdata(domain, options, dt)
+        endif
+      enddo
+    enddo
+  end subroutine
+
+  subroutine ref_mp_simple(nx, nz, ny, pressure, th, pii, rho, qv, qc, qr, qs, rain, snow, dt, dz, &
+                           its, ite, jts, jte, kts, kte) bind(C, name="ref_mp_simple")
+    integer(c_int), value :: nx, nz, ny, its, ite, jts, jte, kts, kte
+    real(c_float), value :: dt
+    real(c_float), intent(inout) :: pressure(nx,nz,ny), th(nx,nz,ny), pii(nx,nz,ny), rho(nx,nz,ny)
+    real(c_float), intent(inout) :: qv(nx,nz,ny), qc(nx,nz,ny), qr(nx,nz,ny), qs(nx,nz,ny)
+    real(c_float), intent(inout) :: rain(nx,ny), snow(nx,ny)
+    real(c_float), intent(in) :: dz(nx,nz,ny)
+    call mp_simple_driver(pressure, th, pii, rho, qv, qc, qr, qs, rain, snow, dt, dz, &
+                          1, nx, 1, ny, 1, nz, its, ite, jts, jte, kts, kte)
+  end subroutine
+
+  !> params(18): Nt_c,TNO,am_s,rho_g,av_s,bv_s,fv_s,av_g,bv_g,av_i,Ef_si,Ef_rs,Ef_rg,Ef_ri,C_cubes,C_sqrd,mu_r,t_adjust
+  !! flags(2): Ef_rw_l, Ef_sw_l.  Writes/reads the reference's *.dat table caches in the CWD.
+  subroutine ref_thompson_init(params, flags) bind(C, name="ref_thompson_init")
+    real(c_float), intent(in) :: params(18)
+    integer(c_int), intent(in) :: flags(2)
+    type(mp_options_type) :: mpo
+    mpo%Nt_c=params(1); mpo%TNO=params(2); mpo%am_s=params(3); mpo%rho_g=params(4)
+    mpo%av_s=params(5); mpo%bv_s=params(6); mpo%fv_s=params(7); mpo%av_g=params(8); mpo%bv_g=params(9)
+    mpo%av_i=params(10); mpo%Ef_si=params(11); mpo%Ef_rs=params(12); mpo%Ef_rg=params(13); mpo%Ef_ri=params(14)
+    mpo%C_cubes=params(15); mpo%C_sqrd=params(16); mpo%mu_r=params(17); mpo%t_adjust=params(18)
+    mpo%Ef_rw_l = (flags(1)/=0); mpo%Ef_sw_l = (flags(2)/=0)
+    mpo%update_interval = 0; mpo%top_mp_level = 0; mpo%local_precip_fraction = 1
+    call thompson_init(mpo)
+  end subroutine
+
+  subroutine ref_thompson(nx, nz, ny, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, dt, &
+                          rainnc, rainncv, snownc, graupelnc, sr, &
+                          ids, ide, jds, jde, kds, kde, its, ite, jts, jte, kts, kte) bind(C, name="ref_thompson")
+    integer(c_int), value :: nx, nz, ny, ids, ide, jds, jde, kds, kde, its, ite, jts, jte, kts, kte
+    real(c_float), value :: dt
+    real(c_float), intent(inout), dimension(nx,nz,ny) :: qv, qc, qr, qi, qs, qg, ni, nr, th
+    real(c_float), intent(in), dimension(nx,nz,ny) :: pii, p, dz
+    real(c_float), intent(inout), dimension(nx,ny) :: rainnc, rainncv, snownc, graupelnc, sr
+    call mp_gt_driver(qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, dt, 1, rainnc, rainncv, &
+                      SNOWNC=snownc, GRAUPELNC=graupelnc, SR=sr, &
+                      ids=ids, ide=ide, jds=jds, jde=jde, kds=kds, kde=kde, &
+                      ims=1, ime=nx, jms=1, jme=ny, kms=1, kme=nz, &
+                      its=its, ite=ite, jts=jts, jte=jte, kts=kts, kte=kte)
+  end subroutine
+end module icar_ref_shim
