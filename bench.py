@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- grid-cell updates/s of ICAR's per-timestep 3-D grid update on MI355X.
+
+A "step" is one pass of the hot path of time_step.f90:440-551 over the tile:
+    update_dt (CFL reduction + co_min) -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect
+on the synthetic ideal case of SURVEY.md 8(d): 512x512x40 owned cells per GPU, MPDATA order 2 + FCT,
+Thompson microphysics (9 advected scalars) -- or mp_simple (5 scalars) with --mp simple.
+Inputs are resident in HBM before the timed region.  Scaling is weak: every rank owns a
+512x512x40 tile of a (512*ximages)x(512*yimages)x40 domain decomposed exactly like grid_obj.f90.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 measured copy
+
+
+def build_tile(args, rank, world, device):
+    from icar_amd import ideal
+    from icar_amd.grid import grid_t, domain_decomposition
+    from icar_amd.domain import domain_t
+    from icar_amd.options import options_t
+    from icar_amd.halo import HaloComm
+    from icar_amd.microphysics import mp_var_request, mp_init
+    from icar_amd.advection import adv_var_request, adv_init
+    from icar_amd.constants import kADV_MPDATA, kADV_UPWIND, kMP_THOMPSON, kMP_SB04, KVARS, ADVECTION_ORDER
+
+    xs, ys = domain_decomposition(args.nx, args.ny, world) if world > 1 else (1, 1)
+    # weak scaling: the global domain grows with the image grid so each tile keeps nx x ny owned cells
+    gnx, gny = args.nx * xs, args.ny * ys
+    g = grid_t().set_grid_dimensions(gnx, gny, args.nz, world, rank + 1)
+    tnx, tny = g.ime - g.ims + 1, g.jme - g.jms + 1
+    case = ideal.make_case(tnx, tny, args.nz, hill_height=args.hill, noise=0.01, seed=1234 + rank, n_hydro=1)
+    # moisten + pre-cool so that the microphysics is active in a sizeable share of the columns
+    case["water_vapor"] = (case["water_vapor"] * np.float32(1.4)).astype(np.float32)
+    opt = options_t()
+    opt.physics.advection = kADV_UPWIND if args.adv == "upwind" else kADV_MPDATA
+    opt.physics.microphysics = {"thompson": kMP_THOMPSON, "simple": kMP_SB04, "none": 0}[args.mp]
+    opt.parameters.ideal = True
+    opt.parameters.dx = float(case["dx"])
+    opt.parameters.dz_levels = case["dz_levels"]
+    mp_var_request(opt); adv_var_request(opt)
+    comm = HaloComm(g, rank + 1) if world > 1 else None
+    d = domain_t(g, device=device, dx=float(case["dx"]), image=rank + 1, comm=comm)
+    d.set_stream(torch.cuda.current_stream().cuda_stream)
+    d.load_case(case)
+    d.exchange_vars = [n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0]
+    mp_init(opt, d); adv_init(d, opt)
+    return d, opt, case, g
+
+
+def one_step(d, opt, group=None, device=None, cool=0.0):
+    from icar_amd.time_step import update_dt
+    from icar_amd.microphysics import mp
+    from icar_amd.advection import advect
+    dt = update_dt(d, opt, group=group, device=device)
+    mp(d, opt, dt, halo=1)
+    d.halo_send()
+    mp(d, opt, dt, subset=1)
+    d.halo_retrieve()
+    advect(d, opt, dt)
+    d.model_time_seconds += dt
+    return dt
+
+
+def cpu_baseline(args, nscalars):
+    """The CPU restatement (oracle/, bit-identical to the compiled reference kernels) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    try:
+        from oracle import orc
+        from icar_amd import ideal
+        orc.build()
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "grid-cell updates/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+    nx, ny, nz = 128, 128, args.nz
+    c = ideal.make_case(nx, ny, nz, hill_height=args.hill, noise=0.01, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.4)).astype(np.float32)
+    dt = min(ideal.cfl_dt(c), 120.0)
+    names = ["water_vapor", "cloud_water", "rain", "snow", "potential_temperature", "cloud_ice", "graupel",
+             "ice_number", "rain_number"][:nscalars]
+    q = np.stack([c[n] for n in names]).copy()
+    rain = np.zeros((ny, nx), np.float32); snow = np.zeros((ny, nx), np.float32)
+    s = {k: c[k].copy() for k in ["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water",
+                                  "rain", "snow", "dz_mass"]}
+    scheme = 1 if args.adv == "upwind" else 2
+
+    def step():
+        if args.mp != "none":
+            # Thompson has no C port yet at this sample: mp_simple stands in and the sample string says so
+            orc.mp_simple(s["pressure"], s["potential_temperature"], s["exner"], s["density"], s["water_vapor"],
+                          s["cloud_water"], s["rain"], s["snow"], rain, snow, dt, s["dz_mass"], 2, nx - 1, 2, ny - 1, 1, nz)
+        orc.advect(scheme, q, c["u"], c["v"], c["w"], c["density"], c["jacobian"], c["jacobian_u"], c["jacobian_v"],
+                   c["jacobian_w"], c["advection_dz"], c["dz_levels"], float(c["dx"]), dt)
+
+    step()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 10.0 or n < 2:
+        step(); n += 1
+    el = time.perf_counter() - t0
+    cells = (nx - 2) * (ny - 2) * nz * n
+    mpname = {"thompson": "mp_simple standing in for Thompson", "simple": "mp_simple", "none": "no microphysics"}[args.mp]
+    return {"value": cells / el, "unit": "grid-cell updates/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{n} steps of {nx}x{ny}x{nz}, {args.adv} advection of {nscalars} scalars + {mpname}, "
+                      f"oracle/icar_oracle.c (bit-identical to the reference kernels) with OpenMP, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=512)
+    ap.add_argument("--ny", type=int, default=512)
+    ap.add_argument("--nz", type=int, default=40)
+    ap.add_argument("--hill", type=float, default=1000.0)
+    ap.add_argument("--adv", default="mpdata", choices=["mpdata", "upwind"])
+    ap.add_argument("--mp", default=os.environ.get("ICAR_BENCH_MP", "thompson"), choices=["thompson", "simple", "none"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from icar_amd import capi
+    d, opt, case, g = build_tile(args, rank, world, local)
+    lib = capi.lib()
+    nscal = sum(1 for v in opt.vars_to_advect.values() if v > 0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(d, opt, device=device)
+    barrier()
+    lib.icar_hip_timing_enable(d.ctx, 1); lib.icar_hip_timing_reset(d.ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dt = one_step(d, opt, device=device)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    own_cells = (g.ite - g.its + 1) * (g.jte - g.jts + 1) * args.nz
+    cells_t = torch.tensor([float(own_cells)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(cells_t)
+    total_cells = float(cells_t.item())
+
+    # roofline of the dominant kernel group: the MPDATA advection launches, HIP events on the ctx stream
+    tot = ctypes.c_double(); n = ctypes.c_int()
+    lib.icar_hip_timing_read(d.ctx, b"advect", ctypes.byref(tot), ctypes.byref(n))
+    adv_ms = tot.value / max(n.value, 1)
+    lib.icar_hip_timing_read(d.ctx, b"mp", ctypes.byref(tot), ctypes.byref(n))
+    mp_ms_step = tot.value / max(args.steps, 1)
+    mem_cells = d.nx * d.ny * d.nz
+    alg_bytes = mem_cells * (8 * nscal + 16)            # B_adv = 8N+16 bytes per cell
+    achieved = alg_bytes / (adv_ms * 1e-3) / 1e9 if adv_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "advect_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_advect_call")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        # liveness: how much of the tile the microphysics is doing work in
+        qc = d.get("cloud_water_mass"); qr = d.get("rain_mass")
+        active = float((((qc > 1e-8) | (qr > 1e-8)).any(axis=1)).mean())
+        out = {
+            "metric": "grid-cell updates/sec (advection+microphysics)",
+            "value": total_cells * args.steps / elapsed,
+            "unit": "grid-cell updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.nx}x{args.ny}x{args.nz} owned cells per GPU, {args.adv} order-2+FCT advection of "
+                                   f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
+                       "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",
+                       "dt_s": dt, "mp_active_column_fraction": active},
+            "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpdata_fluxes + k_mpdata_final)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
+                         "mp_ms_per_step": mp_ms_step},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, nscal)
+        print(json.dumps(out), flush=True)
+    d.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

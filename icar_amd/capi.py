@@ -1,0 +1,47 @@
+"""ctypes binding of libicar_hip.so (include/icar_hip.h).  No fallback: if the library is not
+built, or no gfx950 device is visible, every compute entry point raises IcarHipError."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libicar_hip.so")
+_lib = None
+
+
+class IcarHipError(RuntimeError):
+    pass
+
+
+# every symbol include/icar_hip.h declares (tests/test_abi.py cross-checks this list with the header)
+SYMBOLS = [
+    "icar_hip_ctx_create", "icar_hip_ctx_destroy", "icar_hip_set_stream", "icar_hip_synchronize",
+    "icar_hip_field_upload", "icar_hip_field_download", "icar_hip_field_fill", "icar_hip_field_device_ptr",
+    "icar_hip_field_count", "icar_hip_field_elem_size", "icar_hip_setup_winds", "icar_hip_advect",
+    "icar_hip_mp_simple", "icar_hip_thompson_init", "icar_hip_thompson", "icar_hip_mp_tiles",
+    "icar_hip_max_courant", "icar_hip_balance_uvw", "icar_hip_halo_count", "icar_hip_halo_pack",
+    "icar_hip_halo_unpack", "icar_hip_timing_enable", "icar_hip_timing_read", "icar_hip_timing_reset",
+    "icar_hip_last_error", "icar_hip_version",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IcarHipError(f"{LIB_PATH} is missing: run `python -m icar_amd.build` "
+                               "(there is no CPU fallback for the hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.icar_hip_last_error.restype = ctypes.c_char_p
+        L.icar_hip_version.restype = ctypes.c_char_p
+        L.icar_hip_field_count.restype = ctypes.c_size_t
+        L.icar_hip_field_elem_size.restype = ctypes.c_size_t
+        L.icar_hip_halo_count.restype = ctypes.c_size_t
+        L.icar_hip_field_count.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.icar_hip_halo_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise IcarHipError(f"{what}: {lib().icar_hip_last_error().decode()}")

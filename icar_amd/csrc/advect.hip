@@ -1,0 +1,468 @@
+// icar_amd/csrc/advect.hip -- scalar advection on gfx950 (rows A1-A5 of SURVEY.md section 8).
+//
+// Reference algorithm: src/physics/advect.f90 (upwind), src/physics/adv_mpdata.f90 +
+// adv_mpdata_FCT_core.f90 (MPDATA order 2 with flux-corrected transport).  Written from the
+// algorithm, not from the Fortran loop structure:
+//   * lanes run along i (the contiguous axis) so every global access is coalesced;
+//   * the Courant-number winds / jacobian / density are loaded once per thread and reused for all
+//     advected scalars of the batch (algorithmic traffic 8N+16 B/cell for the donor-cell pass);
+//   * the FCT limiter is never materialised: the final donor-cell pass limits its own six face
+//     pseudo-velocities on the fly (every face of adv_mpdata_FCT_core.f90 is independent given
+//     the unlimited fluxes), which removes a 12 B/cell write + 12 B/cell read per scalar;
+//   * advected scalars ping-pong between two device buffers so no copy-back pass exists.
+// Arithmetic follows the reference's operation order; compiled with -ffp-contract=off and
+// IEEE division so the result is bit-identical to the CPU reference.
+#include "ctx.h"
+
+#define BX 64
+#define BY 4
+
+__device__ __forceinline__ float flux1(float l, float r, float U)
+{   // donor-cell flux, src/physics/adv_mpdata.f90:40
+    return ((U + fabsf(U)) * l + (U - fabsf(U)) * r) / 2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1: U_m, V_m, W_m (+ W_m/dz used by the pseudo-velocity step, adv_mpdata.f90:379)
+// ------------------------------------------------------------------------------------------------
+template <int SCHEME, bool RHO>
+__global__ void __launch_bounds__(BX * BY)
+k_setup_winds(Dims d, const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
+              const float *__restrict__ rho, const float *__restrict__ ju, const float *__restrict__ jv,
+              const float *__restrict__ jw, const float *__restrict__ dz, float dt, float dx,
+              float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float *__restrict__ Wdz)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int k = blockIdx.y * BY + threadIdx.y;
+    const int j = blockIdx.z;
+    if (i >= d.nx || k >= d.nz) return;
+    const int c = d.idx(i, k, j);
+    const float r0 = RHO ? rho[c] : 1.0f;
+    float Uv = 0.0f, Vv = 0.0f, Wv;
+    if (i >= 1) {
+        const float rl = RHO ? rho[c - 1] : 1.0f;
+        const int cu = i + (d.nx + 1) * (k + d.nz * j);
+        if (SCHEME == 1) Uv = u[cu] * dt * ju[cu] * (r0 + rl) * 0.5f / dx;      // advect.f90:345
+        else             Uv = u[cu] * dt * (r0 + rl) * 0.5f * ju[cu] / dx;      // adv_mpdata.f90:500
+    }
+    if (j >= 1) {
+        const float rl = RHO ? rho[c - d.sj] : 1.0f;
+        if (SCHEME == 1) Vv = v[c] * dt * jv[c] * (r0 + rl) * 0.5f / dx;
+        else             Vv = v[c] * dt * (r0 + rl) * 0.5f * jv[c] / dx;
+    }
+    if (k < d.nz - 1) {
+        const float ru = RHO ? rho[c + d.sk] : 1.0f;
+        Wv = w[c] * dt * jw[c] * (ru + r0) * 0.5f;
+    } else
+        Wv = w[c] * dt * jw[c] * r0;
+    U[c] = Uv; V[c] = Vv; W[c] = Wv; Wdz[c] = Wv / dz[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2: donor-cell pass with winds shared by all scalars (advect.f90:139-175, adv_mpdata.f90:44-105)
+// ------------------------------------------------------------------------------------------------
+template <bool RHO>
+__global__ void __launch_bounds__(BX * BY)
+k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
+              const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ W,
+              const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int k = blockIdx.y * BY + threadIdx.y;
+    const int j = blockIdx.z;
+    if (i >= d.nx || k >= d.nz) return;
+    const int c = d.idx(i, k, j);
+    const bool interior = (i > 0) && (i < d.nx - 1) && (j > 0) && (j < d.ny - 1);
+    if (!interior) {
+        for (int m = 0; m < nv; ++m) out.p[m][c] = in.p[m][c];
+        return;
+    }
+    const float Ur = U[c + 1], Ul = U[c], Vn = V[c + d.sj], Vs = V[c], Wt = W[c];
+    const float Wb = (k > 0) ? W[c - d.sk] : 0.0f;
+    const float r = RHO ? rho[c] : 1.0f;
+    const float ja = jaco[c];
+    const float den_h = ja * r;
+    const float den_v = dz[c] * ja * r;
+    const bool bottom = (k == 0), top = (k == d.nz - 1);
+    for (int m = 0; m < nv; ++m) {
+        const float *__restrict__ q = in.p[m];
+        const float q0 = q[c];
+        const float f1r = flux1(q0, q[c + 1], Ur);
+        const float f1l = flux1(q[c - 1], q0, Ul);
+        const float f3 = flux1(q0, q[c + d.sj], Vn);
+        const float f4 = flux1(q[c - d.sj], q0, Vs);
+        float qq = q0 - ((f1r - f1l) + (f3 - f4)) / den_h;
+        if (bottom) {
+            qq = qq - flux1(q0, q[c + d.sk], Wt) / den_v;
+        } else if (top) {
+            qq = qq - (q0 * Wt - flux1(q[c - d.sk], q0, Wb)) / den_v;
+        } else {
+            qq = qq - (flux1(q0, q[c + d.sk], Wt) - flux1(q[c - d.sk], q0, Wb)) / den_v;
+        }
+        out.p[m][c] = qq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A3: anti-diffusive pseudo-velocities (adv_mpdata.f90:107-255) followed by the 0.5 / 0.5*dz
+// scaling of advect3d (:383-385).  One thread = the three faces "owned" by cell (i,k,j):
+// u2 on (i-1|i), v2 on (j-1|j), w2 above level k.
+// ------------------------------------------------------------------------------------------------
+template <bool RHO>
+__global__ void __launch_bounds__(BX * BY)
+k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int nv,
+                const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ Wz,
+                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int k = blockIdx.y * BY + threadIdx.y;
+    const int j = blockIdx.z;
+    if (i >= d.nx || k >= d.nz) return;
+    const int c = d.idx(i, k, j);
+    const int sk = d.sk, sj = d.sj;
+    const bool has_u = (i >= 1), has_v = (j >= 1), has_w = (k < d.nz - 1);
+    const bool j_in = (j > 0) && (j < d.ny - 1);
+    const bool k_in = (k > 0) && (k < d.nz - 1);
+    const bool i_in = (i > 0) && (i < d.nx - 1);
+
+    const float G0 = RHO ? jaco[c] * rho[c] : jaco[c];
+    // scalar-independent pieces (hoisted out of the per-scalar loop)
+    float u = 0, Gsu = 1, au = 0, cu_v = 0, cu_w = 0;
+    if (has_u) {
+        u = U[c];
+        Gsu = G0 + (RHO ? jaco[c - 1] * rho[c - 1] : jaco[c - 1]);
+        au = fabsf(u) * (1 - fabsf(u) / (0.5f * Gsu));
+        if (j_in) cu_v = 0.5f * u * ((1 / 4.0f) * (V[c] + V[c + sj] + V[c - 1] + V[c - 1 + sj]));
+        if (k_in) cu_w = 0.5f * u * ((1 / 4.0f) * (Wz[c] + Wz[c - sk] + Wz[c - 1] + Wz[c - 1 - sk]));
+    }
+    float v = 0, Gsv = 1, av = 0, cv_u = 0, cv_w = 0;
+    if (has_v) {
+        v = V[c];
+        Gsv = G0 + (RHO ? jaco[c - sj] * rho[c - sj] : jaco[c - sj]);
+        av = fabsf(v) * (1 - fabsf(v) / (0.5f * Gsv));
+        // edge_v is zero at the x edges (adv_mpdata.f90:186-195), so the term is -0.5*v*0*0/G = -0
+        const float ev = i_in ? (1 / 4.0f) * (U[c + 1] + U[c + 1 - sj] + U[c] + U[c - sj]) : 0.0f;
+        cv_u = 0.5f * v * ev;
+        if (k_in) cv_w = 0.5f * v * ((1 / 4.0f) * (Wz[c] + Wz[c - sk] + Wz[c - sj] + Wz[c - sk - sj]));
+    }
+    float w = 0, Gsw = 1, aw = 0, cw_u = 0, cw_v = 0, dzc = 0;
+    if (has_w) {
+        w = Wz[c];
+        Gsw = (RHO ? jaco[c + sk] * rho[c + sk] : jaco[c + sk]) + G0;
+        aw = fabsf(w) * (1 - fabsf(w) / (0.5f * Gsw));
+        const float ev = i_in ? (1 / 4.0f) * (U[c + 1] + U[c + 1 + sk] + U[c] + U[c + sk]) : 0.0f;
+        cw_u = 0.5f * w * ev;
+        if (j_in) cw_v = 0.5f * w * ((1 / 4.0f) * (V[c] + V[c + sk] + V[c + sj] + V[c + sk + sj]));
+        dzc = dz[c];
+    }
+
+    for (int m = 0; m < nv; ++m) {
+        const float *__restrict__ q = qin.p[m];
+        const float q0 = q[c];
+        // ---- U face (i-1 | i) : adv_mpdata.f90:134-168
+        float r_u2 = 0.0f;
+        if (has_u) {
+            const float lx = q[c - 1];
+            float val = au * (q0 - lx) / (q0 + lx + 1e-10f);
+            if (j_in) {
+                const float a = q[c + sj], b = q[c - sj], e = q[c - 1 + sj], f = q[c - 1 - sj];
+                const float eq = (a - b + e - f) / (a + b + e + f + 1e-10f);
+                val = val - cu_v * eq / Gsu;
+            }
+            if (k_in) {
+                const float a = q[c + sk], b = q[c - sk], e = q[c - 1 + sk], f = q[c - 1 - sk];
+                const float eq = (a - b + e - f) / (a + b + e + f + 1e-10f);
+                val = val - cu_w * eq / Gsu;
+            }
+            r_u2 = val * 0.5f;
+        }
+        u2o.p[m][c] = r_u2;
+        // ---- V face (j-1 | j) : :172-208
+        float r_v2 = 0.0f;
+        if (has_v) {
+            const float l = q[c - sj];
+            float val = av * (q0 - l) / (q0 + l + 1e-10f);
+            {
+                float eq = 0.0f;
+                if (i_in) {
+                    const float a = q[c + 1 - sj], b = q[c - 1], e = q[c + 1], f = q[c - 1 - sj];
+                    eq = (a - b + e - f) / (e + a + b + f + 1e-10f);
+                }
+                val = val - cv_u * eq / Gsv;
+            }
+            if (k_in) {
+                const float a = q[c + sk - sj], b = q[c - sk], e = q[c + sk], f = q[c - sk - sj];
+                const float eq = (a - b + e - f) / (a + b + e + f + 1e-10f);
+                val = val - cv_w * eq / Gsv;
+            }
+            r_v2 = val * 0.5f;
+        }
+        v2o.p[m][c] = r_v2;
+        // ---- W face (k | k+1) : :214-249
+        float r_w2 = 0.0f;
+        if (has_w) {
+            const float r = q[c + sk];
+            float val = aw * (r - q0) / (r + q0 + 1e-10f);
+            {
+                float eq = 0.0f;
+                if (i_in) {
+                    const float a = q[c + 1 + sk], b = q[c - 1], e = q[c + 1], f = q[c - 1 + sk];
+                    eq = (a - b + e - f) / (e + a + b + f + 1e-10f);
+                }
+                val = val - cw_u * eq / Gsw;
+            }
+            if (j_in) {
+                const float a = q[c + sk + sj], b = q[c - sj], e = q[c + sj], f = q[c + sk - sj];
+                const float eq = (a - b + e - f) / (e + f + a + b + 1e-10f);
+                val = val - cw_v * eq / Gsw;
+            }
+            r_w2 = val * 0.5f * dzc;
+        }
+        w2o.p[m][c] = r_w2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4 core: limited pseudo-velocity of ONE face between cells a and b=a+1 of a 1-D line
+// (adv_mpdata_FCT_core.f90:47-116 with the loop-carried values recomputed from their definition).
+//   qm1,q0,q1,q2 : field after pass 1 at cells a-1,a,b,b+1     lm1,l0,l1,l2 : field before pass 1
+//   Um,U0,Up     : unlimited pseudo-velocities on faces (a-1|a),(a|b),(b|b+1)
+//   first: a is the first cell of the line; last: b is the last cell; is_w: vertical line
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float q2,
+                                           float lm1, float l0, float l1, float l2,
+                                           float Um, float U0, float Up, bool first, bool last, bool is_w)
+{
+    if (!(U0 > 0.0f) && !(U0 < 0.0f)) return U0;
+    const float f0 = flux1(q0, q1, U0);
+    if (U0 > 0.0f) {
+        float qmin_i, fout_i;
+        if (first) {
+            qmin_i = fminf(fminf(q0, q1), fminf(l0, l1));
+            fout_i = is_w ? fmaxf(0.f, f0) : 0.0f;
+        } else {
+            const float fm = flux1(qm1, q0, Um);
+            qmin_i = fminf(fminf(fminf(qm1, q0), fminf(q1, lm1)), fminf(l0, l1));
+            fout_i = fmaxf(0.f, f0) - fminf(0.f, fm);
+        }
+        float qmax_i2, fin_i2;
+        if (!last) {
+            const float fp = flux1(q1, q2, Up);
+            qmax_i2 = fmaxf(fmaxf(fmaxf(q0, q1), fmaxf(q2, l0)), fmaxf(l1, l2));
+            fin_i2 = fmaxf(0.f, f0) - fminf(0.f, fp);
+        } else {
+            qmax_i2 = fmaxf(fmaxf(q0, q1), l0);
+            fin_i2 = is_w ? (fmaxf(0.f, f0) - fminf(0.f, f0)) : 0.0f;
+        }
+        const float beta_out_i = (q0 - qmin_i) / (fout_i + 1e-15f);
+        const float beta_in_i2 = (qmax_i2 - q1) / (fin_i2 + 1e-15f);
+        return fminf(fminf(1.f, beta_in_i2), beta_out_i) * U0;
+    } else {
+        float qmax_i, fin_i;
+        if (first) {
+            qmax_i = fmaxf(fmaxf(q0, q1), fmaxf(l0, l1));
+            fin_i = is_w ? (0.f - fminf(0.f, f0)) : 0.0f;
+        } else {
+            const float fm = flux1(qm1, q0, Um);
+            qmax_i = fmaxf(fmaxf(fmaxf(qm1, q0), fmaxf(q1, lm1)), fmaxf(l0, l1));
+            fin_i = fmaxf(0.f, fm) - fminf(0.f, f0);
+        }
+        float qmin_i2, fout_i2;
+        if (!last) {
+            const float fp = flux1(q1, q2, Up);
+            qmin_i2 = fminf(fminf(fminf(q0, q1), fminf(q2, l0)), fminf(l1, l2));
+            fout_i2 = fmaxf(0.f, fp) - fminf(0.f, f0);
+        } else {
+            qmin_i2 = fminf(fminf(q0, q1), l0);
+            fout_i2 = is_w ? (fmaxf(0.f, f0) - fminf(0.f, f0)) : 0.0f;
+        }
+        const float beta_in_i = (qmax_i - q0) / (fin_i + 1e-15f);
+        const float beta_out_i2 = (q1 - qmin_i2) / (fout_i2 + 1e-15f);
+        return fminf(fminf(1.f, beta_in_i), beta_out_i2) * U0;
+    }
+}
+
+// limited value of the face whose LEFT cell sits `off` elements before index cc along a line of
+// stride s; pos = line coordinate of the left cell, n = line length.
+__device__ __forceinline__ float limit_face(const float *__restrict__ q1f, const float *__restrict__ lf,
+                                            const float *__restrict__ U2, int ca, int cface, int s,
+                                            int pos, int n, bool is_w)
+{
+    // ca = index of left cell a; cface = index where the face (a|b) is stored; face (a-1|a) is at
+    // cface - s and face (b|b+1) at cface + s for all three staggerings used here.
+    const bool first = (pos == 0), last = (pos + 1 == n - 1);
+    const float q0 = q1f[ca], q1 = q1f[ca + s], l0 = lf[ca], l1 = lf[ca + s];
+    float qm1 = 0, lm1 = 0, Um = 0, q2 = 0, l2 = 0, Up = 0;
+    if (!first) { qm1 = q1f[ca - s]; lm1 = lf[ca - s]; Um = U2[cface - s]; }
+    if (!last)  { q2 = q1f[ca + 2 * s]; l2 = lf[ca + 2 * s]; Up = U2[cface + s]; }
+    return fct_limit(qm1, q0, q1, q2, lm1, l0, l1, l2, Um, U2[cface], Up, first, last, is_w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4+A2 fused: final donor-cell pass with per-scalar pseudo-velocities, limiting its own faces.
+//   qold = field before pass 1 ("l"), q1 = field after pass 1, out = new field (ping-pong partner)
+// ------------------------------------------------------------------------------------------------
+template <bool RHO, bool FCT>
+__global__ void __launch_bounds__(BX * BY)
+k_mpdata_final(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
+               const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int k = blockIdx.y * BY + threadIdx.y;
+    const int j = blockIdx.z;
+    if (i >= d.nx || k >= d.nz) return;
+    const int c = d.idx(i, k, j);
+    const int sk = d.sk, sj = d.sj;
+    const bool interior = (i > 0) && (i < d.nx - 1) && (j > 0) && (j < d.ny - 1);
+    if (!interior) {
+        for (int m = 0; m < nv; ++m) out.p[m][c] = q1in.p[m][c];
+        return;
+    }
+    const float r = RHO ? rho[c] : 1.0f;
+    const float ja = jaco[c];
+    const float den_h = ja * r;
+    const float den_v = dz[c] * ja * r;
+    const bool bottom = (k == 0), top = (k == d.nz - 1);
+    for (int m = 0; m < nv; ++m) {
+        const float *__restrict__ q = q1in.p[m];
+        const float *__restrict__ l = qold.p[m];
+        const float *__restrict__ u2 = u2i.p[m];
+        const float *__restrict__ v2 = v2i.p[m];
+        const float *__restrict__ w2 = w2i.p[m];
+        float Ul, Ur, Vs, Vn, Wb = 0.0f, Wt = 0.0f;
+        if (FCT) {
+            Ul = limit_face(q, l, u2, c - 1, c, 1, i - 1, d.nx, false);
+            Ur = limit_face(q, l, u2, c, c + 1, 1, i, d.nx, false);
+            Vs = limit_face(q, l, v2, c - sj, c, sj, j - 1, d.ny, false);
+            Vn = limit_face(q, l, v2, c, c + sj, sj, j, d.ny, false);
+            if (!bottom) Wb = limit_face(q, l, w2, c - sk, c - sk, sk, k - 1, d.nz, true);
+            if (!top)    Wt = limit_face(q, l, w2, c, c, sk, k, d.nz, true);
+        } else {
+            Ul = u2[c]; Ur = u2[c + 1]; Vs = v2[c]; Vn = v2[c + sj];
+            if (!bottom) Wb = w2[c - sk];
+            if (!top)    Wt = w2[c];
+        }
+        const float q0 = q[c];
+        const float f1r = flux1(q0, q[c + 1], Ur);
+        const float f1l = flux1(q[c - 1], q0, Ul);
+        const float f3 = flux1(q0, q[c + sj], Vn);
+        const float f4 = flux1(q[c - sj], q0, Vs);
+        float qq = q0 - ((f1r - f1l) + (f3 - f4)) / den_h;
+        if (bottom) {
+            qq = qq - flux1(q0, q[c + sk], Wt) / den_v;
+        } else if (top) {
+            qq = qq - (q0 * Wt - flux1(q[c - sk], q0, Wb)) / den_v;   // Wt == 0 (adv_mpdata.f90:215,322)
+        } else {
+            qq = qq - (flux1(q0, q[c + sk], Wt) - flux1(q[c - sk], q0, Wb)) / den_v;
+        }
+        out.p[m][c] = qq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static dim3 grid3(const Dims &d) { return dim3((d.nx + BX - 1) / BX, (d.nz + BY - 1) / BY, d.ny); }
+
+static int ensure_adv_scratch(icar_hip_ctx *c, int batch)
+{
+    const size_t bytes = c->n3 * sizeof(float);
+    if (!c->U) {
+        HIPCHK(hipMalloc(&c->U, bytes)); HIPCHK(hipMalloc(&c->V, bytes));
+        HIPCHK(hipMalloc(&c->W, bytes)); HIPCHK(hipMalloc(&c->Wdz, bytes));
+    }
+    if (batch > c->batch_cap) {
+        if (c->q2) { hipFree(c->q2); hipFree(c->u2); hipFree(c->v2); hipFree(c->w2); }
+        HIPCHK(hipMalloc(&c->q2, bytes * batch)); HIPCHK(hipMalloc(&c->u2, bytes * batch));
+        HIPCHK(hipMalloc(&c->v2, bytes * batch)); HIPCHK(hipMalloc(&c->w2, bytes * batch));
+        c->batch_cap = batch;
+    }
+    return 0;
+}
+
+int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density)
+{
+    if (scheme != ICAR_ADV_UPWIND && scheme != ICAR_ADV_MPDATA) { icar_set_error("setup_winds: bad scheme"); return 1; }
+    if (ensure_adv_scratch(c, 0)) return 1;
+    const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V), *w = icar_field_f(c, ICAR_F_W);
+    const float *ju = icar_field_f(c, ICAR_F_JACOBIAN_U), *jv = icar_field_f(c, ICAR_F_JACOBIAN_V);
+    const float *jw = icar_field_f(c, ICAR_F_JACOBIAN_W), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
+    const float *rho = advect_density ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
+    if (!u || !v || !w || !ju || !jv || !jw || !dz || (advect_density && !rho)) return 1;
+    ScopedTimer t(c, "winds");
+    dim3 g = grid3(c->d), b(BX, BY);
+#define LAUNCH(S, R) hipLaunchKernelGGL((k_setup_winds<S, R>), g, b, 0, c->stream, c->d, u, v, w, rho, ju, jv, jw, dz, dt, dx, c->U, c->V, c->W, c->Wdz)
+    if (scheme == 1) { if (advect_density) LAUNCH(1, true); else LAUNCH(1, false); }
+    else             { if (advect_density) LAUNCH(2, true); else LAUNCH(2, false); }
+#undef LAUNCH
+    HIPCHK(hipGetLastError());
+    c->winds_valid = true;
+    return 0;
+}
+
+int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_density, const int *fields, int n)
+{
+    if (!c->winds_valid) { icar_set_error("advect: call icar_hip_setup_winds first"); return 1; }
+    if (n <= 0) return 0;
+    if (n > ICAR_MAX_ADV) { icar_set_error("advect: too many fields"); return 1; }
+    if (scheme == ICAR_ADV_UPWIND) order = 1;
+    if (order < 1) { icar_set_error("advect: mpdata_order must be >= 1"); return 1; }
+    if (ensure_adv_scratch(c, order > 1 ? n : 0)) return 1;
+    const float *rho = advect_density ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
+    const float *jaco = icar_field_f(c, ICAR_F_JACOBIAN), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
+    if (!jaco || !dz || (advect_density && !rho)) return 1;
+    CVarPtrs q, q2c, u2c, v2c, w2c; VarPtrs alt, q2, u2, v2, w2;
+    for (int m = 0; m < n; ++m) {
+        const int f = fields[m];
+        if (f < 0 || f >= ICAR_N_ADVECTABLE) { icar_set_error("advect: field id is not an advectable scalar"); return 1; }
+        for (int mm = 0; mm < m; ++mm) if (fields[mm] == f) { icar_set_error("advect: duplicate field"); return 1; }
+        float *p = icar_field_f(c, f);
+        if (!p) return 1;
+        if (!c->alt[f]) HIPCHK(hipMalloc(&c->alt[f], c->n3 * sizeof(float)));
+        q.p[m] = p; alt.p[m] = c->alt[f];
+        if (order > 1) {
+            q2.p[m] = c->q2 + (size_t)m * c->n3; u2.p[m] = c->u2 + (size_t)m * c->n3;
+            v2.p[m] = c->v2 + (size_t)m * c->n3; w2.p[m] = c->w2 + (size_t)m * c->n3;
+            q2c.p[m] = q2.p[m]; u2c.p[m] = u2.p[m]; v2c.p[m] = v2.p[m]; w2c.p[m] = w2.p[m];
+        }
+    }
+    ScopedTimer t(c, "advect");
+    dim3 g = grid3(c->d), b(BX, BY);
+    auto swap_fields = [&]() {
+        for (int m = 0; m < n; ++m) {
+            const int f = fields[m];
+            float *cur = (float *)c->field[f];
+            c->field[f] = c->alt[f]; c->alt[f] = cur;
+            q.p[m] = (float *)c->field[f]; alt.p[m] = c->alt[f];
+        }
+    };
+    if (order == 1) {
+        // q -> alt, swap  (upwind; or mpdata_order=1: adv_mpdata.f90:374,404-411)
+        if (advect_density) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz);
+        else                hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz);
+        HIPCHK(hipGetLastError());
+        swap_fields();
+        return 0;
+    }
+    // iord = 1 : q -> q2
+    if (advect_density) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, q, q2, n, c->U, c->V, c->W, rho, jaco, dz);
+    else                hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, q, q2, n, c->U, c->V, c->W, rho, jaco, dz);
+    for (int iord = 2; iord <= order; ++iord) {
+        // pseudo-velocities from q2 with the ORIGINAL U_m,V_m,W_m/dz (adv_mpdata.f90:379)
+        if (advect_density) hipLaunchKernelGGL((k_mpdata_fluxes<true>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz);
+        else                hipLaunchKernelGGL((k_mpdata_fluxes<false>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz);
+        // limiter (l = q, q1 = q2) fused into the donor-cell pass q2 -> alt ; then q := alt
+#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final<R, F>), g, b, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz)
+        if (advect_density) { if (fct) FINAL(true, true); else FINAL(true, false); }
+        else                { if (fct) FINAL(false, true); else FINAL(false, false); }
+#undef FINAL
+        swap_fields();
+        if (iord != order) {
+            // adv_mpdata.f90:393-402 : q2 := q before the next corrective iteration
+            for (int m = 0; m < n; ++m)
+                HIPCHK(hipMemcpyAsync(q2.p[m], q.p[m], c->n3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}

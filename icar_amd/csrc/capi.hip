@@ -1,0 +1,442 @@
+// icar_amd/csrc/capi.hip -- extern "C" boundary (include/icar_hip.h), context and field registry,
+// plus the small streaming kernels of rows H1 (halo faces), T2 (CFL reduction), W1 (balance_uvw).
+#include "ctx.h"
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+
+static thread_local std::string g_err;
+void icar_set_error(const std::string &msg) { g_err = msg; }
+int icar_hip_check(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return 0;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// field registry
+// ------------------------------------------------------------------------------------------------
+static bool field_is_2dd(int f) { return f == ICAR_F_PRECIPITATION || f == ICAR_F_SNOWFALL || f == ICAR_F_GRAUPEL_ACC; }
+
+size_t icar_field_count(const icar_hip_ctx *c, int f)
+{
+    const size_t nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
+    if (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U) return (nx + 1) * nz * ny;
+    if (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V) return nx * nz * (ny + 1);
+    if (field_is_2dd(f)) return nx * ny;
+    return nx * nz * ny;
+}
+
+float *icar_field_f(icar_hip_ctx *c, int f, bool required)
+{
+    if (f < 0 || f >= ICAR_N_FIELDS) { icar_set_error("bad field id"); return nullptr; }
+    if (!c->field[f]) {
+        if (required) {
+            char b[96]; snprintf(b, sizeof b, "field %d has not been uploaded to the device", f);
+            icar_set_error(b); return nullptr;
+        }
+        const size_t bytes = icar_field_count(c, f) * icar_hip_field_elem_size(f);
+        if (icar_hip_check(hipMalloc(&c->field[f], bytes), "hipMalloc(field)")) return nullptr;
+        if (icar_hip_check(hipMemsetAsync(c->field[f], 0, bytes, c->stream), "hipMemset(field)")) return nullptr;
+    }
+    return (float *)c->field[f];
+}
+
+ScopedTimer::ScopedTimer(icar_hip_ctx *c_, const char *g) : c(c_), group(g)
+{
+    if (!c->timing) return;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, c->stream);
+}
+ScopedTimer::~ScopedTimer()
+{
+    if (!e0) return;
+    hipEventRecord(e1, c->stream);
+    c->pending.push_back({group, {e0, e1}});
+}
+
+static void drain_timers(icar_hip_ctx *c)
+{
+    for (auto &p : c->pending) {
+        float ms = 0;
+        hipEventSynchronize(p.second.second);
+        hipEventElapsedTime(&ms, p.second.first, p.second.second);
+        auto &t = c->timers[p.first];
+        t.total_ms += ms; t.launches += 1;
+        hipEventDestroy(p.second.first); hipEventDestroy(p.second.second);
+    }
+    c->pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// H1: halo faces.  Buffer layout per field: N/S = [h][nz][nx] (verbatim planes), E/W = [ny][nz][h].
+// ------------------------------------------------------------------------------------------------
+struct HaloArgs { float *f[ICAR_MAX_ADV]; };
+
+template <bool UNPACK>
+__global__ void k_halo_ns(Dims d, HaloArgs a, int nv, int row0, int h, float *__restrict__ buf)
+{
+    // one thread per element of the h*nz*nx slab; i fastest => fully coalesced on both sides
+    const size_t per = (size_t)d.nx * d.nz * h;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per) return;
+    const int m = blockIdx.y;
+    const size_t src = (size_t)row0 * d.sj + t;      // rows row0..row0+h-1 are contiguous in memory
+    if (UNPACK) a.f[m][src] = buf[(size_t)m * per + t];
+    else buf[(size_t)m * per + t] = a.f[m][src];
+}
+
+template <bool UNPACK>
+__global__ void k_halo_ew(Dims d, HaloArgs a, int nv, int col0, int h, float *__restrict__ buf)
+{
+    // stride-nx gather: thread t -> (x = t % h, line = t / h), line = k + nz*j
+    const size_t per = (size_t)h * d.nz * d.ny;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per) return;
+    const int m = blockIdx.y;
+    const int x = (int)(t % h);
+    const size_t line = t / h;
+    const size_t src = line * d.nx + col0 + x;
+    if (UNPACK) a.f[m][src] = buf[(size_t)m * per + t];
+    else buf[(size_t)m * per + t] = a.f[m][src];
+}
+
+int icar_halo_pack(icar_hip_ctx *c, int dir, int h, const int *fields, int n, float *buf, bool unpack)
+{
+    if (n <= 0) return 0;
+    if (n > ICAR_MAX_ADV) { icar_set_error("halo: too many fields"); return 1; }
+    if (h < 1 || 2 * h > c->d.nx || 2 * h > c->d.ny) { icar_set_error("halo: bad halo width"); return 1; }
+    HaloArgs a;
+    for (int m = 0; m < n; ++m) {
+        if (fields[m] < 0 || fields[m] >= ICAR_N_ADVECTABLE) { icar_set_error("halo: only exchangeable scalars"); return 1; }
+        a.f[m] = icar_field_f(c, fields[m]);
+        if (!a.f[m]) return 1;
+    }
+    const Dims &d = c->d;
+    ScopedTimer t(c, "halo");
+    if (dir == 0 || dir == 1) {
+        // put_north sends rows ny-2h..ny-h-1 ; put_south rows h..2h-1          (exchangeable_obj.f90:263,280)
+        // retrieve_north fills rows ny-h..ny-1 ; retrieve_south rows 0..h-1    (:290,:300)
+        int row0;
+        if (!unpack) row0 = (dir == 0) ? d.ny - 2 * h : h;
+        else         row0 = (dir == 0) ? d.ny - h : 0;
+        const size_t per = (size_t)d.nx * d.nz * h;
+        dim3 g((unsigned)((per + 255) / 256), n), b(256);
+        if (unpack) hipLaunchKernelGGL(k_halo_ns<true>, g, b, 0, c->stream, d, a, n, row0, h, buf);
+        else        hipLaunchKernelGGL(k_halo_ns<false>, g, b, 0, c->stream, d, a, n, row0, h, buf);
+    } else if (dir == 2 || dir == 3) {
+        // put_east sends cols nx-2h..nx-h-1 ; put_west cols h..2h-1            (:317,:335)
+        int col0;
+        if (!unpack) col0 = (dir == 2) ? d.nx - 2 * h : h;
+        else         col0 = (dir == 2) ? d.nx - h : 0;
+        const size_t per = (size_t)h * d.nz * d.ny;
+        dim3 g((unsigned)((per + 255) / 256), n), b(256);
+        if (unpack) hipLaunchKernelGGL(k_halo_ew<true>, g, b, 0, c->stream, d, a, n, col0, h, buf);
+        else        hipLaunchKernelGGL(k_halo_ew<false>, g, b, 0, c->stream, d, a, n, col0, h, buf);
+    } else { icar_set_error("halo: dir must be 0..3"); return 1; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// T2: compute_dt strictness-3 reduction (time_step.f90:264-289)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_max_courant(Dims d, const float *__restrict__ u, const float *__restrict__ v,
+                              const float *__restrict__ w, const float *__restrict__ dzl, float dx,
+                              unsigned *__restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.y * 4 + threadIdx.y;
+    const int j = blockIdx.z;
+    float cur = 0.0f;
+    if (i < d.nx && k < d.nz) {
+        const int c = d.idx(i, k, j);
+        const int cu = i + (d.nx + 1) * (k + d.nz * j);
+        const int zo = (k == 0) ? 0 : -d.sk;
+        cur = fmaxf(fabsf(u[cu]), fabsf(u[cu + 1])) / dx
+            + fmaxf(fabsf(v[c]), fabsf(v[c + d.sj])) / dx
+            + fmaxf(fabsf(w[c]), fabsf(w[c + zo])) / dzl[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) cur = fmaxf(cur, __shfl_down(cur, o));
+    __shared__ float s[4];
+    if (threadIdx.x == 0) s[threadIdx.y] = cur;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        cur = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        atomicMax(out, __float_as_uint(cur));   // non-negative floats order like unsigned ints
+    }
+}
+
+int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out)
+{
+    const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V), *w = icar_field_f(c, ICAR_F_W);
+    if (!u || !v || !w) return 1;
+    float *dzl = c->d_red + 16;
+    HIPCHK(hipMemcpyAsync(dzl, dz_levels, sizeof(float) * c->d.nz, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_red, 0, sizeof(float), c->stream));
+    dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
+    hipLaunchKernelGGL(k_max_courant, g, b, 0, c->stream, c->d, u, v, w, dzl, dx, (unsigned *)c->d_red);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->d_red, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// W1: balance_uvw (wind.f90:81-169): w from the horizontal divergence, bottom-up per column
+// ------------------------------------------------------------------------------------------------
+__global__ void k_balance_uvw(Dims d, const float *__restrict__ u, const float *__restrict__ v, float *__restrict__ w,
+                              const float *__restrict__ ju, const float *__restrict__ jv, const float *__restrict__ jw,
+                              const float *__restrict__ dz, float dx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= d.nx) return;
+    float wprev = 0.0f, jwprev = 0.0f;
+    for (int k = 0; k < d.nz; ++k) {
+        const int c = d.idx(i, k, j);
+        const int cu = i + (d.nx + 1) * (k + d.nz * j);
+        const float du = u[cu + 1] * ju[cu + 1] - u[cu] * ju[cu];       // calc_divergence :207-210
+        const float dv = v[c + d.sj] * jv[c + d.sj] - v[c] * jv[c];
+        const float div = (du + dv) / dx;
+        float wk;
+        if (k == 0) wk = 0 - div * dz[c] / jw[c];                       // :141
+        else        wk = (wprev * jwprev - div * dz[c]) / jw[c];        // :143
+        w[c] = wk; wprev = wk; jwprev = jw[c];
+    }
+}
+
+int icar_balance_uvw_run(icar_hip_ctx *c, float dx)
+{
+    const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V);
+    const float *ju = icar_field_f(c, ICAR_F_JACOBIAN_U), *jv = icar_field_f(c, ICAR_F_JACOBIAN_V);
+    const float *jw = icar_field_f(c, ICAR_F_JACOBIAN_W), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
+    float *w = icar_field_f(c, ICAR_F_W, false);
+    if (!u || !v || !ju || !jv || !jw || !dz || !w) return 1;
+    dim3 g((c->d.nx + 63) / 64, c->d.ny), b(64);
+    hipLaunchKernelGGL(k_balance_uvw, g, b, 0, c->stream, c->d, u, v, w, ju, jv, jw, dz, dx);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extern "C"
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *icar_hip_last_error(void) { return g_err.c_str(); }
+const char *icar_hip_version(void) { return "icar_hip 0.1 (gfx950)"; }
+size_t icar_hip_field_elem_size(int field) { return field_is_2dd(field) ? sizeof(double) : sizeof(float); }
+size_t icar_hip_field_count(const icar_hip_ctx *ctx, int field) { return ctx ? icar_field_count(ctx, field) : 0; }
+
+int icar_hip_ctx_create(icar_hip_ctx **out, int device, int ims, int ime, int kms, int kme, int jms, int jme)
+{
+    if (!out) { icar_set_error("ctx_create: null out"); return 1; }
+    *out = nullptr;
+    if (ime < ims + 2 || jme < jms + 2 || kme < kms + 1) { icar_set_error("ctx_create: tile must be at least 3x2x3"); return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        icar_set_error("ctx_create: no HIP device visible (libicar_hip has no CPU fallback)"); return 1;
+    }
+    if (device < 0 || device >= ndev) { icar_set_error("ctx_create: bad device index"); return 1; }
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950")) {
+        icar_set_error(std::string("ctx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return 1;
+    }
+    icar_hip_ctx *c = new icar_hip_ctx();
+    c->device = device;
+    c->ims = ims; c->ime = ime; c->kms = kms; c->kme = kme; c->jms = jms; c->jme = jme;
+    c->d.nx = ime - ims + 1; c->d.nz = kme - kms + 1; c->d.ny = jme - jms + 1;
+    c->d.sk = c->d.nx; c->d.sj = c->d.nx * c->d.nz;
+    c->n3 = (size_t)c->d.nx * c->d.nz * c->d.ny;
+    if ((size_t)(c->d.nx + 1) * c->d.nz * (c->d.ny + 1) >= (size_t)1 << 31) { delete c; icar_set_error("ctx_create: tile too large for 32-bit indexing"); return 1; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; icar_set_error("hipStreamCreate failed"); return 1; }
+    c->own_stream = true;
+    if (hipMalloc(&c->d_red, sizeof(float) * (16 + 4096)) != hipSuccess || hipMalloc(&c->d_flag, sizeof(int) * 16) != hipSuccess) {
+        delete c; icar_set_error("hipMalloc failed"); return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+int icar_hip_ctx_destroy(icar_hip_ctx *c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->field[f]) hipFree(c->field[f]);
+    for (int f = 0; f < ICAR_N_ADVECTABLE; ++f) if (c->alt[f]) hipFree(c->alt[f]);
+    float *scr[] = {c->U, c->V, c->W, c->Wdz, c->q2, c->u2, c->v2, c->w2, c->d_red};
+    for (float *p : scr) if (p) hipFree(p);
+    if (c->d_flag) hipFree(c->d_flag);
+    icar_thompson_free(c);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int icar_hip_set_stream(icar_hip_ctx *c, void *s)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (s) {
+        if (c->own_stream) { hipStreamDestroy(c->stream); c->own_stream = false; }
+        c->stream = (hipStream_t)s;
+    } else if (!c->own_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return 0;
+}
+
+int icar_hip_synchronize(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int icar_hip_field_upload(icar_hip_ctx *c, int f, const void *host)
+{
+    if (!c || !host) { icar_set_error("field_upload: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    float *p = icar_field_f(c, f, false);
+    if (!p) return 1;
+    HIPCHK(hipMemcpyAsync(p, host, icar_field_count(c, f) * icar_hip_field_elem_size(f), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W || (f >= ICAR_F_DENSITY && f <= ICAR_F_ADVECTION_DZ)) c->winds_valid = false;
+    return 0;
+}
+
+int icar_hip_field_download(icar_hip_ctx *c, int f, void *host)
+{
+    if (!c || !host) { icar_set_error("field_download: null argument"); return 1; }
+    float *p = icar_field_f(c, f, true);
+    if (!p) return 1;
+    HIPCHK(hipMemcpyAsync(host, p, icar_field_count(c, f) * icar_hip_field_elem_size(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+__global__ void k_fill_f(float *p, size_t n, float v) { size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (t < n) p[t] = v; }
+__global__ void k_fill_d(double *p, size_t n, double v) { size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (t < n) p[t] = v; }
+
+int icar_hip_field_fill(icar_hip_ctx *c, int f, double value)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    float *p = icar_field_f(c, f, false);
+    if (!p) return 1;
+    const size_t n = icar_field_count(c, f);
+    if (field_is_2dd(f)) hipLaunchKernelGGL(k_fill_d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (double *)p, n, value);
+    else                 hipLaunchKernelGGL(k_fill_f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p, n, (float)value);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int icar_hip_field_device_ptr(icar_hip_ctx *c, int f, void **dptr)
+{
+    if (!c || !dptr) { icar_set_error("field_device_ptr: null argument"); return 1; }
+    float *p = icar_field_f(c, f, false);
+    if (!p) return 1;
+    *dptr = p;
+    return 0;
+}
+
+int icar_hip_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_advect_setup_winds(c, scheme, dt, dx, advect_density);
+}
+
+int icar_hip_advect(icar_hip_ctx *c, int scheme, int mpdata_order, int fct, int advect_density, const int *fields, int nfields)
+{
+    if (!c || (!fields && nfields > 0)) { icar_set_error("advect: null argument"); return 1; }
+    return icar_advect_run(c, scheme, mpdata_order, fct, advect_density, fields, nfields);
+}
+
+int icar_hip_mp_simple(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_count)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_mp_simple_run(c, dt, its, ite, jts, jte, kts, kte, err_count);
+}
+
+int icar_hip_thompson_init(icar_hip_ctx *c, const float params[18], const int flags[2])
+{
+    if (!c || !params || !flags) { icar_set_error("thompson_init: null argument"); return 1; }
+    return icar_thompson_init_run(c, params, flags);
+}
+
+int icar_hip_thompson(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
+                      int ids, int ide, int jds, int jde, int kds, int kde)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_thompson_run(c, dt, its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde);
+}
+
+int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, int tiles[4][4])
+{
+    // mp_driver.f90:609-658 (process_halo) and :728-737 (subset)
+    if (halo > 0) {
+        const int t[4][4] = {
+            {its, its + halo - 1, jts, jte},                     // west strip, full height
+            {ite - halo + 1, ite, jts, jte},                     // east strip
+            {its + halo, ite - halo, jts, jts + halo - 1},       // south strip without corners
+            {its + halo, ite - halo, jte - halo + 1, jte}};      // north strip
+        memcpy(tiles, t, sizeof t);
+        return 4;
+    }
+    tiles[0][0] = its + subset; tiles[0][1] = ite - subset; tiles[0][2] = jts + subset; tiles[0][3] = jte - subset;
+    return 1;
+}
+
+int icar_hip_max_courant(icar_hip_ctx *c, float dx, const float *dz_levels, float *out)
+{
+    if (!c || !dz_levels || !out) { icar_set_error("max_courant: null argument"); return 1; }
+    if (c->d.nz > 4096) { icar_set_error("max_courant: nz too large"); return 1; }
+    return icar_max_courant_run(c, dx, dz_levels, out);
+}
+
+int icar_hip_balance_uvw(icar_hip_ctx *c, float dx)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_balance_uvw_run(c, dx);
+}
+
+size_t icar_hip_halo_count(const icar_hip_ctx *c, int dir, int halo)
+{
+    if (!c) return 0;
+    if (dir == 0 || dir == 1) return (size_t)c->d.nx * c->d.nz * halo;
+    return (size_t)halo * c->d.nz * c->d.ny;
+}
+
+int icar_hip_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int nfields, void *dbuf)
+{
+    if (!c || !dbuf) { icar_set_error("halo_pack: null argument"); return 1; }
+    return icar_halo_pack(c, dir, halo, fields, nfields, (float *)dbuf, false);
+}
+
+int icar_hip_halo_unpack(icar_hip_ctx *c, int dir, int halo, const int *fields, int nfields, const void *dbuf)
+{
+    if (!c || !dbuf) { icar_set_error("halo_unpack: null argument"); return 1; }
+    return icar_halo_pack(c, dir, halo, fields, nfields, (float *)dbuf, true);
+}
+
+int icar_hip_timing_enable(icar_hip_ctx *c, int on) { if (!c) return 1; c->timing = on != 0; return 0; }
+int icar_hip_timing_reset(icar_hip_ctx *c) { if (!c) return 1; hipStreamSynchronize(c->stream); drain_timers(c); c->timers.clear(); return 0; }
+int icar_hip_timing_read(icar_hip_ctx *c, const char *group, double *total_ms, int *launches)
+{
+    if (!c || !group) return 1;
+    hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    auto it = c->timers.find(group);
+    if (total_ms) *total_ms = (it == c->timers.end()) ? 0.0 : it->second.total_ms;
+    if (launches) *launches = (it == c->timers.end()) ? 0 : it->second.launches;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// icar_amd/csrc/ctx.h -- device context behind the C ABI (include/icar_hip.h).
+// Replaces the reference's module-level SAVE state (adv_upwind/adv_mpdata U_m,V_m,W_m;
+// microphysics SR,last_model_time; Thompson tables) with one handle per image/GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <map>
+#include <vector>
+#include "../../include/icar_hip.h"
+
+#define ICAR_MAX_ADV 12
+
+struct Dims {
+    int nx, nz, ny;      // memory extents (ime-ims+1, ...)
+    int sk, sj;          // strides of k and j (sk = nx, sj = nx*nz)
+    __host__ __device__ inline int idx(int i, int k, int j) const { return i + nx * (k + nz * j); }
+};
+
+struct VarPtrs { float *p[ICAR_MAX_ADV]; };
+struct CVarPtrs { const float *p[ICAR_MAX_ADV]; };
+
+struct TimingGroup { double total_ms = 0; int launches = 0; };
+
+struct ThompsonTables;   // mp_thompson.hip
+
+struct icar_hip_ctx {
+    int device = 0;
+    int ims, ime, kms, kme, jms, jme;
+    Dims d;
+    size_t n3 = 0;                       // nx*nz*ny
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void *field[ICAR_N_FIELDS] = {nullptr};
+    // advection scratch (A1-A5)
+    float *U = nullptr, *V = nullptr, *W = nullptr, *Wdz = nullptr;
+    float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
+    float *q2 = nullptr, *u2 = nullptr, *v2 = nullptr, *w2 = nullptr;   // each holds batch_cap fields
+    int batch_cap = 0;
+    bool winds_valid = false;
+    // reductions / flags
+    float *d_red = nullptr;              // small device scratch for reductions
+    int *d_flag = nullptr;
+    ThompsonTables *thompson = nullptr;
+    // timing
+    bool timing = false;
+    std::map<std::string, TimingGroup> timers;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+};
+
+void icar_set_error(const std::string &msg);
+int icar_hip_check(hipError_t e, const char *what);
+#define HIPCHK(x) do { if (icar_hip_check((x), #x)) return 1; } while (0)
+
+// field geometry
+size_t icar_field_count(const icar_hip_ctx *c, int field);
+float *icar_field_f(icar_hip_ctx *c, int field, bool required = true);   // allocates lazily
+
+// timing helpers
+struct ScopedTimer {
+    icar_hip_ctx *c; const char *group; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ScopedTimer(icar_hip_ctx *c_, const char *g);
+    ~ScopedTimer();
+};
+
+// kernels implemented in the .hip files
+int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density);
+int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_density, const int *fields, int n);
+int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err);
+int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
+int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out);
+int icar_balance_uvw_run(icar_hip_ctx *c, float dx);
+int icar_thompson_init_run(icar_hip_ctx *c, const float *params, const int *flags);
+int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
+                      int ids, int ide, int jds, int jde, int kds, int kde);
+void icar_thompson_free(icar_hip_ctx *c);

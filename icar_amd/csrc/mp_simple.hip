@@ -1,0 +1,252 @@
+// icar_amd/csrc/mp_simple.hip -- ICAR's "simple" (SB04) bulk microphysics on gfx950 (row M1).
+//
+// Reference algorithm: src/physics/mp_simple.f90 (driver :595-646, column :481-566, per-level
+// conversions :381-420, saturation adjustment :198-280, sedimentation :437-459).
+// Design: one column per lane with lanes along i, so every level-k access of a wave is one
+// coalesced 256-B row.  The five mutable column species (T, qv, qc, qr, qs) are staged in LDS as
+// [species][k][lane] (lane-contiguous => bank-conflict free) for the whole column lifetime; the
+// read-only p, rho, dz stream from global (L2-resident).  FP32 throughout like the reference;
+// exp() is evaluated in FP64 and rounded once so that it agrees with the host libm's correctly
+// rounded expf in all but ~1e-3 of evaluations (documented tolerance in tests/).
+#include "ctx.h"
+#include <cmath>
+
+#define MPS_LANES 64
+
+namespace {
+constexpr float LH_vapor = 2.26E6f, dLHvdt = 2400.0f, LH_liquid = 3.34E5f, heat_capacity = 1006.0f;
+constexpr float SMALL_VALUE = 1E-30f, freezing_threshold = 273.15f;
+constexpr float snow_fall_rate = 1.5f, rain_fall_rate = 10.0f, snow_cloud_init = 0.0001f, rain_cloud_init = 0.0001f;
+
+__device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
+
+__device__ __forceinline__ float sat_mr(float temperature, float pressure)
+{   // mp_simple.f90:146-182
+    float a, b;
+    if (temperature < freezing_threshold) { a = 21.8745584f; b = 7.66f; }
+    else { a = 17.2693882f; b = 35.86f; }
+    float e_s = 610.78f * expf_cr(a * (temperature - 273.16f) / (temperature - b));
+    if ((pressure - e_s) <= 0) e_s = pressure * 0.99999f;
+    return 0.6219907f * e_s / (pressure - e_s);
+}
+
+__device__ __forceinline__ void phase_change(float &temperature, float &q1, float qmax, float &q2,
+                                             float Lheat, float change_rate, int &err)
+{   // :333-362
+    const float mass2temp = Lheat / heat_capacity;
+    float delta = (qmax - q2) * change_rate;
+    if (delta > q1) delta = q1;
+    if (delta > ((qmax - q2) * 0.99f)) delta = (qmax - q2) * 0.99f;
+    q1 = q1 - delta;
+    if (q1 < 0) {
+        if ((q1 + SMALL_VALUE) < 0) q1 = 0;
+        else err = 1;                       // the reference prints and STOPs here
+    }
+    q2 = q2 + delta;
+    temperature = temperature + delta * mass2temp;
+}
+
+__device__ __forceinline__ void cloud2hydrometeor(float &qc, float &q, float conversion, float qcmin)
+{   // :295-315
+    float delta = (qc > qcmin) ? qc - (qc * conversion) : 0.0f;
+    if (delta < qc) { qc = qc - delta; q = q + delta; }
+    else { q = q + qc; qc = 0.f; }
+    qc = fmaxf(qc, 0.f);
+}
+
+__device__ void mp_conversions(float pressure, float &temperature, float &qv, float &qc, float &qr, float &qs,
+                               float cloud2rain, float cloud2snow, int &err)
+{   // :381-420 with cloud_conversion (:198-280) inlined
+    const float L_melt = -1 * LH_liquid;
+    const float L_evap = -1 * (LH_vapor + (373.15f - temperature) * dLHvdt);
+    const float L_subl = L_melt + L_evap;
+    float qvsat = 0.0f;
+    {
+        const float maxerr = 1e-4f;
+        int iteration = 0;
+        float lastqv = qv + maxerr * 2;
+        const float vapor2temp = (LH_vapor + (373.15f - temperature) * dLHvdt) / heat_capacity;
+        const float pre_qc = qc, pre_t = temperature;
+        while ((fabsf(lastqv - qv) > maxerr) && (iteration < 15)) {
+            iteration = iteration + 1;
+            lastqv = qv;
+            qvsat = sat_mr(temperature, pressure);
+            if (qv > qvsat) {
+                const float excess = (qv - qvsat) * 0.5f;
+                temperature = temperature + (excess * vapor2temp);
+                qv = qv - excess;
+                qc = qc + excess;
+            } else if (qc > 0) {
+                const float excess = (qvsat - qv) * 0.5f;
+                if (excess < qc) {
+                    temperature = temperature - (excess * vapor2temp);
+                    qv = qv + excess;
+                    qc = qc - excess;
+                } else {
+                    qv = qv + qc;
+                    temperature = temperature - (qc * vapor2temp);
+                    qc = 0.f;
+                }
+            }
+        }
+        if (iteration == 15) {
+            qv = sat_mr(pre_t, pressure);
+            temperature = pre_t;
+            qc = pre_qc;
+        }
+        qc = fmaxf(qc, 0.f);
+    }
+    if ((qc + qr + qs) > SMALL_VALUE) {
+        if (qc > SMALL_VALUE) {
+            if (temperature > freezing_threshold) {
+                cloud2hydrometeor(qc, qr, cloud2rain, rain_cloud_init);
+                if (qs > SMALL_VALUE) phase_change(temperature, qs, 100.f, qr, L_melt, cloud2rain, err);
+            } else
+                cloud2hydrometeor(qc, qs, cloud2snow, snow_cloud_init);
+        }
+        if (qv < qvsat) {
+            if (qr > SMALL_VALUE) phase_change(temperature, qr, qvsat, qv, L_evap, cloud2rain / 2, err);
+            if (qs > SMALL_VALUE) phase_change(temperature, qs, qvsat, qv, L_subl, cloud2snow / 2, err);
+        }
+    }
+}
+
+// one explicit-upwind fall sub-step of species column q (LDS), :437-459 with the flux array fused
+// away: flux(i) only ever sees the not-yet-modified q(i+1).
+__device__ __forceinline__ float sediment(float *q, int ls, float vfall, const float *__restrict__ rho,
+                                          const float *__restrict__ dz, int gs, int nz, int kts, int kte)
+{
+    const float sed = vfall * q[kts * ls] * rho[kts * gs];
+    q[kts * ls] = q[kts * ls] - (sed / dz[kts * gs] / rho[kts * gs]);
+    const int top = (kte < nz - 2) ? kte : nz - 2;
+    for (int i = kts; i <= top; ++i) {
+        const float flux = vfall * q[(i + 1) * ls] * rho[(i + 1) * gs];
+        q[i * ls] = q[i * ls] + flux / (rho[i * gs] * dz[i * gs]);
+        q[(i + 1) * ls] = q[(i + 1) * ls] - flux / (rho[(i + 1) * gs] * dz[(i + 1) * gs]);
+    }
+    return sed;
+}
+
+__global__ void __launch_bounds__(MPS_LANES)
+k_mp_simple(Dims d, const float *__restrict__ pressure, float *__restrict__ th, const float *__restrict__ pii,
+            const float *__restrict__ rho, float *__restrict__ qv_g, float *__restrict__ qc_g,
+            float *__restrict__ qr_g, float *__restrict__ qs_g, const float *__restrict__ dz,
+            double *__restrict__ precip_acc, double *__restrict__ snow_acc,
+            float dt, float cloud2rain, float cloud2snow,
+            int i0, int i1, int j0, int kts, int kte, int *__restrict__ err_count)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int i = i0 + blockIdx.x * MPS_LANES + lane;
+    const int j = j0 + blockIdx.y;
+    if (i > i1) return;
+    const int nz = d.nz, gs = d.sk, ls = MPS_LANES;
+    float *T = lds + lane, *qv = T + nz * ls, *qc = qv + nz * ls, *qr = qc + nz * ls, *qs = qr + nz * ls;
+    const int c0 = d.idx(i, 0, j);
+    const float *p = pressure + c0, *rh = rho + c0, *dzc = dz + c0, *pi_c = pii + c0;
+    for (int k = 0; k < nz; ++k) {
+        const int g = c0 + k * gs;
+        T[k * ls] = th[g] * pi_c[k * gs];
+        qv[k * ls] = qv_g[g]; qc[k * ls] = qc_g[g]; qr[k * ls] = qr_g[g]; qs[k * ls] = qs_g[g];
+    }
+    int err = 0;
+    float rain = 0.0f, snow = 0.0f;
+    const float L_melt = -1 * LH_liquid;
+    float qr_max = -INFINITY, qs_max = -INFINITY;
+    for (int k = kts; k <= kte; ++k) {
+        float t = T[k * ls], v = qv[k * ls], cc = qc[k * ls], r = qr[k * ls], s = qs[k * ls];
+        mp_conversions(p[k * gs], t, v, cc, r, s, cloud2rain, cloud2snow, err);
+        T[k * ls] = t; qv[k * ls] = v; qc[k * ls] = cc; qr[k * ls] = r; qs[k * ls] = s;
+    }
+    for (int k = 0; k < nz; ++k) qr_max = fmaxf(qr_max, qr[k * ls]);
+    if (qr_max > SMALL_VALUE) {
+        float m = dt / dzc[0] * rain_fall_rate;
+        for (int k = 1; k < nz; ++k) m = fmaxf(m, dt / dzc[k * gs] * rain_fall_rate);
+        const float cfl = ceilf(m);
+        const float vfall = dt * rain_fall_rate / cfl;
+        const int ncfl = (int)lroundf(cfl);
+        const float rate = cloud2rain / (2 * ncfl);
+        for (int s = 1; s <= ncfl; ++s) {
+            rain = rain + sediment(qr, ls, vfall, rh, dzc, gs, nz, kts, kte);
+            for (int k = kts; k <= kte; ++k) {
+                float t = T[k * ls];
+                const float L_evap = -1 * (LH_vapor + (373.15f - t) * dLHvdt);
+                const float qvsat = sat_mr(t, p[k * gs]);
+                float v = qv[k * ls], r = qr[k * ls];
+                if (v < qvsat && r > SMALL_VALUE) {
+                    phase_change(t, r, qvsat, v, L_evap, rate, err);
+                    T[k * ls] = t; qv[k * ls] = v; qr[k * ls] = r;
+                }
+            }
+        }
+    }
+    for (int k = 0; k < nz; ++k) qs_max = fmaxf(qs_max, qs[k * ls]);
+    if (qs_max > SMALL_VALUE) {
+        float m = dt / dzc[0] * snow_fall_rate;
+        for (int k = 1; k < nz; ++k) m = fmaxf(m, dt / dzc[k * gs] * snow_fall_rate);
+        const float cfl = ceilf(m);
+        const float vfall = dt * snow_fall_rate / cfl;
+        const int ncfl = (int)lroundf(cfl);
+        const float rate = cloud2snow / (2 * ncfl);
+        for (int s = 1; s <= ncfl; ++s) {
+            const float snowfall = sediment(qs, ls, vfall, rh, dzc, gs, nz, kts, kte);
+            snow = snow + snowfall;
+            rain = rain + snowfall;
+            for (int k = kts; k <= kte; ++k) {
+                float t = T[k * ls];
+                const float L_evap = -1 * (LH_vapor + (373.15f - t) * dLHvdt);
+                const float L_subl = L_melt + L_evap;
+                const float qvsat = sat_mr(t, p[k * gs]);
+                float v = qv[k * ls], sn = qs[k * ls];
+                if (v < qvsat && sn > SMALL_VALUE) {
+                    phase_change(t, sn, qvsat, v, L_subl, rate, err);
+                    T[k * ls] = t; qv[k * ls] = v; qs[k * ls] = sn;
+                }
+            }
+        }
+    }
+    for (int k = 0; k < nz; ++k) {
+        const int g = c0 + k * gs;
+        th[g] = T[k * ls] / pi_c[k * gs];
+        qv_g[g] = qv[k * ls]; qc_g[g] = qc[k * ls]; qr_g[g] = qr[k * ls]; qs_g[g] = qs[k * ls];
+    }
+    // process_subdomain, mp_driver.f90:587-595: REAL(8) accumulators += REAL(4) tile fluxes
+    const int c2 = i + d.nx * j;
+    precip_acc[c2] = precip_acc[c2] + rain;
+    snow_acc[c2] = snow_acc[c2] + snow;
+    if (err) atomicAdd(err_count, 1);
+}
+}  // namespace
+
+int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_out)
+{
+    if (its < c->ims || ite > c->ime || jts < c->jms || jte > c->jme || kts < c->kms || kte > c->kme) {
+        icar_set_error("mp_simple: tile outside memory bounds"); return 1;
+    }
+    if (err_out) *err_out = 0;
+    if (ite < its || jte < jts || kte < kts) return 0;
+    float *p = icar_field_f(c, ICAR_F_PRESSURE), *th = icar_field_f(c, ICAR_F_POTENTIAL_TEMPERATURE);
+    float *pii = icar_field_f(c, ICAR_F_EXNER), *rho = icar_field_f(c, ICAR_F_DENSITY);
+    float *qv = icar_field_f(c, ICAR_F_WATER_VAPOR), *qc = icar_field_f(c, ICAR_F_CLOUD_WATER);
+    float *qr = icar_field_f(c, ICAR_F_RAIN), *qs = icar_field_f(c, ICAR_F_SNOW), *dz = icar_field_f(c, ICAR_F_DZ_MASS);
+    double *pa = (double *)icar_field_f(c, ICAR_F_PRECIPITATION, false), *sa = (double *)icar_field_f(c, ICAR_F_SNOWFALL, false);
+    if (!p || !th || !pii || !rho || !qv || !qc || !qr || !qs || !dz || !pa || !sa) return 1;
+    // mp_simple.f90:619-620, evaluated with the host libm like the reference
+    const float cloud2snow = std::exp(-1.0f * (1 / 2000.0f) * dt);
+    const float cloud2rain = std::exp(-1.0f * (1 / 500.0f) * dt);
+    const size_t lds_bytes = (size_t)5 * c->d.nz * MPS_LANES * sizeof(float);
+    if (lds_bytes > 160 * 1024) { icar_set_error("mp_simple: nz too large for the LDS column staging"); return 1; }
+    HIPCHK(hipFuncSetAttribute((const void *)k_mp_simple, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    ScopedTimer t(c, "mp");
+    const int ncol = ite - its + 1;
+    dim3 g((ncol + MPS_LANES - 1) / MPS_LANES, jte - jts + 1), b(MPS_LANES);
+    hipLaunchKernelGGL(k_mp_simple, g, b, lds_bytes, c->stream, c->d, p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa,
+                       dt, cloud2rain, cloud2snow, its - c->ims, ite - c->ims, jts - c->jms, kts - c->kms, kte - c->kms, c->d_flag);
+    HIPCHK(hipGetLastError());
+    if (err_out) {
+        HIPCHK(hipMemcpyAsync(err_out, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}

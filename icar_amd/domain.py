@@ -1,0 +1,147 @@
+"""domain_t mirror: device-resident fields of one tile behind the reference's member names
+(src/objects/domain_h.f90:18-363), plus halo_send / halo_retrieve / halo_exchange
+(src/objects/domain_obj.f90:109-143 over src/objects/exchangeable_obj.f90:138-356).
+
+Device memory lives in libicar_hip's context; numpy arrays only cross at upload/download
+(forcing / output boundaries), like the reference's NetCDF I/O points."""
+import ctypes
+import numpy as np
+from . import _fields as F
+from .capi import lib, check, IcarHipError
+from .constants import ADVECTION_ORDER, KVARS
+from .grid import grid_t
+
+DIR_NORTH, DIR_SOUTH, DIR_EAST, DIR_WEST = 0, 1, 2, 3
+
+
+class domain_t:
+    def __init__(self, grid: grid_t, device=0, dx=1000.0, image=1, comm=None):
+        self.grid = grid
+        self.dx = float(dx)
+        self.image = image
+        self.comm = comm                 # halo transport (icar_amd.halo); None for a single image
+        for n in ("ims", "ime", "jms", "jme", "kms", "kme", "its", "ite", "jts", "jte", "kts", "kte",
+                  "ids", "ide", "jds", "jde", "kds", "kde"):
+            setattr(self, n, getattr(grid, n))
+        self._ctx = ctypes.c_void_p()
+        check(lib().icar_hip_ctx_create(ctypes.byref(self._ctx), int(device), grid.ims, grid.ime, grid.kms,
+                                        grid.kme, grid.jms, grid.jme), "icar_hip_ctx_create")
+        self.nx, self.nz, self.ny = grid.ime - grid.ims + 1, grid.kme - grid.kms + 1, grid.jme - grid.jms + 1
+        self.model_time_seconds = 0.0    # domain%model_time%seconds()
+        self.exchange_vars = []          # kVARS names with an associated exchangeable (halo_send order)
+
+    # ---- plumbing -------------------------------------------------------------------------
+    @property
+    def ctx(self):
+        if not self._ctx:
+            raise IcarHipError("domain context destroyed")
+        return self._ctx
+
+    def close(self):
+        if self._ctx:
+            lib().icar_hip_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shape(self, fid):
+        if fid in (F.U, F.JACOBIAN_U): return (self.ny, self.nz, self.nx + 1)
+        if fid in (F.V, F.JACOBIAN_V): return (self.ny + 1, self.nz, self.nx)
+        if fid in F.IS_2DD: return (self.ny, self.nx)
+        return (self.ny, self.nz, self.nx)
+
+    @staticmethod
+    def fid(name):
+        if isinstance(name, int): return name
+        if name in F.NAMES: return F.NAMES[name]
+        if name in KVARS: return KVARS[name][0]
+        raise KeyError(name)
+
+    def set(self, name, array):
+        """Upload a host array (C-order (ny,nz,nx) == Fortran (i,k,j)) into the named member."""
+        fid = self.fid(name)
+        dt = np.float64 if fid in F.IS_2DD else np.float32
+        a = np.ascontiguousarray(array, dtype=dt)
+        if a.shape != self.shape(fid):
+            raise ValueError(f"{name}: shape {a.shape} != {self.shape(fid)}")
+        check(lib().icar_hip_field_upload(self.ctx, fid, a.ctypes.data_as(ctypes.c_void_p)), f"upload {name}")
+
+    def get(self, name):
+        fid = self.fid(name)
+        a = np.empty(self.shape(fid), np.float64 if fid in F.IS_2DD else np.float32)
+        check(lib().icar_hip_field_download(self.ctx, fid, a.ctypes.data_as(ctypes.c_void_p)), f"download {name}")
+        return a
+
+    def fill(self, name, value):
+        check(lib().icar_hip_field_fill(self.ctx, self.fid(name), ctypes.c_double(value)), f"fill {name}")
+
+    def device_ptr(self, name):
+        p = ctypes.c_void_p()
+        check(lib().icar_hip_field_device_ptr(self.ctx, self.fid(name), ctypes.byref(p)), f"device_ptr {name}")
+        return p.value
+
+    def synchronize(self):
+        check(lib().icar_hip_synchronize(self.ctx), "synchronize")
+
+    def set_stream(self, stream_ptr):
+        check(lib().icar_hip_set_stream(self.ctx, ctypes.c_void_p(stream_ptr)), "set_stream")
+
+    def load_case(self, case):
+        """Upload every member present in an icar_amd.ideal case dict."""
+        alias = {"cloud_water": "cloud_water_mass", "rain": "rain_mass", "snow": "snow_mass",
+                 "cloud_ice": "cloud_ice_mass", "graupel": "graupel_mass", "ice_number": "cloud_ice_number"}
+        for k, v in case.items():
+            name = alias.get(k, k)
+            if isinstance(v, np.ndarray) and name in F.NAMES and v.ndim >= 2:
+                self.set(name, v)
+
+    # ---- halo exchange (H1) ----------------------------------------------------------------
+    def _exchange_fields(self):
+        order = {n: i for i, n in enumerate(ADVECTION_ORDER)}
+        return [KVARS[n][0] for n in sorted(self.exchange_vars, key=lambda n: order[n])]
+
+    def halo_send(self):
+        """domain_obj.f90:109-128: put my edge planes of every exchangeable to the 4 neighbours."""
+        if self.comm is not None:
+            self.comm.send(self, self._exchange_fields())
+
+    def halo_retrieve(self):
+        """domain_obj.f90:130-143: sync with neighbours, then copy the inboxes into my halo planes."""
+        if self.comm is not None:
+            self.comm.retrieve(self, self._exchange_fields())
+
+    def halo_exchange(self):
+        self.halo_send()
+        self.halo_retrieve()
+
+
+# ---- tile interface used by icar_amd.halo.HaloComm (device buffers are torch tensors) ------------
+def _halo_count(self, direction, halo):
+    return int(lib().icar_hip_halo_count(self.ctx, int(direction), int(halo)))
+
+
+def _new_buffer(self, n):
+    import torch
+    return torch.empty(int(n), dtype=torch.float32, device=f"cuda:{torch.cuda.current_device()}")
+
+
+def _halo_pack(self, direction, halo, field_ids, buf):
+    arr = (ctypes.c_int * len(field_ids))(*field_ids)
+    check(lib().icar_hip_halo_pack(self.ctx, int(direction), int(halo), arr, len(field_ids),
+                                   ctypes.c_void_p(buf.data_ptr())), "icar_hip_halo_pack")
+
+
+def _halo_unpack(self, direction, halo, field_ids, buf):
+    arr = (ctypes.c_int * len(field_ids))(*field_ids)
+    check(lib().icar_hip_halo_unpack(self.ctx, int(direction), int(halo), arr, len(field_ids),
+                                     ctypes.c_void_p(buf.data_ptr())), "icar_hip_halo_unpack")
+
+
+domain_t.halo_count = _halo_count
+domain_t.new_buffer = _new_buffer
+domain_t.halo_pack = _halo_pack
+domain_t.halo_unpack = _halo_unpack

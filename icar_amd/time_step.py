@@ -1,0 +1,47 @@
+"""time stepper mirror (src/main/time_step.f90): compute_dt / update_dt / step."""
+import ctypes
+import numpy as np
+from .capi import lib, check, IcarHipError
+from .advection import advect
+from .microphysics import mp
+from .halo import co_min
+
+
+def compute_dt(domain, options):
+    """time_step.f90:217-330, cfl_strictness 3 (the default): CFL / max(sum of face-max winds)."""
+    if options.parameters.cfl_strictness != 3:
+        raise NotImplementedError("only cfl_strictness=3 (the reference default) is on the device path")
+    dzl = np.ascontiguousarray(options.parameters.dz_levels, np.float32)
+    out = ctypes.c_float()
+    check(lib().icar_hip_max_courant(domain.ctx, ctypes.c_float(domain.dx), dzl.ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.byref(out)), "icar_hip_max_courant")
+    dt = np.float32(options.parameters.cfl_reduction_factor) / np.float32(out.value)
+    if dt < 1e-1:
+        raise IcarHipError("ERROR time step too small")      # time_step.f90:322-328 `stop`
+    return float(dt)
+
+
+def update_dt(domain, options, group=None, device=None):
+    """time_step.f90:375-423: local CFL dt, co_min over images, cap at 120 s."""
+    seconds = co_min(compute_dt(domain, options), group=group, device=device)
+    return min(seconds, 120.0)
+
+
+def step(domain, end_time, options, group=None, device=None):
+    """time_step.f90:440-551 for configurations 1-4 (rad/lsm/pbl/cu off): the operator-split loop
+         update_dt -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect.
+    diagnostic_update / apply_forcing are the rank-1 "next" row of SURVEY.md 8(f)."""
+    nsteps = 0
+    while domain.model_time_seconds < end_time:
+        dt = update_dt(domain, options, group=group, device=device)
+        if domain.model_time_seconds + dt > end_time:          # :469-471
+            dt = end_time - domain.model_time_seconds
+        if dt > 1e-3:                                          # :483
+            mp(domain, options, dt, halo=1)                    # :512
+            domain.halo_send()                                 # :515
+            mp(domain, options, dt, subset=1)                  # :523
+            domain.halo_retrieve()                             # :526
+            advect(domain, options, dt)                        # :529
+        domain.model_time_seconds += dt                        # :547
+        nsteps += 1
+    return nsteps

@@ -1,0 +1,150 @@
+/* include/icar_hip.h -- C ABI of libicar_hip.so: the MI355X (gfx950) implementation of ICAR's
+ * per-timestep 3-D grid update (advection + column microphysics + wind balance + halo faces).
+ *
+ * Every entry point replaces one Fortran procedure of the reference (NCAR/icar, cited as
+ * src/...:line).  The reference has no C ABI of its own; the seam chosen is its level-2 physics
+ * kernels, which already take plain REAL(4) arrays + WRF-style index triplets.
+ * The Fortran-2008 iso_c_binding module that binds these (icar_amd/fortran/icar_hip_mod.f90)
+ * and the call sites a maintainer edits are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All 3-D fields are REAL(4) in Fortran order X(ims:ime, kms:kme, jms:jme): i (x) fastest,
+ *    then k (z), then j (y).  u is staggered (ims:ime+1), v is (jms:jme+1).
+ *    2-D accumulators are REAL(8) X(ims:ime, jms:jme) like domain%...%data_2dd.
+ *  - Index arguments (its..kte, ids..kde) are in the same index space as the ims..jme given at
+ *    context creation (any lower bound), inclusive, exactly as the reference passes them.
+ *  - Functions return 0 on success, non-zero on error; icar_hip_last_error() gives the text.
+ *    (The reference's convention is `stop`/`error stop`; the Fortran binding maps !=0 to error stop.)
+ *  - One context per coarray image / GPU; calls on a context are serialised by the caller
+ *    (same as the reference's module-level SAVE state, which the context replaces).
+ *  - No CPU fallback exists: without a visible gfx950 device icar_hip_ctx_create fails.
+ */
+#ifndef ICAR_HIP_H
+#define ICAR_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icar_hip_ctx icar_hip_ctx;
+
+/* Field ids mirror the domain_t members the path touches (src/objects/domain_h.f90:35-50,283-293)
+ * and the kVARS order used by the advection dispatch (src/physics/adv_mpdata.f90:512-522). */
+enum icar_hip_field {
+    ICAR_F_WATER_VAPOR = 0,        /* domain%water_vapor%data_3d            */
+    ICAR_F_CLOUD_WATER = 1,        /* domain%cloud_water_mass%data_3d       */
+    ICAR_F_RAIN = 2,               /* domain%rain_mass%data_3d              */
+    ICAR_F_SNOW = 3,               /* domain%snow_mass%data_3d              */
+    ICAR_F_POTENTIAL_TEMPERATURE = 4,
+    ICAR_F_CLOUD_ICE = 5,          /* domain%cloud_ice_mass%data_3d         */
+    ICAR_F_GRAUPEL = 6,            /* domain%graupel_mass%data_3d           */
+    ICAR_F_ICE_NUMBER = 7,         /* domain%cloud_ice_number%data_3d       */
+    ICAR_F_RAIN_NUMBER = 8,        /* domain%rain_number%data_3d            */
+    ICAR_F_SNOW_NUMBER = 9,        /* domain%snow_number%data_3d            */
+    ICAR_F_GRAUPEL_NUMBER = 10,    /* domain%graupel_number%data_3d         */
+    ICAR_N_ADVECTABLE = 11,
+    ICAR_F_U = 11,                 /* domain%u%data_3d   (nx+1, nz, ny)     */
+    ICAR_F_V = 12,                 /* domain%v%data_3d   (nx, nz, ny+1)     */
+    ICAR_F_W = 13,                 /* domain%w%data_3d                      */
+    ICAR_F_PRESSURE = 14,
+    ICAR_F_EXNER = 15,
+    ICAR_F_DENSITY = 16,
+    ICAR_F_DZ_MASS = 17,           /* domain%dz_mass%data_3d                */
+    ICAR_F_JACOBIAN = 18,          /* domain%jacobian                       */
+    ICAR_F_JACOBIAN_U = 19,        /* (nx+1, nz, ny)                        */
+    ICAR_F_JACOBIAN_V = 20,        /* (nx, nz, ny+1)                        */
+    ICAR_F_JACOBIAN_W = 21,
+    ICAR_F_ADVECTION_DZ = 22,      /* domain%advection_dz                   */
+    ICAR_F_PRECIPITATION = 23,     /* domain%accumulated_precipitation%data_2dd  REAL(8) (nx,ny) */
+    ICAR_F_SNOWFALL = 24,          /* domain%accumulated_snowfall%data_2dd       REAL(8) (nx,ny) */
+    ICAR_F_GRAUPEL_ACC = 25,       /* domain%graupel%data_2dd                    REAL(8) (nx,ny) */
+    ICAR_N_FIELDS = 26
+};
+
+enum { ICAR_ADV_UPWIND = 1, ICAR_ADV_MPDATA = 2 };   /* kADV_UPWIND / kADV_MPDATA, icar_constants.f90:341 */
+
+/* ---- context + device-resident field mirrors (replaces module SAVE state) ---- */
+int icar_hip_ctx_create(icar_hip_ctx **ctx, int device,
+                        int ims, int ime, int kms, int kme, int jms, int jme);
+int icar_hip_ctx_destroy(icar_hip_ctx *ctx);
+/* Run all kernels of this context on the caller's HIP stream (hipStream_t); NULL = own stream. */
+int icar_hip_set_stream(icar_hip_ctx *ctx, void *hip_stream);
+int icar_hip_synchronize(icar_hip_ctx *ctx);
+/* Lazily allocates the device mirror of a field.  Host buffers are the domain_t arrays
+ * (contiguous, Fortran order).  Element count: icar_hip_field_count(). */
+int icar_hip_field_upload(icar_hip_ctx *ctx, int field, const void *host);
+int icar_hip_field_download(icar_hip_ctx *ctx, int field, void *host);
+int icar_hip_field_fill(icar_hip_ctx *ctx, int field, double value);
+/* Current device pointer of a field (advect() ping-pongs the advected scalars, so re-query
+ * after every icar_hip_advect call). */
+int icar_hip_field_device_ptr(icar_hip_ctx *ctx, int field, void **dptr);
+size_t icar_hip_field_count(const icar_hip_ctx *ctx, int field);
+size_t icar_hip_field_elem_size(int field);
+
+/* ---- A1: Courant-number winds U_m,V_m,W_m -----------------------------------------------------
+ * replaces setup_module_winds (src/physics/advect.f90:306-351, scheme=1) and the inline block of
+ * mpdata (src/physics/adv_mpdata.f90:496-506, scheme=2; the two differ in multiplication order). */
+int icar_hip_setup_winds(icar_hip_ctx *ctx, int scheme, float dt, float dx, int advect_density);
+
+/* ---- A2-A5: advect the listed scalars with the winds of the last icar_hip_setup_winds --------
+ * replaces the per-variable advect3d dispatch of upwind (src/physics/advect.f90:380-418) and
+ * mpdata (src/physics/adv_mpdata.f90:463-524; advect3d :356-418, upwind_advection :44-105,
+ * mpdata_fluxes :107-255, flux_limiter :257-354 + adv_mpdata_FCT_core.f90:47-116).
+ * fields[] are ICAR_F_* ids < ICAR_N_ADVECTABLE (the caller derives them from
+ * options%vars_to_advect); mpdata_order / fct = options%adv_options. */
+int icar_hip_advect(icar_hip_ctx *ctx, int scheme, int mpdata_order, int fct, int advect_density,
+                    const int *fields, int nfields);
+
+/* ---- M1: mp_simple_driver (src/physics/mp_simple.f90:595-646) on the tile its..kte -----------
+ * uses PRESSURE, POTENTIAL_TEMPERATURE, EXNER, DENSITY, WATER_VAPOR, CLOUD_WATER, RAIN, SNOW,
+ * DZ_MASS; adds the tile's surface fluxes to PRECIPITATION / SNOWFALL exactly as
+ * process_subdomain does (src/physics/mp_driver.f90:587-595).  *err_count (may be NULL) receives
+ * the number of columns on which the reference would have hit its `stop` in phase_change. */
+int icar_hip_mp_simple(icar_hip_ctx *ctx, float dt,
+                       int its, int ite, int jts, int jte, int kts, int kte, int *err_count);
+
+/* ---- M2-M4: Thompson microphysics ------------------------------------------------------------
+ * thompson_init (src/physics/mp_thompson.f90:342-766; params/flags = mp_options_type in the
+ * order Nt_c,TNO,am_s,rho_g,av_s,bv_s,fv_s,av_g,bv_g,av_i,Ef_si,Ef_rs,Ef_rg,Ef_ri,C_cubes,
+ * C_sqrd,mu_r,t_adjust ; Ef_rw_l,Ef_sw_l) and mp_gt_driver (:772-1044). */
+int icar_hip_thompson_init(icar_hip_ctx *ctx, const float params[18], const int flags[2]);
+int icar_hip_thompson(icar_hip_ctx *ctx, float dt,
+                      int its, int ite, int jts, int jte, int kts, int kte,
+                      int ids, int ide, int jds, int jde, int kds, int kde);
+
+/* ---- M0: tile bookkeeping of mp()/process_halo (src/physics/mp_driver.f90:609-772) -----------
+ * Fills tiles[n][4] = {its,ite,jts,jte} for halo>0 (W,E,S,N strips; corners once) or for the
+ * interior shrunk by subset; returns the number of tiles (integer-exact restatement). */
+int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, int tiles[4][4]);
+
+/* ---- T2: CFL reduction for compute_dt (src/main/time_step.f90:217-330, cfl_strictness 3) -----
+ * out = max over the tile of max(|u_i|,|u_i+1|)/dx + max(|v_j|,|v_j+1|)/dx + max(|w_k|,|w_k-1|)/dz_levels(k) */
+int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, float *out);
+
+/* ---- W1: balance_uvw (src/physics/wind.f90:81-169): w from the horizontal divergence ---------- */
+int icar_hip_balance_uvw(icar_hip_ctx *ctx, float dx);
+
+/* ---- H1: halo faces (src/objects/exchangeable_obj.f90:138-356) --------------------------------
+ * dir: 0=north 1=south 2=east 3=west.  pack gathers what exchangeable%put_<dir> would PUT
+ * (my interior planes next to that edge, width halo, N/S over the full memory width so corners
+ * travel) for all listed fields into one contiguous device buffer; unpack scatters a received
+ * buffer into my halo planes like retrieve_<dir>_halo.  Buffers are device pointers; the element
+ * count per field is icar_hip_halo_count(). */
+size_t icar_hip_halo_count(const icar_hip_ctx *ctx, int dir, int halo);
+int icar_hip_halo_pack(icar_hip_ctx *ctx, int dir, int halo, const int *fields, int nfields, void *dbuf);
+int icar_hip_halo_unpack(icar_hip_ctx *ctx, int dir, int halo, const int *fields, int nfields, const void *dbuf);
+
+/* ---- measurement helpers --------------------------------------------------------------------- */
+/* Average duration (ms) of the launches of a named kernel group since the last reset, measured
+ * with HIP events on the context's stream (bench.py roofline block). group: "advect", "mp". */
+int icar_hip_timing_enable(icar_hip_ctx *ctx, int on);
+int icar_hip_timing_read(icar_hip_ctx *ctx, const char *group, double *total_ms, int *launches);
+int icar_hip_timing_reset(icar_hip_ctx *ctx);
+
+const char *icar_hip_last_error(void);
+const char *icar_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICAR_HIP_H */

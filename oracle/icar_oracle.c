@@ -16,6 +16,10 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
+
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { omp_set_num_threads(n); }
 
 #define IDX(i,k,j) ((size_t)(i) + (size_t)nx*((size_t)(k) + (size_t)nz*(size_t)(j)))
 
@@ -70,6 +74,7 @@ void orc_upwind_pass(int nx, int nz, int ny, const float *qin,
     float *out = q;
     float *tmp = NULL;
     if (q == qin) { tmp = (float *)malloc(sizeof(float) * (size_t)nx * nz * ny); memcpy(tmp, qin, sizeof(float) * (size_t)nx * nz * ny); qin = tmp; }
+#pragma omp parallel for schedule(static)
     for (int j = 1; j < ny - 1; ++j)
         for (int k = 0; k < nz; ++k)
             for (int i = 1; i < nx - 1; ++i) {
@@ -108,6 +113,7 @@ void orc_mpdata_fluxes(int nx, int nz, int ny, const float *q,
     memset(v2, 0, n * sizeof(float));
     memset(w2, 0, n * sizeof(float));
 #define Q(i,k,j) q[IDX(i,k,j)]
+#pragma omp parallel for schedule(static)
     for (int j = 0; j < ny; ++j)
         for (int k = 0; k < nz; ++k) {
             /* U component: faces i=1..nx-1 (":134 if (i>0)" is always true) */
@@ -242,8 +248,11 @@ void orc_flux_limiter(int nx, int nz, int ny, const float *q, const float *q2,
                       float *u2, float *v2, float *w2)
 {
     int nmax = nx > ny ? nx : ny; if (nz > nmax) nmax = nz;
+#pragma omp parallel
+    {
     float *q1 = (float *)malloc(sizeof(float) * nmax * 4);
     float *l = q1 + nmax, *U2 = l + nmax, *f = U2 + nmax;
+#pragma omp for schedule(static)
     for (int j = 1; j < ny - 1; ++j) {
         for (int k = 0; k < nz; ++k) {            /* x-lines :295-304 */
             for (int i = 0; i < nx; ++i) { q1[i] = q2[IDX(i, k, j)]; l[i] = q[IDX(i, k, j)]; }
@@ -259,6 +268,7 @@ void orc_flux_limiter(int nx, int nz, int ny, const float *q, const float *q2,
             w2[IDX(i, nz - 1, j)] = 0;
         }
     }
+#pragma omp for schedule(static)
     for (int i = 0; i < nx; ++i)                  /* y-lines :340-350, all i,k */
         for (int k = 0; k < nz; ++k) {
             for (int j = 0; j < ny; ++j) { q1[j] = q2[IDX(i, k, j)]; l[j] = q[IDX(i, k, j)]; }
@@ -267,6 +277,7 @@ void orc_flux_limiter(int nx, int nz, int ny, const float *q, const float *q2,
             for (int j = 0; j < ny - 1; ++j) v2[IDX(i, k, j + 1)] = U2[j];
         }
     free(q1);
+    }
 }
 
 /* A5: src/physics/adv_mpdata.f90:356-418 (order 1 or 2).  rho==NULL means rho=1. */
@@ -278,8 +289,10 @@ void orc_advect3d_mpdata(int nx, int nz, int ny, float *q, const float *U, const
     float *u2 = q2 + n, *v2 = u2 + n, *w2 = v2 + n, *wdz = w2 + n, *G = wdz + n, *qnew = G + n;
     orc_upwind_pass(nx, nz, ny, q, U, V, W, rho, jaco, dz, q2);
     if (order < 2) { memcpy(q, q2, n * sizeof(float)); free(q2); return; }
+#pragma omp parallel for schedule(static)
     for (size_t c = 0; c < n; ++c) { wdz[c] = W[c] / dz[c]; G[c] = jaco[c] * (rho ? rho[c] : 1.0f); }
     orc_mpdata_fluxes(nx, nz, ny, q2, U, V, wdz, G, u2, v2, w2);
+#pragma omp parallel for schedule(static)
     for (size_t c = 0; c < n; ++c) { u2[c] = u2[c] * 0.5f; v2[c] = v2[c] * 0.5f; w2[c] = w2[c] * 0.5f * dz[c]; }
     if (fct) orc_flux_limiter(nx, nz, ny, q, q2, u2, v2, w2);
     orc_upwind_pass(nx, nz, ny, q2, u2, v2, w2, rho, jaco, dz, qnew);
@@ -323,12 +336,22 @@ void orc_advect(int scheme, int nx, int nz, int ny, int nvars, float *q,
 
 typedef struct { float cloud2rain, cloud2snow; int err; } mps_consts;
 
+/* Transcendental mode.  0 (default): libm expf exactly as the flang-compiled reference calls it
+ * => the oracle is bit-identical to oracle/_ref.  1: exp evaluated in FP64 and rounded once
+ * (correctly rounded in all but ~1e-8 of cases) -- the same definition the HIP kernels use, so
+ * HIP-vs-oracle(mode 1) is a bit-exact check of the device code, while oracle(0)-vs-oracle(1)
+ * measures the scheme's own sensitivity to a 1-ulp change in exp (threshold flips in the
+ * saturation adjustment, mp_simple.f90:217). */
+static int g_math_mode = 0;
+void orc_set_math_mode(int m) { g_math_mode = m; }
+static inline float orc_expf(float x) { return g_math_mode ? (float)exp((double)x) : expf(x); }
+
 static float sat_mr(float temperature, float pressure)
 {   /* :146-182 */
     float a, b;
     if (temperature < freezing_threshold) { a = 21.8745584f; b = 7.66f; }
     else { a = 17.2693882f; b = 35.86f; }
-    float e_s = 610.78f * expf(a * (temperature - 273.16f) / (temperature - b));
+    float e_s = 610.78f * orc_expf(a * (temperature - 273.16f) / (temperature - b));
     if ((pressure - e_s) <= 0) e_s = pressure * 0.99999f;
     return 0.6219907f * e_s / (pressure - e_s);
 }
@@ -492,9 +515,14 @@ int orc_mp_simple(int nx, int nz, int ny, float *pressure, float *th, const floa
     C.cloud2snow = expf(-1.0f * (1 / 2000.0f) * dt);
     C.cloud2rain = expf(-1.0f * (1 / 500.0f) * dt);
     C.err = 0;
+    int any_err = 0;
+#pragma omp parallel reduction(|:any_err)
+    {
+    mps_consts Ct = C;
     float *col = (float *)malloc(sizeof(float) * nz * 10);
     float *p1 = col, *t1 = p1 + nz, *r1 = t1 + nz, *v1 = r1 + nz, *c1 = v1 + nz, *rr1 = c1 + nz, *s1 = rr1 + nz,
           *d1 = s1 + nz, *fall = d1 + nz, *flux = fall + nz;
+#pragma omp for schedule(dynamic, 1)
     for (int j = jts - 1; j <= jte - 1; ++j)
         for (int i = its - 1; i <= ite - 1; ++i) {
             for (int k = 0; k < nz; ++k) {
@@ -503,12 +531,15 @@ int orc_mp_simple(int nx, int nz, int ny, float *pressure, float *th, const floa
                 rr1[k] = qr[c]; s1[k] = qs[c]; d1[k] = dz[c];
             }
             mp_simple_column(p1, t1, r1, v1, c1, rr1, s1, &rain[i + (size_t)nx * j], &snow[i + (size_t)nx * j], dt, d1,
-                             nz, kts - 1, kte - 1, &C, fall, flux);
+                             nz, kts - 1, kte - 1, &Ct, fall, flux);
             for (int k = 0; k < nz; ++k) {
                 const size_t c = IDX(i, k, j);
                 th[c] = t1[k] / pii[c]; qv[c] = v1[k]; qc[c] = c1[k]; qr[c] = rr1[k]; qs[c] = s1[k];
             }
         }
     free(col);
+    any_err |= Ct.err;
+    }
+    C.err = any_err;
     return C.err;
 }

@@ -65,3 +65,16 @@ def mp_simple(pressure, th, pii, rho, qv, qc, qr, qs, rain, snow, dt, dz, its, i
     fn.restype = ctypes.c_int
     return fn(_i(nx), _i(nz), _i(ny), _p(pressure), _p(th), _p(pii), _p(rho), _p(qv), _p(qc), _p(qr),
               _p(qs), _p(rain), _p(snow), _f(dt), _p(dz), _i(its), _i(ite), _i(jts), _i(jte), _i(kts), _i(kte))
+
+
+def set_math_mode(mode):
+    """0: libm expf (bit-identical to the compiled reference); 1: FP64 exp rounded once (what the HIP kernels do)."""
+    lib().orc_set_math_mode(_i(mode))
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(_i(n))
