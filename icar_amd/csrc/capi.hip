@@ -4,6 +4,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <algorithm>
 
 static thread_local std::string g_err;
 void icar_set_error(const std::string &msg) { g_err = msg; }
@@ -142,21 +143,26 @@ int icar_halo_pack(icar_hip_ctx *c, int dir, int h, const int *fields, int n, fl
 // ------------------------------------------------------------------------------------------------
 // T2: compute_dt strictness-3 reduction (time_step.f90:264-289)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_max_courant(Dims d, const float *__restrict__ u, const float *__restrict__ v,
-                              const float *__restrict__ w, const float *__restrict__ dzl, float dx,
-                              unsigned *__restrict__ out)
+__global__ void __launch_bounds__(256)
+k_max_courant(Dims d, const float *__restrict__ u, const float *__restrict__ v,
+              const float *__restrict__ w, const float *__restrict__ dzl, float dx,
+              unsigned *__restrict__ out)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    const int k = blockIdx.y * 4 + threadIdx.y;
-    const int j = blockIdx.z;
+    // grid-stride over (k,j) lines, lanes along i; one atomic per block at the end
     float cur = 0.0f;
-    if (i < d.nx && k < d.nz) {
-        const int c = d.idx(i, k, j);
-        const int cu = i + (d.nx + 1) * (k + d.nz * j);
+    const int nlines = d.nz * d.ny;
+    for (int line = blockIdx.x * 4 + threadIdx.y; line < nlines; line += gridDim.x * 4) {
+        const int k = line % d.nz, j = line / d.nz;
         const int zo = (k == 0) ? 0 : -d.sk;
-        cur = fmaxf(fabsf(u[cu]), fabsf(u[cu + 1])) / dx
-            + fmaxf(fabsf(v[c]), fabsf(v[c + d.sj])) / dx
-            + fmaxf(fabsf(w[c]), fabsf(w[c + zo])) / dzl[k];
+        const float rdz = dzl[k];
+        for (int i = threadIdx.x; i < d.nx; i += 64) {
+            const int c = d.idx(i, k, j);
+            const int cu = i + (d.nx + 1) * (k + d.nz * j);
+            const float cw = fmaxf(fabsf(u[cu]), fabsf(u[cu + 1])) / dx
+                           + fmaxf(fabsf(v[c]), fabsf(v[c + d.sj])) / dx
+                           + fmaxf(fabsf(w[c]), fabsf(w[c + zo])) / rdz;
+            cur = fmaxf(cur, cw);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) cur = fmaxf(cur, __shfl_down(cur, o));
     __shared__ float s[4];
@@ -175,7 +181,9 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
     float *dzl = c->d_red + 16;
     HIPCHK(hipMemcpyAsync(dzl, dz_levels, sizeof(float) * c->d.nz, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_red, 0, sizeof(float), c->stream));
-    dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
+    const int nlines = c->d.nz * c->d.ny;
+    dim3 g(std::min((nlines + 3) / 4, 2048)), b(64, 4);
+    ScopedTimer t(c, "cfl");
     hipLaunchKernelGGL(k_max_courant, g, b, 0, c->stream, c->d, u, v, w, dzl, dx, (unsigned *)c->d_red);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, c->d_red, sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -62,8 +62,12 @@ def balance_uvw(u, v, jaco_u, jaco_v, jaco_w, dz, dx):
 
 
 def make_case(nx, ny, nz, dx=1000.0, hill_height=0.0, u0=10.0, v0=3.0, uniform_dz=None,
-              blob_amp=0.004, noise=0.0, seed=1234, n_hydro=0, cool=0.0):
+              blob_amp=0.004, noise=0.0, seed=1234, n_hydro=0, cool=0.0, exact=False):
     """Build the synthetic state described in SURVEY.md section 8(d).
+
+    exact=True builds the same kind of state from IEEE-exact operations only (+,-,*,/,sqrt; rational
+    bumps instead of cos/exp/pow) so that the inputs are bit-reproducible on any host CPU/libm --
+    used by the large golden fixtures whose inputs are regenerated rather than stored.
 
     Returns a dict of float32 arrays: u,v,w,jacobian,jacobian_u,jacobian_v,jacobian_w,
     advection_dz,dz_levels,dz_mass,pressure,exner,density,potential_temperature,water_vapor,
@@ -71,7 +75,12 @@ def make_case(nx, ny, nz, dx=1000.0, hill_height=0.0, u0=10.0, v0=3.0, uniform_d
     """
     f32 = np.float32
     dzl = dz_levels(nz, uniform_dz)
-    terrain = cosine_hill(nx, ny, hill_height) if hill_height > 0 else np.zeros((ny, nx), f32)
+    if hill_height > 0 and exact:
+        xg = (np.arange(nx, dtype=np.float64) / max(nx - 1, 1) * 2 - 1); yg = (np.arange(ny, dtype=np.float64) / max(ny - 1, 1) * 2 - 1)
+        bx = (1 - xg * xg) * (1 - xg * xg); by = (1 - yg * yg) * (1 - yg * yg)
+        terrain = (by[:, None] * bx[None, :] * hill_height).astype(f32)
+    else:
+        terrain = cosine_hill(nx, ny, hill_height) if hill_height > 0 else np.zeros((ny, nx), f32)
     Hs = f32(dzl.sum())
     jac2d = ((Hs - terrain) / Hs).astype(f32)
     jaco = np.ascontiguousarray(np.broadcast_to(jac2d[:, None, :], (ny, nz, nx))).astype(f32)
@@ -96,19 +105,33 @@ def make_case(nx, ny, nz, dx=1000.0, hill_height=0.0, u0=10.0, v0=3.0, uniform_d
     z_if = np.concatenate([[0.0], np.cumsum(dzl.astype(np.float64))])
     zc = 0.5 * (z_if[1:] + z_if[:-1])
     z = terrain[:, None, :].astype(np.float64) + zc[None, :, None] * jac2d[:, None, :]
-    theta = 300.0 + 43.0 * np.minimum(z / 12000.0, 1.0) ** 1.25
-    theta = theta - cool
-    p = 1.0e5 * (1.0 - 2.25577e-5 * z) ** 5.25588
-    exner = (p / 1.0e5) ** (float(RD) / float(CP))
-    T = theta * exner
-    rho = p / (float(RD) * T)
-    qsat = sat_mr(T, p)
-    qv = 0.8 * qsat * np.where(z < 3000.0, 1.0, np.exp(-(z - 3000.0) / 2500.0))
     ii = np.arange(nx, dtype=np.float64)[None, None, :]
     jj = np.arange(ny, dtype=np.float64)[:, None, None]
     sig = max(nx / 8.0, 1.5)
-    blob = blob_amp * np.exp(-(((ii - nx / 2.0) ** 2 + (jj - ny / 2.0) ** 2) / (2 * sig * sig)))
-    qv = qv + blob * np.exp(-z / 2500.0)
+    r2 = ((ii - nx / 2.0) * (ii - nx / 2.0) + (jj - ny / 2.0) * (jj - ny / 2.0)) / (2 * sig * sig)
+    if exact:
+        xz = np.minimum(z / 12000.0, 1.0)
+        theta = 300.0 + 43.0 * xz * np.sqrt(np.sqrt(xz)) - cool
+        b = 1.0 - z / 44330.0
+        p = 1.0e5 * b * b * b * b * b
+        exner = np.sqrt(np.sqrt(p / 1.0e5))
+        T = theta * exner
+        rho = p / (float(RD) * T)
+        zs = z / 2000.0
+        qv = 0.8 * 0.008 / (1.0 + zs * zs)
+        blob = blob_amp / ((1.0 + r2) * (1.0 + r2))
+        qv = qv + blob / (1.0 + z / 2500.0)
+    else:
+        theta = 300.0 + 43.0 * np.minimum(z / 12000.0, 1.0) ** 1.25
+        theta = theta - cool
+        p = 1.0e5 * (1.0 - 2.25577e-5 * z) ** 5.25588
+        exner = (p / 1.0e5) ** (float(RD) / float(CP))
+        T = theta * exner
+        rho = p / (float(RD) * T)
+        qsat = sat_mr(T, p)
+        qv = 0.8 * qsat * np.where(z < 3000.0, 1.0, np.exp(-(z - 3000.0) / 2500.0))
+        blob = blob_amp * np.exp(-r2)
+        qv = qv + blob * np.exp(-z / 2500.0)
     if noise > 0:
         rng = np.random.default_rng(seed)
         qv = qv * (1.0 + noise * rng.uniform(-1, 1, qv.shape))

@@ -1,0 +1,112 @@
+"""N>1 path on CPU: world_size 2 and 4 over gloo.  Exercises the product's grid_t decomposition,
+HaloComm (neighbour sets, batched send/recv, retrieve) and co_min with a host-array tile double,
+and checks the reference's halo semantics (exchangeable_obj.f90):
+  * after one exchange every non-corner halo cell equals the neighbour's interior value,
+    corners (which ride on the N/S messages over the full memory width) are one exchange stale;
+  * N steps of [exchange -> upwind advect per tile] reproduce the single-tile result on every
+    owned cell bit-for-bit (radius-1 stencil)."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NXG, NYG, NZ = 38, 30, 6
+
+
+def global_field(seed=0):
+    j, k, i = np.meshgrid(np.arange(NYG), np.arange(NZ), np.arange(NXG), indexing="ij")
+    return (1.0 + 0.01 * i + 0.1 * j + 3.0 * k + 0.001 * seed * i * j).astype(np.float32)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from icar_amd.grid import grid_t
+        from icar_amd.halo import HaloComm, co_min
+        from icar_amd import ideal
+        from host_tile import HostTile
+        from oracle import orc
+        g = grid_t().set_grid_dimensions(NXG, NYG, NZ, world, rank + 1)
+        sl = (slice(g.jms - 1, g.jme), slice(None), slice(g.ims - 1, g.ime))
+        # ---- 1. halo semantics on two analytic fields exchanged in ONE message per neighbour
+        G0, G1 = global_field(0), global_field(3)
+        f = {0: G0[sl].copy(), 4: G1[sl].copy()}
+        h = g.halo_size
+        for a in f.values():          # poison my halo planes
+            if not g.north_boundary: a[-h:] = -1
+            if not g.south_boundary: a[:h] = -1
+            if not g.east_boundary: a[:, :, -h:] = -1
+            if not g.west_boundary: a[:, :, :h] = -1
+        tile = HostTile(g, f); comm = HaloComm(g, rank + 1)
+        comm.send(tile, [0, 4]); comm.retrieve(tile, [0, 4])
+        for fid, G in ((0, G0), (4, G1)):
+            bad = f[fid] != G[sl]
+            # only corner halo cells (both an x-halo and a y-halo) may still be stale
+            xh = np.zeros(bad.shape, bool); yh = np.zeros(bad.shape, bool)
+            if not g.west_boundary: xh[:, :, :h] = True
+            if not g.east_boundary: xh[:, :, -h:] = True
+            if not g.south_boundary: yh[:h] = True
+            if not g.north_boundary: yh[-h:] = True
+            assert not (bad & ~(xh & yh)).any(), f"rank {rank}: non-corner halo wrong after exchange"
+        comm.send(tile, [0, 4]); comm.retrieve(tile, [0, 4])
+        assert np.array_equal(f[0], G0[sl]) and np.array_equal(f[4], G1[sl]), "corners must be right after 2 exchanges"
+        # ---- 2. co_min
+        assert co_min(10.0 + rank) == 10.0
+        # ---- 3. tiled upwind == single-tile upwind on owned cells
+        case = ideal.make_case(NXG, NYG, NZ, hill_height=600.0, noise=0.02, n_hydro=1, exact=True)
+        dt = 0.8 * ideal.cfl_dt(case)
+        names = ["water_vapor", "cloud_water"]
+        def tile_of(a, stag=None):
+            if stag == "u": return np.ascontiguousarray(a[g.jms - 1:g.jme, :, g.ims - 1:g.ime + 1])
+            if stag == "v": return np.ascontiguousarray(a[g.jms - 1:g.jme + 1, :, g.ims - 1:g.ime])
+            return np.ascontiguousarray(a[sl])
+        loc = {n: tile_of(case[n]) for n in ["w", "density", "jacobian", "jacobian_w", "advection_dz"] + names}
+        loc["u"] = tile_of(case["u"], "u"); loc["jacobian_u"] = tile_of(case["jacobian_u"], "u")
+        loc["v"] = tile_of(case["v"], "v"); loc["jacobian_v"] = tile_of(case["jacobian_v"], "v")
+        tile = HostTile(g, {0: loc["water_vapor"], 1: loc["cloud_water"]}); comm = HaloComm(g, rank + 1)
+        for _ in range(3):
+            comm.send(tile, [0, 1]); comm.retrieve(tile, [0, 1])
+            q_ = np.stack([loc[n] for n in names])
+            orc.advect(1, q_, loc["u"], loc["v"], loc["w"], loc["density"], loc["jacobian"], loc["jacobian_u"], loc["jacobian_v"],
+                       loc["jacobian_w"], loc["advection_dz"], case["dz_levels"], float(case["dx"]), dt)
+            for m, n in enumerate(names): loc[n][...] = q_[m]
+        if rank == 0:
+            qg = np.stack([case[n] for n in names]).copy()
+            orc.advect(1, qg, case["u"], case["v"], case["w"], case["density"], case["jacobian"], case["jacobian_u"],
+                       case["jacobian_v"], case["jacobian_w"], case["advection_dz"], case["dz_levels"], float(case["dx"]), dt, nsteps=3)
+            ref_bytes = qg.tobytes()
+        else:
+            ref_bytes = None
+        obj = [ref_bytes]; dist.broadcast_object_list(obj, src=0)
+        qg = np.frombuffer(obj[0], np.float32).reshape(2, NYG, NZ, NXG)
+        oj = slice(g.jts - g.jms, g.jte - g.jms + 1); oi = slice(g.its - g.ims, g.ite - g.ims + 1)
+        for m, n in enumerate(names):
+            want = qg[m][g.jts - 1:g.jte, :, g.its - 1:g.ite]
+            assert np.array_equal(loc[n][oj, :, oi], want), f"rank {rank} {n}: tiled result differs from single tile"
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_halo_exchange_and_tiled_advection_gloo(world):
+    from oracle import orc
+    orc.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + world + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs: p.join(timeout=60)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
