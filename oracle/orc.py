@@ -78,3 +78,26 @@ def num_threads():
 
 def set_num_threads(n):
     lib().orc_set_num_threads(_i(n))
+
+
+def thompson_init(params, flags=(0, 0), build_tables=True):
+    p = np.ascontiguousarray(params, np.float32); f = np.ascontiguousarray(flags, np.int32)
+    lib().orc_thompson_init(_p(p), _p(f), _i(build_tables))
+
+
+def thompson_table(name):
+    fn = lib().orc_thompson_table
+    fn.restype = ctypes.POINTER(ctypes.c_double)
+    n = ctypes.c_size_t()
+    ptr = fn(name.encode(), ctypes.byref(n))
+    if not ptr:
+        raise KeyError(name)
+    return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+
+def thompson(qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, dt, rainnc, rainncv, snownc, graupelnc, sr,
+             ids, ide, jds, jde, kds, kde, its, ite, jts, jte, kts, kte):
+    ny, nz, nx = qv.shape
+    lib().orc_thompson(_i(nx), _i(nz), _i(ny), _p(qv), _p(qc), _p(qr), _p(qi), _p(qs), _p(qg), _p(ni), _p(nr), _p(th),
+                       _p(pii), _p(p), _p(dz), _f(dt), _p(rainnc), _p(rainncv), _p(snownc), _p(graupelnc), _p(sr),
+                       *[_i(x) for x in (ids, ide, jds, jde, kds, kde, its, ite, jts, jte, kts, kte)])

@@ -92,3 +92,21 @@ def thompson(qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, dt, rainnc, rainncv
                        _p(p), _p(dz), _f(dt), _p(rainnc), _p(rainncv), _p(snownc), _p(graupelnc), _p(sr),
                        *[ctypes.c_int(int(x)) for x in (ids, ide, jds, jde, kds, kde,
                                                         its, ite, jts, jte, kts, kte)])
+
+
+THOMPSON_TABLES = ["tcg_racg", "tmr_racg", "tcr_gacr", "tmg_gacr", "tnr_racg", "tnr_gacr", "tcs_racs1", "tmr_racs1", "tcs_racs2",
+                   "tmr_racs2", "tcr_sacr1", "tms_sacr1", "tcr_sacr2", "tms_sacr2", "tnr_racs1", "tnr_racs2", "tnr_sacr1", "tnr_sacr2",
+                   "tpi_qcfz", "tni_qcfz", "tpi_qrfz", "tpg_qrfz", "tni_qrfz", "tnr_qrfz", "tps_iaus", "tni_iaus", "tpi_ide",
+                   "t_Efrw", "t_Efsw", "rate_constants", "size_bins"]
+
+
+def thompson_table(name):
+    """One of the reference's module-level Thompson tables (after thompson_init) as a flat float64 array."""
+    tid = THOMPSON_TABLES.index(name) + 1
+    buf = np.empty(28 * 28 * 37 * 37, np.float64)
+    fn = lib().ref_thompson_table
+    fn.restype = ctypes.c_int
+    m = fn(ctypes.c_int(tid), ctypes.c_int(buf.size), buf.ctypes.data_as(ctypes.c_void_p))
+    if m < 0:
+        raise KeyError(name)
+    return buf[:m].copy()

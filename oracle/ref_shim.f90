@@ -22,7 +22,12 @@ module icar_ref_shim
   use adv_mpdata,        only: mpdata
   use adv_upwind,        only: upwind
   use module_mp_simple,  only: mp_simple_driver
-  use module_mp_thompson,only: thompson_init, mp_gt_driver
+  use module_mp_thompson,only: thompson_init, mp_gt_driver, &
+       tcg_racg, tmr_racg, tcr_gacr, tmg_gacr, tnr_racg, tnr_gacr, tcs_racs1, tmr_racs1, tcs_racs2, tmr_racs2, &
+       tcr_sacr1, tms_sacr1, tcr_sacr2, tms_sacr2, tnr_racs1, tnr_racs2, tnr_sacr1, tnr_sacr2, tpi_qcfz, tni_qcfz, &
+       tpi_qrfz, tpg_qrfz, tni_qrfz, tnr_qrfz, tps_iaus, tni_iaus, tpi_ide, t_Efrw, t_Efsw, &
+       t1_qr_qc, t1_qr_qi, t2_qr_qi, t1_qg_qc, t1_qs_qc, t1_qs_qi, t1_qr_ev, t2_qr_ev, t1_qs_sd, t2_qs_sd, &
+       t1_qg_sd, t2_qg_sd, t1_qs_me, t2_qs_me, t1_qg_me, t2_qg_me, Dc, Di, Dr, Ds, Dg, dtc, dti, dtr, dts, dtg
   implicit none
   type(options_t), save :: options
   type(domain_t), allocatable, save :: domain
@@ -121,4 +126,54 @@ contains
                       ims=1, ime=nx, jms=1, jme=ny, kms=1, kme=nz, &
                       its=its, ite=ite, jts=jts, jte=jte, kts=kts, kte=kte)
   end subroutine
+
+  !> Copy one of the reference's (public) Thompson lookup tables / constants into out(n). Returns the
+  !! number of elements, or -1 for an unknown id.  ids follow oracle/ref.py:THOMPSON_TABLES.
+  integer(c_int) function ref_thompson_table(id, n, out) bind(C, name="ref_thompson_table")
+    integer(c_int), value :: id, n
+    real(c_double), intent(out) :: out(n)
+    integer :: m
+    m = -1
+    select case (id)
+    case (1);  m = size(tcg_racg);  if (m<=n) out(1:m) = reshape(tcg_racg, [m])
+    case (2);  m = size(tmr_racg);  if (m<=n) out(1:m) = reshape(tmr_racg, [m])
+    case (3);  m = size(tcr_gacr);  if (m<=n) out(1:m) = reshape(tcr_gacr, [m])
+    case (4);  m = size(tmg_gacr);  if (m<=n) out(1:m) = reshape(tmg_gacr, [m])
+    case (5);  m = size(tnr_racg);  if (m<=n) out(1:m) = reshape(tnr_racg, [m])
+    case (6);  m = size(tnr_gacr);  if (m<=n) out(1:m) = reshape(tnr_gacr, [m])
+    case (7);  m = size(tcs_racs1); if (m<=n) out(1:m) = reshape(tcs_racs1, [m])
+    case (8);  m = size(tmr_racs1); if (m<=n) out(1:m) = reshape(tmr_racs1, [m])
+    case (9);  m = size(tcs_racs2); if (m<=n) out(1:m) = reshape(tcs_racs2, [m])
+    case (10); m = size(tmr_racs2); if (m<=n) out(1:m) = reshape(tmr_racs2, [m])
+    case (11); m = size(tcr_sacr1); if (m<=n) out(1:m) = reshape(tcr_sacr1, [m])
+    case (12); m = size(tms_sacr1); if (m<=n) out(1:m) = reshape(tms_sacr1, [m])
+    case (13); m = size(tcr_sacr2); if (m<=n) out(1:m) = reshape(tcr_sacr2, [m])
+    case (14); m = size(tms_sacr2); if (m<=n) out(1:m) = reshape(tms_sacr2, [m])
+    case (15); m = size(tnr_racs1); if (m<=n) out(1:m) = reshape(tnr_racs1, [m])
+    case (16); m = size(tnr_racs2); if (m<=n) out(1:m) = reshape(tnr_racs2, [m])
+    case (17); m = size(tnr_sacr1); if (m<=n) out(1:m) = reshape(tnr_sacr1, [m])
+    case (18); m = size(tnr_sacr2); if (m<=n) out(1:m) = reshape(tnr_sacr2, [m])
+    case (19); m = size(tpi_qcfz);  if (m<=n) out(1:m) = reshape(tpi_qcfz, [m])
+    case (20); m = size(tni_qcfz);  if (m<=n) out(1:m) = reshape(tni_qcfz, [m])
+    case (21); m = size(tpi_qrfz);  if (m<=n) out(1:m) = reshape(tpi_qrfz, [m])
+    case (22); m = size(tpg_qrfz);  if (m<=n) out(1:m) = reshape(tpg_qrfz, [m])
+    case (23); m = size(tni_qrfz);  if (m<=n) out(1:m) = reshape(tni_qrfz, [m])
+    case (24); m = size(tnr_qrfz);  if (m<=n) out(1:m) = reshape(tnr_qrfz, [m])
+    case (25); m = size(tps_iaus);  if (m<=n) out(1:m) = reshape(tps_iaus, [m])
+    case (26); m = size(tni_iaus);  if (m<=n) out(1:m) = reshape(tni_iaus, [m])
+    case (27); m = size(tpi_ide);   if (m<=n) out(1:m) = reshape(tpi_ide, [m])
+    case (28); m = size(t_Efrw);    if (m<=n) out(1:m) = reshape(t_Efrw, [m])
+    case (29); m = size(t_Efsw);    if (m<=n) out(1:m) = reshape(t_Efsw, [m])
+    case (30)
+      m = 16
+      if (m<=n) out(1:16) = [t1_qr_qc, t1_qr_qi, t2_qr_qi, t1_qg_qc, t1_qs_qc, t1_qs_qi, t1_qr_ev, t2_qr_ev, t1_qs_sd, t2_qs_sd, &
+                             t1_qg_sd, t2_qg_sd, t1_qs_me, t2_qs_me, t1_qg_me, t2_qg_me]
+    case (31); m = 1000
+      if (m<=n) then
+        out(1:100)=Dc; out(101:200)=dtc; out(201:300)=Di; out(301:400)=dti; out(401:500)=Dr; out(501:600)=dtr
+        out(601:700)=Ds; out(701:800)=dts; out(801:900)=Dg; out(901:1000)=dtg
+      endif
+    end select
+    ref_thompson_table = m
+  end function
 end module icar_ref_shim
