@@ -386,6 +386,12 @@ int icar_hip_thompson(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
     return icar_thompson_run(c, dt, its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde);
 }
 
+int icar_hip_thompson_table(icar_hip_ctx *c, const char *name, double *out, size_t capacity, size_t *count)
+{
+    if (!c || !name) { icar_set_error("thompson_table: null argument"); return 1; }
+    return icar_thompson_table_download(c, name, out, capacity, count);
+}
+
 int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, int tiles[4][4])
 {
     // mp_driver.f90:609-658 (process_halo) and :728-737 (subset)

@@ -73,3 +73,4 @@ int icar_thompson_init_run(icar_hip_ctx *c, const float *params, const int *flag
 int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
                       int ids, int ide, int jds, int jde, int kds, int kde);
 void icar_thompson_free(icar_hip_ctx *c);
+int icar_thompson_table_download(icar_hip_ctx *c, const char *name, double *out, size_t cap, size_t *n_out);

@@ -112,6 +112,11 @@ int icar_hip_thompson(icar_hip_ctx *ctx, float dt,
                       int its, int ite, int jts, int jte, int kts, int kte,
                       int ids, int ide, int jds, int jde, int kds, int kde);
 
+/* Download one Thompson lookup table by its reference name (tcg_racg ... t_Efsw, Fortran order) for
+ * cross-checks against ICAR's own qr_acr_qg_mpt.dat / qr_acr_qs_mpt.dat / freezeH2O_mpt.dat caches
+ * (src/physics/mp_thompson.f90:2870-2887).  out may be NULL to query the element count. */
+int icar_hip_thompson_table(icar_hip_ctx *ctx, const char *name, double *out, size_t capacity, size_t *count);
+
 /* ---- M0: tile bookkeeping of mp()/process_halo (src/physics/mp_driver.f90:609-772) -----------
  * Fills tiles[n][4] = {its,ite,jts,jte} for halo>0 (W,E,S,N strips; corners once) or for the
  * interior shrunk by subset; returns the number of tiles (integer-exact restatement). */

@@ -342,7 +342,7 @@ typedef struct { float cloud2rain, cloud2snow; int err; } mps_consts;
  * HIP-vs-oracle(mode 1) is a bit-exact check of the device code, while oracle(0)-vs-oracle(1)
  * measures the scheme's own sensitivity to a 1-ulp change in exp (threshold flips in the
  * saturation adjustment, mp_simple.f90:217). */
-static int g_math_mode = 0;
+int g_math_mode = 0;
 void orc_set_math_mode(int m) { g_math_mode = m; }
 static inline float orc_expf(float x) { return g_math_mode ? (float)exp((double)x) : expf(x); }
 

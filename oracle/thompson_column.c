@@ -9,6 +9,14 @@
 #include "thompson_oracle.h"
 
 #define KMAX 256
+
+/* Transcendental mode (see icar_oracle.c: orc_set_math_mode).  Mode 0 = libm float functions exactly as
+ * the flang-compiled reference calls them (bit-identical to oracle/_ref).  Mode 1 = the same functions
+ * evaluated in FP64 and rounded once, which is how the HIP kernel defines them. */
+extern int g_math_mode;
+static inline float M_powf(float x, float y) { return g_math_mode ? (float)pow((double)x, (double)y) : powf(x, y); }
+static inline float M_expf(float x) { return g_math_mode ? (float)exp((double)x) : expf(x); }
+static inline float M_log10f(float x) { return g_math_mode ? (float)log10((double)x) : log10f(x); }
 #define IDX3(i,k,j) ((size_t)(i) + (size_t)nx*((size_t)(k) + (size_t)nz*(size_t)(j)))
 
 /* 10.**nn with an INTEGER exponent: flang calls __powisf2 (repeated squaring) */
@@ -24,7 +32,7 @@ static inline float powi10f(int b)
 /* decade-table index: :1562-1574 and siblings (REAL argument) */
 static inline int dec_index_f(float r, int n2)
 {
-    const int nic = (int)lroundf(log10f(r));
+    const int nic = (int)lroundf(M_log10f(r));
     int n = nic - 1;
     for (int nn = nic - 1; nn <= nic + 1; ++nn) {
         n = nn;
@@ -159,7 +167,7 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
             ri[k] = qi1d[k] * rho[k];
             ni[k] = fmaxf(R2, ni1d[k] * rho[k]);
             L_qi[k] = 1;
-            lami = powf(am_i * cig[1] * TH.oig1 * ni[k] / ri[k], TH.obmi);
+            lami = M_powf(am_i * cig[1] * TH.oig1 * ni[k] / ri[k], TH.obmi);
             ilami = 1. / lami;
             xDi = (float)((double)(bm_i + mu_i + 1.f) * ilami);
             if (xDi < 20.E-6f) {
@@ -177,7 +185,7 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
             rr[k] = qr1d[k] * rho[k];
             nr[k] = fmaxf(R2, nr1d[k] * rho[k]);
             L_qr[k] = 1;
-            lamr = powf(am_r * crg[2] * TH.org2 * nr[k] / rr[k], TH.obmr);
+            lamr = M_powf(am_r * crg[2] * TH.org2 * nr[k] / rr[k], TH.obmr);
             mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
             if (mvd_r[k] > 2.5E-3f) {
                 mvd_r[k] = 2.5E-3f;
@@ -210,7 +218,7 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
         if (fabsf(ssatw[k]) < eps) ssatw[k] = 0.0f;
         if (fabsf(ssati[k]) < eps) ssati[k] = 0.0f;
         if (no_micro && ssati[k] > 0.0f) no_micro = 0;
-        diffu[k] = 2.11E-5f * powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
+        diffu[k] = 2.11E-5f * M_powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
         if (tempc >= 0.0f) visco[k] = (1.718f + 0.0049f * tempc) * 1.0E-5f;
         else visco[k] = (1.718f + 0.0049f * tempc - 1.2E-5f * tempc * tempc) * 1.0E-5f;
         ocp[k] = 1.f / (TH_Cp2 * (1.f + 0.887f * qv[k]));
@@ -228,47 +236,47 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
         smob[k] = rs[k] * TH.oams;
         if (TH_bm_s > (2.0f - 1.e-3f) && TH_bm_s < (2.0f + 1.e-3f)) smo2[k] = smob[k];
         else {
-            loga_ = snow_poly_f(sa, tc0, TH_bm_s); a_ = powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH_bm_s);
-            smo2[k] = powf(smob[k] / a_, 1.f / b_);
+            loga_ = snow_poly_f(sa, tc0, TH_bm_s); a_ = M_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH_bm_s);
+            smo2[k] = M_powf(smob[k] / a_, 1.f / b_);
         }
         loga_ = sa[0] + sa[1] * tc0 + sa[4] * tc0 * tc0 + sa[8] * tc0 * tc0 * tc0;
-        a_ = powf(10.0f, loga_);
+        a_ = M_powf(10.0f, loga_);
         b_ = sb[0] + sb[1] * tc0 + sb[4] * tc0 * tc0 + sb[8] * tc0 * tc0 * tc0;
-        smo0[k] = a_ * powf(smo2[k], b_);
+        smo0[k] = a_ * M_powf(smo2[k], b_);
         loga_ = sa[0] + sa[1] * tc0 + sa[2] + sa[3] * tc0 + sa[4] * tc0 * tc0 + sa[5] + sa[6] * tc0 * tc0 + sa[7] * tc0
               + sa[8] * tc0 * tc0 * tc0 + sa[9];
-        a_ = powf(10.0f, loga_);
+        a_ = M_powf(10.0f, loga_);
         b_ = sb[0] + sb[1] * tc0 + sb[2] + sb[3] * tc0 + sb[4] * tc0 * tc0 + sb[5] + sb[6] * tc0 * tc0 + sb[7] * tc0
            + sb[8] * tc0 * tc0 * tc0 + sb[9];
-        smo1[k] = a_ * powf(smo2[k], b_);
-        loga_ = snow_poly_f(sa, tc0, TH.cse[0]); a_ = powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH.cse[0]);
-        smoc[k] = a_ * powf(smo2[k], b_);
-        loga_ = snow_poly_f(sa, tc0, TH.cse[12]); a_ = powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH.cse[12]);
-        smoe[k] = a_ * powf(smo2[k], b_);
-        loga_ = snow_poly_f(sa, tc0, TH.cse[15]); a_ = powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH.cse[15]);
-        smof[k] = a_ * powf(smo2[k], b_);
+        smo1[k] = a_ * M_powf(smo2[k], b_);
+        loga_ = snow_poly_f(sa, tc0, TH.cse[0]); a_ = M_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH.cse[0]);
+        smoc[k] = a_ * M_powf(smo2[k], b_);
+        loga_ = snow_poly_f(sa, tc0, TH.cse[12]); a_ = M_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH.cse[12]);
+        smoe[k] = a_ * M_powf(smo2[k], b_);
+        loga_ = snow_poly_f(sa, tc0, TH.cse[15]); a_ = M_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH.cse[15]);
+        smof[k] = a_ * M_powf(smo2[k], b_);
     }
 
     /* ---- :1456-1482 graupel intercept/slope, top-down running minimum ---- */
     N0_min = TH_gonv_max;
     for (k = kte; k >= kts; --k) {
-        if (temp[k] < 270.65f && L_qr[k] && mvd_r[k] > 100.E-6f) xslw1 = 4.01f + log10f(mvd_r[k]);
+        if (temp[k] < 270.65f && L_qr[k] && mvd_r[k] > 100.E-6f) xslw1 = 4.01f + M_log10f(mvd_r[k]);
         else xslw1 = 0.01f;
-        ygra1 = 4.31f + log10f(fmaxf(5.E-5f, rg[k]));
+        ygra1 = 4.31f + M_log10f(fmaxf(5.E-5f, rg[k]));
         zans1 = 3.1f + (100.f / (300.f * xslw1 * ygra1 / (10.f / xslw1 + 1.f + 0.25f * ygra1) + 30.f + 10.f * ygra1));
-        N0_exp = powf(10.f, zans1);
+        N0_exp = M_powf(10.f, zans1);
         N0_exp = fmax((double)TH_gonv_min, fmin(N0_exp, (double)TH_gonv_max));
         N0_min = fmin(N0_exp, N0_min);
         N0_exp = N0_min;
         lam_exp = pow(N0_exp * am_g * cgg[0] / rg[k], (double)TH.oge1);
-        lamg = lam_exp * powf(cgg[2] * TH.ogg2 * TH.ogg1, TH.obmg);
+        lamg = lam_exp * M_powf(cgg[2] * TH.ogg2 * TH.ogg1, TH.obmg);
         ilamg[k] = 1. / lamg;
         N0_g[k] = N0_exp / (cgg[1] * lam_exp) * pow(lamg, (double)cge[1]);
     }
 
     /* ---- :1489-1494 rain intercept/slope ---- */
     for (k = kte; k >= kts; --k) {
-        lamr = powf(am_r * crg[2] * TH.org2 * nr[k] / rr[k], TH.obmr);
+        lamr = M_powf(am_r * crg[2] * TH.org2 * nr[k] / rr[k], TH.obmr);
         ilamr[k] = 1. / lamr;
         mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
         N0_r[k] = (double)(nr[k] * TH.org2) * pow(lamr, (double)cre[1]);
@@ -277,17 +285,17 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
     /* ---- :1500-1544 warm rain ---- */
     for (k = kts; k <= kte; ++k) {
         if (L_qr[k] && mvd_r[k] > D0r) {
-            Ef_rr = 2.0f - expf(2300.0f * (mvd_r[k] - 1600.0E-6f));
+            Ef_rr = 2.0f - M_expf(2300.0f * (mvd_r[k] - 1600.0E-6f));
             pnr_rcr[k] = Ef_rr * 4.f * nr[k] * rr[k];
         }
         mvd_c[k] = D0c;
         if (!L_qc[k]) continue;
-        xDc = fmaxf(D0c * 1.E6f, (powf(rc[k] / (am_r * Nt_c), TH.obmr)) * 1.E6f);
-        lamc = powf(Nt_c * am_r * ccg[1] * TH.ocg1 / rc[k], TH.obmr);
+        xDc = fmaxf(D0c * 1.E6f, (M_powf(rc[k] / (am_r * Nt_c), TH.obmr)) * 1.E6f);
+        lamc = M_powf(Nt_c * am_r * ccg[1] * TH.ocg1 / rc[k], TH.obmr);
         mvd_c[k] = (float)((double)(3.0f + mu_c + 0.672f) / lamc);
         if (rc[k] > 0.01e-3f) {
-            Dc_g = (float)(((double)powf(ccg[2] * TH.ocg2, TH.obmr) / lamc) * (double)1.E6f);
-            Dc_b = powf(xDc * xDc * xDc * Dc_g * Dc_g * Dc_g - xDc * xDc * xDc * xDc * xDc * xDc, 1.f / 6.f);
+            Dc_g = (float)(((double)M_powf(ccg[2] * TH.ocg2, TH.obmr) / lamc) * (double)1.E6f);
+            Dc_b = M_powf(xDc * xDc * xDc * Dc_g * Dc_g * Dc_g - xDc * xDc * xDc * xDc * xDc * xDc, 1.f / 6.f);
             zeta1 = 0.5f * ((6.25E-6f * xDc * Dc_b * Dc_b * Dc_b - 0.4f) + fabsf(6.25E-6f * xDc * Dc_b * Dc_b * Dc_b - 0.4f));
             zeta = 0.027f * rc[k] * zeta1;
             taud = 0.5f * ((0.5f * Dc_b - 7.5f) + fabsf(0.5f * Dc_b - 7.5f)) + R1;
@@ -366,7 +374,7 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
                 vtg = (float)((double)(rhof[k] * av_g * cgg[5] * TH.ogg3) * pow(ilamg[k], (double)bv_g));
                 stoke_g = mvd_c[k] * mvd_c[k] * vtg * rho_w / (9.f * visco[k] * xDg);
                 if (xDg > D0g) {
-                    if (stoke_g >= 0.4f && stoke_g <= 10.f) Ef_gw = 0.55f * log10f(2.51f * stoke_g);
+                    if (stoke_g >= 0.4f && stoke_g <= 10.f) Ef_gw = 0.55f * M_log10f(2.51f * stoke_g);
                     else if (stoke_g < 0.4f) Ef_gw = 0.0f;
                     else if (stoke_g > 10.f) Ef_gw = 0.77f;
                     prg_gcw[k] = (double)(rhof[k] * TH.t1_qg_qc * Ef_gw * rc[k]) * N0_g[k] * pow(ilamg[k], (double)cge[8]);
@@ -432,14 +440,14 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
                 pni_wfz[k] = fmin(fmin((double)(Nt_c * odts), pri_wfz[k] / (double)(2.f * xm0i)), pni_wfz[k]);
             }
             if ((ssati[k] >= 0.25f) || (ssatw[k] > eps && temp[k] < 261.15f)) {
-                xnc = fminf(250.E3f, TH.TNO * expf(TH_ATO * (T_0 - temp[k])));
+                xnc = fminf(250.E3f, TH.TNO * M_expf(TH_ATO * (T_0 - temp[k])));
                 xni = (float)((double)ni[k] + (pni_rfz[k] + pni_wfz[k]) * (double)dtsave);
                 pni_inu[k] = 0.5f * (xnc - xni + fabsf(xnc - xni)) * odts;
                 pri_inu[k] = fmin((double)rate_max, (double)xm0i * pni_inu[k]);
                 pni_inu[k] = pri_inu[k] / (double)xm0i;
             }
             if (L_qi[k]) {
-                lami = powf(am_i * cig[1] * TH.oig1 * ni[k] / ri[k], TH.obmi);
+                lami = M_powf(am_i * cig[1] * TH.oig1 * ni[k] / ri[k], TH.obmi);
                 ilami = 1. / lami;
                 xDi = (float)fmax((double)TH.D0i, (double)(bm_i + mu_i + 1.f) * ilami);
                 xmi = am_i * (xDi * xDi * xDi);
@@ -482,7 +490,7 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
                 else prg_gde[k] = fmin(prg_gde[k], (double)rate_max);
             }
             if (L_qi[k]) {
-                lami = powf(am_i * cig[1] * TH.oig1 * ni[k] / ri[k], TH.obmi);
+                lami = M_powf(am_i * cig[1] * TH.oig1 * ni[k] / ri[k], TH.obmi);
                 ilami = 1. / lami;
                 xDi = (float)fmax((double)TH.D0i, (double)(bm_i + mu_i + 1.f) * ilami);
                 xmi = am_i * (xDi * xDi * xDi);
@@ -523,7 +531,7 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
                              * (TH.t1_qs_me * smo1[k] + TH.t2_qs_me * rhof2[k] * vsc2[k] * smof[k]);
                 prr_sml[k] = prr_sml[k] + (double)(4218.f * olfus * tempc) * (prr_rcs[k] + prs_scw[k]);
                 prr_sml[k] = fmin((double)(rs[k] * odts), fmax(0., prr_sml[k]));
-                pnr_sml[k] = (double)(smo0[k] / rs[k]) * prr_sml[k] * (double)powf(10.0f, -0.75f * tempc);
+                pnr_sml[k] = (double)(smo0[k] / rs[k]) * prr_sml[k] * (double)M_powf(10.0f, -0.75f * tempc);
                 pnr_sml[k] = fmin((double)(smo0[k] * odts), pnr_sml[k]);
                 if (tempc > 3.5f || rs[k] < 0.005E-3f) pnr_sml[k] = 0.0;
                 if (ssati[k] < 0.f) {
@@ -538,7 +546,7 @@ void th_column(float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, 
                                 + (double)(TH.t2_qg_me * rhof2[k] * vsc2[k]) * pow(ilamg[k], (double)cge[10]));
                 prr_gml[k] = fmin((double)(rg[k] * odts), fmax(0., prr_gml[k]));
                 pnr_gml[k] = N0_g[k] * (double)cgg[1] * pow(ilamg[k], (double)cge[1]) / (double)rg[k]
-                             * prr_gml[k] * (double)powf(10.0f, -1.5f * tempc);
+                             * prr_gml[k] * (double)M_powf(10.0f, -1.5f * tempc);
                 if (tempc > 7.5f || rg[k] < 0.005E-3f) pnr_gml[k] = 0.0;
                 if (ssati[k] < 0.f) {
                     prg_gde[k] = (double)(C_cube * t1_subl * diffu[k] * ssati[k] * rvs) * N0_g[k]

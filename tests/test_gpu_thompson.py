@@ -1,0 +1,131 @@
+"""HIP Thompson microphysics (rows M2-M4) vs the CPU oracle through the C ABI.
+
+* lookup tables: every table of thompson_init is BIT-IDENTICAL to the oracle's (which is
+  bit-identical to the compiled reference, tests/test_oracle_vs_ref.py): the O(1e10)-term FP64
+  collection integrals run on the GPU in the reference's summation order without FMA contraction.
+* column physics: compared with the oracle in math-mode 1 (float pow/exp/log10 evaluated in FP64 and
+  rounded once -- the device's definition; the remaining difference is the last bit of FP64
+  pow/exp/log between ocml and glibc, ~1e-16 relative) and in mode 0 (the reference's libm).
+  Tolerance: rtol 1e-5 relative to each field's column-scale (north-star tolerance); table indices
+  and category switches are integer-exact, so differences stay at rounding level."""
+import ctypes
+import numpy as np
+import pytest
+from icar_amd import ideal
+from icar_amd.capi import lib, check
+from icar_amd.options import options_t
+from icar_amd.microphysics import mp, mp_init
+from icar_amd.constants import kMP_THOMPSON
+from util import single_image_domain
+
+pytestmark = pytest.mark.gpu
+TABLES = ["tcg_racg", "tmr_racg", "tcr_gacr", "tmg_gacr", "tnr_racg", "tnr_gacr", "tcs_racs1", "tmr_racs1", "tcs_racs2",
+          "tmr_racs2", "tcr_sacr1", "tms_sacr1", "tcr_sacr2", "tms_sacr2", "tnr_racs1", "tnr_racs2", "tnr_sacr1", "tnr_sacr2",
+          "tpi_qcfz", "tni_qcfz", "tpi_qrfz", "tpg_qrfz", "tni_qrfz", "tnr_qrfz", "tps_iaus", "tni_iaus", "tpi_ide", "t_Efrw", "t_Efsw"]
+FIELDS = {"water_vapor": "water_vapor", "cloud_water": "cloud_water_mass", "rain": "rain_mass", "cloud_ice": "cloud_ice_mass",
+          "snow": "snow_mass", "graupel": "graupel_mass", "ice_number": "cloud_ice_number", "rain_number": "rain_number",
+          "potential_temperature": "potential_temperature"}
+
+
+@pytest.fixture(scope="module")
+def th_oracle(oracle):
+    opt = options_t()
+    p, f = opt.mp_options.as_arrays()
+    oracle.thompson_init(p, f)
+    return oracle
+
+
+def device_table(d, name):
+    n = ctypes.c_size_t()
+    check(lib().icar_hip_thompson_table(d.ctx, name.encode(), None, ctypes.c_size_t(0), ctypes.byref(n)), "table size")
+    out = np.empty(n.value, np.float64)
+    check(lib().icar_hip_thompson_table(d.ctx, name.encode(), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(out.size), None), "table")
+    return out
+
+
+def test_lookup_tables_bit_identical(th_oracle):
+    c = ideal.make_case(8, 8, 4)
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    mp_init(opt, d)
+    for name in TABLES:
+        a = device_table(d, name); b = th_oracle.thompson_table(name)
+        assert a.shape == b.shape, name
+        nb = int((a.view(np.int64) != b.view(np.int64)).sum())
+        assert nb == 0, f"{name}: {nb} of {a.size} entries differ, max rel {np.abs(a-b).max()/max(np.abs(b).max(),1e-300):.2e}"
+    d.close()
+
+
+def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode):
+    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(moist)).astype(np.float32)
+    s = {k: c[k].copy() for k in list(FIELDS) + ["exner", "pressure", "dz_mass"]}
+    acc = {k: np.zeros((ny, nx), np.float64) for k in ("rain", "snow", "graupel")}
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    mp_init(opt, d)
+    oracle.set_math_mode(mode)
+    try:
+        for _ in range(steps):
+            r = np.zeros((ny, nx), np.float32); rv = r.copy(); sn = r.copy(); gr = r.copy(); sr = r.copy()
+            oracle.thompson(s["water_vapor"], s["cloud_water"], s["rain"], s["cloud_ice"], s["snow"], s["graupel"], s["ice_number"],
+                            s["rain_number"], s["potential_temperature"], s["exner"], s["pressure"], s["dz_mass"], dt, r, rv, sn, gr, sr,
+                            1, nx, 1, ny, 1, nz, 2, nx - 1, 2, ny - 1, 1, nz)
+            acc["rain"] += r; acc["snow"] += sn; acc["graupel"] += gr
+            s["potential_temperature"] -= np.float32(cool)
+            mp(d, opt, dt)
+            d.model_time_seconds += dt
+            d.set("potential_temperature", d.get("potential_temperature") - np.float32(cool))
+    finally:
+        oracle.set_math_mode(0)
+    out = {k: d.get(m) for k, m in FIELDS.items()}
+    out["acc_rain"] = d.get("accumulated_precipitation"); out["acc_snow"] = d.get("accumulated_snowfall"); out["acc_graupel"] = d.get("graupel")
+    d.close()
+    ref = dict(s); ref["acc_rain"] = acc["rain"]; ref["acc_snow"] = acc["snow"]; ref["acc_graupel"] = acc["graupel"]
+    return out, ref
+
+
+def check_close(out, ref, rtol, frac_allowed, label):
+    report = []
+    for k in list(FIELDS) + ["acc_rain", "acc_snow", "acc_graupel"]:
+        a = out[k].astype(np.float64); b = ref[k].astype(np.float64)
+        scale = max(np.abs(b).max(), 1e-300)
+        bad = np.abs(a - b) > rtol * np.maximum(np.abs(b), 1e-3 * scale)
+        nb = int((out[k] != ref[k].astype(out[k].dtype)).sum())
+        report.append(f"{k}: bitdiff {nb}/{a.size}, beyond-rtol {bad.mean():.2e}, max|d|/max {np.abs(a-b).max()/scale:.2e}")
+        assert bad.mean() <= frac_allowed, f"[{label}] " + report[-1]
+    print(f"[{label}]\n  " + "\n  ".join(report))
+
+
+CASES = {"warm_mixed": dict(nx=70, ny=20, nz=30, steps=10, cool=1.0, moist=1.6, dt=40.0),
+         "cold_graupel": dict(nx=66, ny=18, nz=40, steps=20, cool=2.0, moist=2.0, dt=60.0),
+         "long_dt": dict(nx=40, ny=12, nz=40, steps=12, cool=3.0, moist=2.5, dt=130.0)}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_thompson_vs_oracle_device_math(th_oracle, case):
+    out, ref = run_case(th_oracle, mode=1, **CASES[case])
+    if case == "cold_graupel":
+        assert ref["snow"].max() > 1e-4 and ref["graupel"].max() > 1e-5 and ref["cloud_ice"].max() > 1e-6
+    assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
+    check_close(out, ref, rtol=1e-5, frac_allowed=1e-4, label=case + "/mode1")
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_thompson_vs_oracle_reference_math(th_oracle, case):
+    out, ref = run_case(th_oracle, mode=0, **CASES[case])
+    check_close(out, ref, rtol=1e-5, frac_allowed=2e-2, label=case + "/mode0")
+
+
+def test_thompson_excludes_last_global_row_and_column(th_oracle):
+    """i_end = min(ite, ide-1), j_end = min(jte, jde-1)."""
+    nx, ny, nz = 20, 12, 20
+    c = ideal.make_case(nx, ny, nz, hill_height=500.0)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(2.0)).astype(np.float32)
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    mp_init(opt, d)
+    g = d.grid
+    check(lib().icar_hip_thompson(d.ctx, ctypes.c_float(30.0), 1, nx, 1, ny, 1, nz, g.ids, g.ide, g.jds, g.jde, g.kds, g.kde), "thompson")
+    qc = d.get("cloud_water_mass"); d.close()
+    assert qc[:-1, :, :-1].max() > 0 and qc[-1].max() == 0 and qc[:, :, -1].max() == 0
