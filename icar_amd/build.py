@@ -47,5 +47,28 @@ def build(force=False, verbose=False):
     return LIB
 
 
+FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
+FDIR = os.path.join(HERE, "fortran")
+DEMO = os.path.join(LIBDIR, "icar_hip_demo")
+
+
+def build_fortran_host(force=False, verbose=False):
+    """Fortran 2008 host side (iso_c_binding module + demo driver); needs flang (present in the image)."""
+    if not os.path.exists(FLANG):
+        return None
+    mod = os.path.join(FDIR, "icar_hip_mod.f90"); demo = os.path.join(FDIR, "icar_hip_demo.f90")
+    if not (force or _stale(DEMO, [mod, demo, LIB])):
+        return DEMO
+    obj = os.path.join(LIBDIR, "icar_hip_mod.o")
+    cmds = [[FLANG, "-O2", "-c", mod, "-o", obj, "-module-dir", LIBDIR],
+            [FLANG, "-O2", "-I" + LIBDIR, demo, obj, "-L" + LIBDIR, "-licar_hip", "-Wl,-rpath,$ORIGIN", "-o", DEMO]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return DEMO
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_fortran_host(force="--force" in sys.argv, verbose=True))

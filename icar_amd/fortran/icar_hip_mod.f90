@@ -1,0 +1,199 @@
+!> icar_hip_mod.f90 -- Fortran 2008 host side of libicar_hip.so (include/icar_hip.h).
+!!
+!! `use icar_hip` gives (a) the raw iso_c_binding interfaces of every C-ABI entry point and
+!! (b) thin wrappers with the reference's operator names and argument meaning:
+!!     call hip_advect(ctx, options%physics%advection, mpdata_order, fct, advect_density, dt, dx, vars)
+!!     call hip_mp_simple(ctx, dt, its,ite, jts,jte, kts,kte)
+!!     call hip_thompson_init(ctx, mp_options...) ; call hip_thompson(ctx, dt, its..kte, ids..kde)
+!! A non-zero return code becomes `error stop` with the library's message -- the reference's own
+!! error convention (stop / error stop; SURVEY 8b).  INTEGRATION.md shows where ICAR calls these.
+module icar_hip
+  use iso_c_binding
+  implicit none
+  private
+  public :: hip_ctx_t, hip_create, hip_destroy, hip_upload, hip_download, hip_upload_2dd, hip_download_2dd, &
+            hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync
+  public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
+            ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
+            ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
+            ICAR_F_JACOBIAN_V, ICAR_F_JACOBIAN_W, ICAR_F_ADVECTION_DZ, ICAR_F_PRECIPITATION, ICAR_F_SNOWFALL, ICAR_F_GRAUPEL_ACC
+
+  ! enum icar_hip_field (include/icar_hip.h)
+  integer(c_int), parameter :: ICAR_F_WATER_VAPOR=0, ICAR_F_CLOUD_WATER=1, ICAR_F_RAIN=2, ICAR_F_SNOW=3, &
+       ICAR_F_POTENTIAL_TEMPERATURE=4, ICAR_F_CLOUD_ICE=5, ICAR_F_GRAUPEL=6, ICAR_F_ICE_NUMBER=7, ICAR_F_RAIN_NUMBER=8, &
+       ICAR_F_U=11, ICAR_F_V=12, ICAR_F_W=13, ICAR_F_PRESSURE=14, ICAR_F_EXNER=15, ICAR_F_DENSITY=16, ICAR_F_DZ_MASS=17, &
+       ICAR_F_JACOBIAN=18, ICAR_F_JACOBIAN_U=19, ICAR_F_JACOBIAN_V=20, ICAR_F_JACOBIAN_W=21, ICAR_F_ADVECTION_DZ=22, &
+       ICAR_F_PRECIPITATION=23, ICAR_F_SNOWFALL=24, ICAR_F_GRAUPEL_ACC=25
+
+  type :: hip_ctx_t
+     type(c_ptr) :: p = c_null_ptr
+  end type
+
+  interface
+     integer(c_int) function icar_hip_ctx_create(ctx, device, ims, ime, kms, kme, jms, jme) bind(C, name="icar_hip_ctx_create")
+       import; type(c_ptr), intent(out) :: ctx; integer(c_int), value :: device, ims, ime, kms, kme, jms, jme
+     end function
+     integer(c_int) function icar_hip_ctx_destroy(ctx) bind(C, name="icar_hip_ctx_destroy")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_synchronize(ctx) bind(C, name="icar_hip_synchronize")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_field_upload(ctx, field, host) bind(C, name="icar_hip_field_upload")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: field; type(c_ptr), value :: host
+     end function
+     integer(c_int) function icar_hip_field_download(ctx, field, host) bind(C, name="icar_hip_field_download")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: field; type(c_ptr), value :: host
+     end function
+     integer(c_int) function icar_hip_setup_winds(ctx, scheme, dt, dx, advect_density) bind(C, name="icar_hip_setup_winds")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: scheme, advect_density; real(c_float), value :: dt, dx
+     end function
+     integer(c_int) function icar_hip_advect(ctx, scheme, mpdata_order, fct, advect_density, fields, nfields) bind(C, name="icar_hip_advect")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: scheme, mpdata_order, fct, advect_density, nfields
+       integer(c_int), intent(in) :: fields(*)
+     end function
+     integer(c_int) function icar_hip_mp_simple(ctx, dt, its, ite, jts, jte, kts, kte, err_count) bind(C, name="icar_hip_mp_simple")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dt; integer(c_int), value :: its, ite, jts, jte, kts, kte
+       type(c_ptr), value :: err_count
+     end function
+     integer(c_int) function icar_hip_thompson_init(ctx, params, flags) bind(C, name="icar_hip_thompson_init")
+       import; type(c_ptr), value :: ctx; real(c_float), intent(in) :: params(18); integer(c_int), intent(in) :: flags(2)
+     end function
+     integer(c_int) function icar_hip_thompson(ctx, dt, its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde) bind(C, name="icar_hip_thompson")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dt
+       integer(c_int), value :: its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde
+     end function
+     integer(c_int) function icar_hip_max_courant(ctx, dx, dz_levels, res) bind(C, name="icar_hip_max_courant")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dx; real(c_float), intent(in) :: dz_levels(*); real(c_float), intent(out) :: res
+     end function
+     integer(c_int) function icar_hip_balance_uvw(ctx, dx) bind(C, name="icar_hip_balance_uvw")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dx
+     end function
+     type(c_ptr) function icar_hip_last_error() bind(C, name="icar_hip_last_error")
+       import
+     end function
+  end interface
+
+contains
+
+  subroutine check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: what
+    character(kind=c_char), pointer :: msg(:)
+    integer :: n
+    if (rc == 0) return
+    call c_f_pointer(icar_hip_last_error(), msg, [512])
+    n = 0
+    do while (n < 512)
+       if (msg(n+1) == c_null_char) exit
+       n = n + 1
+    end do
+    write(*,*) "icar_hip: ", what, ": ", msg(1:n)
+    error stop "icar_hip call failed"
+  end subroutine
+
+  !> one context per image; ims..jme are the tile's memory bounds (domain%grid%ims ...)
+  subroutine hip_create(ctx, device, ims, ime, kms, kme, jms, jme)
+    type(hip_ctx_t), intent(out) :: ctx
+    integer, intent(in) :: device, ims, ime, kms, kme, jms, jme
+    call check(icar_hip_ctx_create(ctx%p, int(device,c_int), int(ims,c_int), int(ime,c_int), int(kms,c_int), &
+                                   int(kme,c_int), int(jms,c_int), int(jme,c_int)), "ctx_create")
+  end subroutine
+
+  subroutine hip_destroy(ctx)
+    type(hip_ctx_t), intent(inout) :: ctx
+    call check(icar_hip_ctx_destroy(ctx%p), "ctx_destroy"); ctx%p = c_null_ptr
+  end subroutine
+
+  subroutine hip_sync(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_synchronize(ctx%p), "synchronize")
+  end subroutine
+
+  !> domain%X%data_3d -> device.  The reference allocates these whole-array, i.e. contiguous; the
+  !! pointers are not declared CONTIGUOUS (exchangeable_h.f90:14), so assert it before c_loc.
+  subroutine hip_upload(ctx, field, a)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: field
+    real(c_float), intent(in), target, contiguous :: a(:,:,:)
+    call check(icar_hip_field_upload(ctx%p, field, c_loc(a)), "field_upload")
+  end subroutine
+
+  subroutine hip_download(ctx, field, a)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: field
+    real(c_float), intent(inout), target, contiguous :: a(:,:,:)
+    call check(icar_hip_field_download(ctx%p, field, c_loc(a)), "field_download")
+  end subroutine
+
+  subroutine hip_upload_2dd(ctx, field, a)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: field
+    real(c_double), intent(in), target, contiguous :: a(:,:)
+    call check(icar_hip_field_upload(ctx%p, field, c_loc(a)), "field_upload")
+  end subroutine
+
+  subroutine hip_download_2dd(ctx, field, a)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: field
+    real(c_double), intent(inout), target, contiguous :: a(:,:)
+    call check(icar_hip_field_download(ctx%p, field, c_loc(a)), "field_download")
+  end subroutine
+
+  !> advect(domain, options, dt) of advection_driver.f90:51 : scheme = options%physics%advection,
+  !! vars = field ids with options%vars_to_advect(...)>0 in the order of adv_mpdata.f90:512-522.
+  subroutine hip_advect(ctx, scheme, mpdata_order, fct, advect_density, dt, dx, vars)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: scheme, mpdata_order
+    logical, intent(in) :: fct, advect_density
+    real, intent(in) :: dt, dx
+    integer(c_int), intent(in) :: vars(:)
+    call check(icar_hip_setup_winds(ctx%p, int(scheme,c_int), real(dt,c_float), real(dx,c_float), &
+                                    merge(1_c_int,0_c_int,advect_density)), "setup_winds")
+    call check(icar_hip_advect(ctx%p, int(scheme,c_int), int(mpdata_order,c_int), merge(1_c_int,0_c_int,fct), &
+                               merge(1_c_int,0_c_int,advect_density), vars, int(size(vars),c_int)), "advect")
+  end subroutine
+
+  !> mp_simple_driver (mp_simple.f90:595) on a tile, incl. the precipitation accumulation of process_subdomain
+  subroutine hip_mp_simple(ctx, dt, its, ite, jts, jte, kts, kte)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dt
+    integer, intent(in) :: its, ite, jts, jte, kts, kte
+    call check(icar_hip_mp_simple(ctx%p, real(dt,c_float), int(its,c_int), int(ite,c_int), int(jts,c_int), int(jte,c_int), &
+                                  int(kts,c_int), int(kte,c_int), c_null_ptr), "mp_simple")
+  end subroutine
+
+  subroutine hip_thompson_init(ctx, params, Ef_rw_l, Ef_sw_l)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_float), intent(in) :: params(18)      ! mp_options_type in declaration order (opt_types.f90:30-41)
+    logical, intent(in) :: Ef_rw_l, Ef_sw_l
+    integer(c_int) :: flags(2)
+    flags = [merge(1_c_int,0_c_int,Ef_rw_l), merge(1_c_int,0_c_int,Ef_sw_l)]
+    call check(icar_hip_thompson_init(ctx%p, params, flags), "thompson_init")
+  end subroutine
+
+  subroutine hip_thompson(ctx, dt, its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dt
+    integer, intent(in) :: its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde
+    call check(icar_hip_thompson(ctx%p, real(dt,c_float), int(its,c_int), int(ite,c_int), int(jts,c_int), int(jte,c_int), &
+               int(kts,c_int), int(kte,c_int), int(ids,c_int), int(ide,c_int), int(jds,c_int), int(jde,c_int), &
+               int(kds,c_int), int(kde,c_int)), "thompson")
+  end subroutine
+
+  !> the reduction inside compute_dt (time_step.f90:264-289); dt = CFL / result
+  real function hip_max_courant(ctx, dx, dz_levels)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dx
+    real(c_float), intent(in) :: dz_levels(:)
+    real(c_float) :: r
+    call check(icar_hip_max_courant(ctx%p, real(dx,c_float), dz_levels, r), "max_courant")
+    hip_max_courant = r
+  end function
+
+  subroutine hip_balance_uvw(ctx, dx)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dx
+    call check(icar_hip_balance_uvw(ctx%p, real(dx,c_float)), "balance_uvw")
+  end subroutine
+end module icar_hip
