@@ -7,8 +7,11 @@
 // the reference; table indices are integer-exact.  Float transcendentals are evaluated in FP64 and
 // rounded once (within 1 ulp of the host libm the reference uses; see tests/test_gpu_thompson.py).
 //
-// This first version keeps the reference's per-level work arrays as private (scratch) arrays, which
-// are lane-interleaved and therefore coalesced; DESIGN.md lists the planned register/LDS staging.
+// The reference keeps ~130 per-level work arrays.  Here the per-level phases are fused (saturation /
+// snow moments / rain slopes / warm rain / frozen processes / conservation / tendencies in one level
+// loop; TAU+1 update / condensation / rain evaporation in a second) so that all process rates are
+// registers; only the state that crosses levels (graupel N0 chain, fall-speed carry-down,
+// sedimentation) stays in lane-interleaved private arrays.
 #include "ctx.h"
 #include "thompson_state.h"
 #include <cmath>
@@ -112,24 +115,15 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
     const int kts = 0, kte = nz - 1;
 
     float tten[KMAX], qvten[KMAX], qcten[KMAX], qiten[KMAX], qrten[KMAX], qsten[KMAX], qgten[KMAX], niten[KMAX], nrten[KMAX];
-    double prw_vcd[KMAX];
-    double prr_wau[KMAX], prr_rcw[KMAX], prr_rcs[KMAX], prr_rcg[KMAX], prr_sml[KMAX], prr_gml[KMAX], prr_rci[KMAX], prv_rev[KMAX],
-        pnr_wau[KMAX], pnr_rcs[KMAX], pnr_rcg[KMAX], pnr_rci[KMAX], pnr_sml[KMAX], pnr_gml[KMAX], pnr_rev[KMAX], pnr_rcr[KMAX], pnr_rfz[KMAX];
-    double pri_inu[KMAX], pni_inu[KMAX], pri_ihm[KMAX], pni_ihm[KMAX], pri_wfz[KMAX], pni_wfz[KMAX], pri_rfz[KMAX], pni_rfz[KMAX],
-        pri_ide[KMAX], pni_ide[KMAX], pri_rci[KMAX], pni_rci[KMAX], pni_sci[KMAX], pni_iau[KMAX];
-    double prs_iau[KMAX], prs_sci[KMAX], prs_rcs[KMAX], prs_scw[KMAX], prs_sde[KMAX], prs_ihm[KMAX], prs_ide[KMAX];
-    double prg_scw[KMAX], prg_rfz[KMAX], prg_gde[KMAX], prg_gcw[KMAX], prg_rci[KMAX], prg_rcs[KMAX], prg_rcg[KMAX], prg_ihm[KMAX];
-    float temp[KMAX], pres[KMAX], qv[KMAX], rc[KMAX], ri[KMAX], rr[KMAX], rs[KMAX], rg[KMAX], ni[KMAX], nr[KMAX];
-    float rho[KMAX], rhof[KMAX], rhof2[KMAX], qvs[KMAX], qvsi[KMAX], delQvs[KMAX], satw[KMAX], sati[KMAX], ssatw[KMAX], ssati[KMAX];
-    float diffu[KMAX], visco[KMAX], vsc2[KMAX], tcond[KMAX], lvap[KMAX], ocp[KMAX], lvt2[KMAX];
-    double ilamr[KMAX], ilamg[KMAX], N0_r[KMAX], N0_g[KMAX];
-    float mvd_r[KMAX], mvd_c[KMAX];
-    float smob[KMAX], smo2[KMAX], smo1[KMAX], smo0[KMAX], smoc[KMAX], smod[KMAX], smoe[KMAX], smof[KMAX];
-    float sed_r[KMAX], sed_s[KMAX], sed_g[KMAX], sed_i[KMAX], sed_n[KMAX];
+    float temp[KMAX], qv[KMAX], rc[KMAX], ri[KMAX], rr[KMAX], rs[KMAX], rg[KMAX], ni[KMAX], nr[KMAX];
+    float rho[KMAX], rhof[KMAX], lvap[KMAX], ocp[KMAX];
+    double ilamg[KMAX], N0_g[KMAX];
+    float mvd_r[KMAX], smob[KMAX], smoc[KMAX], xslw_arr[KMAX];
+    float sed_r[KMAX], sed_n[KMAX];
     float vtik[KMAX + 1], vtnik[KMAX + 1], vtrk[KMAX + 1], vtnrk[KMAX + 1], vtsk[KMAX + 1], vtgk[KMAX + 1];
     float vts_boost[KMAX];
     int L_qc[KMAX], L_qi[KMAX], L_qr[KMAX], L_qs[KMAX], L_qg[KMAX];
-    (void)smod; (void)satw; (void)sati;
+    const float *pres = p1d;
 
     float rgvm, delta_tp, orho, lfus2, onstep[4];
     double N0_exp, N0_min, lam_exp, lamc, lamr, lamg, lami, ilami;
@@ -144,22 +138,11 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
 
     dtsave = dt; odt = 1.f / dt; odts = 1.f / dtsave;
 
-#define Z(a) for (int zz = 0; zz < nz; ++zz) a[zz] = 0
-    Z(tten); Z(qvten); Z(qcten); Z(qiten); Z(qrten); Z(qsten); Z(qgten); Z(niten); Z(nrten); Z(prw_vcd);
-    Z(prv_rev); Z(prr_wau); Z(prr_rcw); Z(prr_rcs); Z(prr_rcg); Z(prr_sml); Z(prr_gml); Z(prr_rci); Z(pnr_wau); Z(pnr_rcs);
-    Z(pnr_rcg); Z(pnr_rci); Z(pnr_sml); Z(pnr_gml); Z(pnr_rev); Z(pnr_rcr); Z(pnr_rfz);
-    Z(pri_inu); Z(pni_inu); Z(pri_ihm); Z(pni_ihm); Z(pri_wfz); Z(pni_wfz); Z(pri_rfz); Z(pni_rfz); Z(pri_ide); Z(pni_ide);
-    Z(pri_rci); Z(pni_rci); Z(pni_sci); Z(pni_iau);
-    Z(prs_iau); Z(prs_sci); Z(prs_rcs); Z(prs_scw); Z(prs_sde); Z(prs_ihm); Z(prs_ide);
-    Z(prg_scw); Z(prg_rfz); Z(prg_gde); Z(prg_gcw); Z(prg_rci); Z(prg_rcs); Z(prg_rcg); Z(prg_ihm);
-    Z(smob); Z(smo2); Z(smo1); Z(smo0); Z(smoc); Z(smoe); Z(smof);   /* never read uninitialised below; zero for determinism */
-#undef Z
-
+    for (k = 0; k < nz; ++k) { tten[k] = 0; qvten[k] = 0; qcten[k] = 0; qiten[k] = 0; qrten[k] = 0; qsten[k] = 0; qgten[k] = 0; niten[k] = 0; nrten[k] = 0; }
     /* ---- :1240-1319 column -> local arrays ---- */
     for (k = kts; k <= kte; ++k) {
         temp[k] = t1d[k];
         qv[k] = fmaxf(1.E-10f, qv1d[k]);
-        pres[k] = p1d[k];
         rho[k] = 0.622f * pres[k] / (TH_RR2 * temp[k] * (qv[k] + 0.622f));
         if (qc1d[k] > R1) { no_micro = 0; rc[k] = qc1d[k] * rho[k]; L_qc[k] = 1; }
         else { qc1d[k] = 0.0f; rc[k] = R1; L_qc[k] = 0; }
@@ -203,61 +186,18 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         if (qg1d[k] > R1) { no_micro = 0; rg[k] = qg1d[k] * rho[k]; L_qg[k] = 1; }
         else { qg1d[k] = 0.0f; rg[k] = R1; L_qg[k] = 0; }
     }
-
-    /* ---- :1328-1356 thermodynamics ---- */
-    for (k = kts; k <= kte; ++k) {
-        tempc = temp[k] - 273.15f;
-        rhof[k] = sqrtf(TH_rho_not / rho[k]);
-        rhof2[k] = sqrtf(rhof[k]);
-        qvs[k] = rslf(pres[k], temp[k]);
-        delQvs[k] = fmaxf(0.0f, rslf(pres[k], 273.15f) - qv[k]);
-        if (tempc <= 0.0f) qvsi[k] = rsif(pres[k], temp[k]); else qvsi[k] = qvs[k];
-        satw[k] = qv[k] / qvs[k];
-        sati[k] = qv[k] / qvsi[k];
-        ssatw[k] = satw[k] - 1.f;
-        ssati[k] = sati[k] - 1.f;
-        if (fabsf(ssatw[k]) < eps) ssatw[k] = 0.0f;
-        if (fabsf(ssati[k]) < eps) ssati[k] = 0.0f;
-        if (no_micro && ssati[k] > 0.0f) no_micro = 0;
-        diffu[k] = 2.11E-5f * d_powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
-        if (tempc >= 0.0f) visco[k] = (1.718f + 0.0049f * tempc) * 1.0E-5f;
-        else visco[k] = (1.718f + 0.0049f * tempc - 1.2E-5f * tempc * tempc) * 1.0E-5f;
-        ocp[k] = 1.f / (TH_Cp2 * (1.f + 0.887f * qv[k]));
-        vsc2[k] = sqrtf(rho[k] / visco[k]);
-        lvap[k] = lvap0 + (2106.0f - 4218.0f) * tempc;
-        tcond[k] = (5.69f + 0.0168f * tempc) * 1.0E-5f * 418.936f;
-    }
-
-    if (no_micro) return;     /* :1363 */
-
-    /* ---- :1369-1451 snow moments ---- */
-    for (k = kts; k <= kte; ++k) {
-        if (!L_qs[k]) continue;
-        tc0 = fminf(-0.1f, temp[k] - 273.15f);
-        smob[k] = rs[k] * T->oams;
-        if (TH_bm_s > (2.0f - 1.e-3f) && TH_bm_s < (2.0f + 1.e-3f)) smo2[k] = smob[k];
-        else {
-            loga_ = snow_poly_f(sa, tc0, TH_bm_s); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH_bm_s);
-            smo2[k] = d_powf(smob[k] / a_, 1.f / b_);
+    /* ---- no_micro can only be decided after the saturation pass of :1328-1356 ---- */
+    if (no_micro) {
+        for (k = kts; k <= kte; ++k) {
+            const float tc_ = temp[k] - 273.15f;
+            const float qvs_ = rslf(pres[k], temp[k]);
+            const float qvsi_ = (tc_ <= 0.0f) ? rsif(pres[k], temp[k]) : qvs_;
+            float ssati_ = qv[k] / qvsi_ - 1.f;
+            if (fabsf(ssati_) < eps) ssati_ = 0.0f;
+            if (ssati_ > 0.0f) no_micro = 0;
         }
-        loga_ = sa[0] + sa[1] * tc0 + sa[4] * tc0 * tc0 + sa[8] * tc0 * tc0 * tc0;
-        a_ = d_powf(10.0f, loga_);
-        b_ = sb[0] + sb[1] * tc0 + sb[4] * tc0 * tc0 + sb[8] * tc0 * tc0 * tc0;
-        smo0[k] = a_ * d_powf(smo2[k], b_);
-        loga_ = sa[0] + sa[1] * tc0 + sa[2] + sa[3] * tc0 + sa[4] * tc0 * tc0 + sa[5] + sa[6] * tc0 * tc0 + sa[7] * tc0
-              + sa[8] * tc0 * tc0 * tc0 + sa[9];
-        a_ = d_powf(10.0f, loga_);
-        b_ = sb[0] + sb[1] * tc0 + sb[2] + sb[3] * tc0 + sb[4] * tc0 * tc0 + sb[5] + sb[6] * tc0 * tc0 + sb[7] * tc0
-           + sb[8] * tc0 * tc0 * tc0 + sb[9];
-        smo1[k] = a_ * d_powf(smo2[k], b_);
-        loga_ = snow_poly_f(sa, tc0, T->cse[0]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[0]);
-        smoc[k] = a_ * d_powf(smo2[k], b_);
-        loga_ = snow_poly_f(sa, tc0, T->cse[12]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[12]);
-        smoe[k] = a_ * d_powf(smo2[k], b_);
-        loga_ = snow_poly_f(sa, tc0, T->cse[15]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[15]);
-        smof[k] = a_ * d_powf(smo2[k], b_);
+        if (no_micro) return;     /* :1363 */
     }
-
     /* ---- :1456-1482 graupel intercept/slope, top-down running minimum ---- */
     N0_min = TH_gonv_max;
     for (k = kte; k >= kts; --k) {
@@ -274,26 +214,69 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         ilamg[k] = 1. / lamg;
         N0_g[k] = N0_exp / (cgg[1] * lam_exp) * pow(lamg, (double)cge[1]);
     }
-
-    /* ---- :1489-1494 rain intercept/slope ---- */
-    for (k = kte; k >= kts; --k) {
-        lamr = d_powf(am_r * crg[2] * T->org2 * nr[k] / rr[k], T->obmr);
-        ilamr[k] = 1. / lamr;
-        mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
-        N0_r[k] = (double)(nr[k] * T->org2) * pow(lamr, (double)cre[1]);
-    }
-
-    /* ---- :1500-1544 warm rain ---- */
     for (k = kts; k <= kte; ++k) {
-        if (L_qr[k] && mvd_r[k] > D0r) {
-            Ef_rr = 2.0f - d_expf(2300.0f * (mvd_r[k] - 1600.0E-6f));
-            pnr_rcr[k] = Ef_rr * 4.f * nr[k] * rr[k];
+        double prr_wau = 0, prr_rcw = 0, prr_rcs = 0, prr_rcg = 0, prr_sml = 0, prr_gml = 0, prr_rci = 0, pnr_wau = 0, pnr_rcs = 0, pnr_rcg = 0, pnr_rci = 0, pnr_sml = 0, pnr_gml = 0, pnr_rcr = 0, pnr_rfz = 0, pri_inu = 0, pni_inu = 0, pri_ihm = 0, pni_ihm = 0, pri_wfz = 0, pni_wfz = 0, pri_rfz = 0, pni_rfz = 0, pri_ide = 0, pni_ide = 0, pri_rci = 0, pni_rci = 0, pni_sci = 0, pni_iau = 0, prs_iau = 0, prs_sci = 0, prs_rcs = 0, prs_scw = 0, prs_sde = 0, prs_ihm = 0, prs_ide = 0, prg_scw = 0, prg_rfz = 0, prg_gde = 0, prg_gcw = 0, prg_rci = 0, prg_rcs = 0, prg_rcg = 0, prg_ihm = 0;
+        float rhof, rhof2, qvs, qvsi, delQvs, satw, sati, ssatw, ssati, diffu, visco, vsc2, tcond, lvap, ocp, mvd_c;
+        float smob = 0.f, smo2 = 0.f, smo1 = 0.f, smo0 = 0.f, smoc = 0.f, smoe = 0.f, smof = 0.f;
+        double ilamr, N0_r;
+        (void)satw; (void)sati; (void)smo2;
+        tempc = temp[k] - 273.15f;
+        rhof = sqrtf(TH_rho_not / rho[k]);
+        rhof2 = sqrtf(rhof);
+        qvs = rslf(pres[k], temp[k]);
+        delQvs = fmaxf(0.0f, rslf(pres[k], 273.15f) - qv[k]);
+        if (tempc <= 0.0f) qvsi = rsif(pres[k], temp[k]); else qvsi = qvs;
+        satw = qv[k] / qvs;
+        sati = qv[k] / qvsi;
+        ssatw = satw - 1.f;
+        ssati = sati - 1.f;
+        if (fabsf(ssatw) < eps) ssatw = 0.0f;
+        if (fabsf(ssati) < eps) ssati = 0.0f;
+        diffu = 2.11E-5f * d_powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
+        if (tempc >= 0.0f) visco = (1.718f + 0.0049f * tempc) * 1.0E-5f;
+        else visco = (1.718f + 0.0049f * tempc - 1.2E-5f * tempc * tempc) * 1.0E-5f;
+        ocp = 1.f / (TH_Cp2 * (1.f + 0.887f * qv[k]));
+        vsc2 = sqrtf(rho[k] / visco);
+        lvap = lvap0 + (2106.0f - 4218.0f) * tempc;
+        tcond = (5.69f + 0.0168f * tempc) * 1.0E-5f * 418.936f;
+            if (L_qs[k]) {
+        tc0 = fminf(-0.1f, temp[k] - 273.15f);
+        smob = rs[k] * T->oams;
+        if (TH_bm_s > (2.0f - 1.e-3f) && TH_bm_s < (2.0f + 1.e-3f)) smo2 = smob;
+        else {
+            loga_ = snow_poly_f(sa, tc0, TH_bm_s); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH_bm_s);
+            smo2 = d_powf(smob / a_, 1.f / b_);
         }
-        mvd_c[k] = D0c;
-        if (!L_qc[k]) continue;
+        loga_ = sa[0] + sa[1] * tc0 + sa[4] * tc0 * tc0 + sa[8] * tc0 * tc0 * tc0;
+        a_ = d_powf(10.0f, loga_);
+        b_ = sb[0] + sb[1] * tc0 + sb[4] * tc0 * tc0 + sb[8] * tc0 * tc0 * tc0;
+        smo0 = a_ * d_powf(smo2, b_);
+        loga_ = sa[0] + sa[1] * tc0 + sa[2] + sa[3] * tc0 + sa[4] * tc0 * tc0 + sa[5] + sa[6] * tc0 * tc0 + sa[7] * tc0
+              + sa[8] * tc0 * tc0 * tc0 + sa[9];
+        a_ = d_powf(10.0f, loga_);
+        b_ = sb[0] + sb[1] * tc0 + sb[2] + sb[3] * tc0 + sb[4] * tc0 * tc0 + sb[5] + sb[6] * tc0 * tc0 + sb[7] * tc0
+           + sb[8] * tc0 * tc0 * tc0 + sb[9];
+        smo1 = a_ * d_powf(smo2, b_);
+        loga_ = snow_poly_f(sa, tc0, T->cse[0]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[0]);
+        smoc = a_ * d_powf(smo2, b_);
+        loga_ = snow_poly_f(sa, tc0, T->cse[12]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[12]);
+        smoe = a_ * d_powf(smo2, b_);
+        loga_ = snow_poly_f(sa, tc0, T->cse[15]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[15]);
+        smof = a_ * d_powf(smo2, b_);
+            }
+        lamr = d_powf(am_r * crg[2] * T->org2 * nr[k] / rr[k], T->obmr);
+        ilamr = 1. / lamr;
+        mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
+        N0_r = (double)(nr[k] * T->org2) * pow(lamr, (double)cre[1]);
+            if (L_qr[k] && mvd_r[k] > D0r) {
+            Ef_rr = 2.0f - d_expf(2300.0f * (mvd_r[k] - 1600.0E-6f));
+            pnr_rcr = Ef_rr * 4.f * nr[k] * rr[k];
+        }
+        mvd_c = D0c;
+        if (L_qc[k]) {
         xDc = fmaxf(D0c * 1.E6f, (d_powf(rc[k] / (am_r * Nt_c), T->obmr)) * 1.E6f);
         lamc = d_powf(Nt_c * am_r * ccg[1] * T->ocg1 / rc[k], T->obmr);
-        mvd_c[k] = (float)((double)(3.0f + mu_c + 0.672f) / lamc);
+        mvd_c = (float)((double)(3.0f + mu_c + 0.672f) / lamc);
         if (rc[k] > 0.01e-3f) {
             Dc_g = (float)(((double)d_powf(ccg[2] * T->ocg2, T->obmr) / lamc) * (double)1.E6f);
             Dc_b = d_powf(xDc * xDc * xDc * Dc_g * Dc_g * Dc_g - xDc * xDc * xDc * xDc * xDc * xDc, 1.f / 6.f);
@@ -301,24 +284,21 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             zeta = 0.027f * rc[k] * zeta1;
             taud = 0.5f * ((0.5f * Dc_b - 7.5f) + fabsf(0.5f * Dc_b - 7.5f)) + R1;
             tau = 3.72f / (rc[k] * taud);
-            prr_wau[k] = zeta / tau;
-            prr_wau[k] = fmin((double)(rc[k] * odts), prr_wau[k]);
-            pnr_wau[k] = prr_wau[k] / (double)(am_r * mu_c * D0r * D0r * D0r);
+            prr_wau = zeta / tau;
+            prr_wau = fmin((double)(rc[k] * odts), prr_wau);
+            pnr_wau = prr_wau / (double)(am_r * mu_c * D0r * D0r * D0r);
         }
-        if (L_qr[k] && mvd_r[k] > D0r && mvd_c[k] > D0c) {
-            lamr = 1. / ilamr[k];
+        if (L_qr[k] && mvd_r[k] > D0r && mvd_c > D0c) {
+            lamr = 1. / ilamr;
             idx = 1 + (int)(NBINS * log((double)mvd_r[k] / T->Dr[0]) / log(T->Dr[NBINS - 1] / T->Dr[0]));
             idx = imin(idx, NBINS);
-            int ic = (int)(mvd_c[k] * 1.E6f);
+            int ic = (int)(mvd_c * 1.E6f);
             ic = imax(1, imin(ic, NBINS));          /* the reference does not bound this index */
             Ef_rw = (float)T->t_Efrw[(idx - 1) + NBINS * (ic - 1)];
-            prr_rcw[k] = (double)(rhof[k] * T->t1_qr_qc * Ef_rw * rc[k]) * N0_r[k] * pow(lamr + (double)fv_r, -(double)cre[8]);
-            prr_rcw[k] = fmin((double)(rc[k] * odts), prr_rcw[k]);
+            prr_rcw = (double)(rhof * T->t1_qr_qc * Ef_rw * rc[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[8]);
+            prr_rcw = fmin((double)(rc[k] * odts), prr_rcw);
         }
-    }
-
-    /* ---- :1550-2009 frozen-species process terms ---- */
-    for (k = kts; k <= kte; ++k) {
+            }
         vts_boost[k] = 1.5f;
         tempc = temp[k] - 273.15f;
         idx_tc = imax(1, imin((int)lroundf(-tempc), 45));
@@ -331,7 +311,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         if (ni[k] > T->Nt_i[0]) { idx_i1 = dec_index_f(ni[k], T->nii3); idx_i1 = imax(1, imin(idx_i1, NTB_I1)); } else idx_i1 = 1;
         if (rr[k] > T->r_r[0]) {
             idx_r = dec_index_f(rr[k], T->nir2); idx_r = imax(1, imin(idx_r, NTB_R));
-            lamr = 1. / ilamr[k];
+            lamr = 1. / ilamr;
             lam_exp = lamr * cube_f(crg[2] * T->org2 * T->org1);
             N0_exp = (double)(T->org1 * rr[k] / am_r) * pow(lam_exp, (double)cre[0]);
             idx_r1 = dec_index_d(N0_exp, T->nir3); idx_r1 = imax(1, imin(idx_r1, NTB_R1));
@@ -347,38 +327,38 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
 
         /* deposition/sublimation prefactor :1679-1695 */
         otemp = 1.f / temp[k];
-        rvs = rho[k] * qvsi[k];
+        rvs = rho[k] * qvsi;
         rvs_p = rvs * otemp * (lsub * otemp * oRv - 1.f);
         rvs_pp = rvs * (otemp * (lsub * otemp * oRv - 1.f) * otemp * (lsub * otemp * oRv - 1.f)
                         + (-2.f * lsub * otemp * otemp * otemp * oRv) + otemp * otemp);
-        gamsc = lsub * diffu[k] / tcond[k] * rvs_p;
+        gamsc = lsub * diffu / tcond * rvs_p;
         alphsc = 0.5f * (gamsc / (1.f + gamsc)) * (gamsc / (1.f + gamsc)) * rvs_pp / rvs_p * rvs / rvs_p;
         alphsc = fmaxf(1.E-9f, alphsc);
-        xsat = ssati[k];
+        xsat = ssati;
         if (fabsf(xsat) < 1.E-9f) xsat = 0.f;
         t1_subl = 4.f * PI2 * (1.0f - alphsc * xsat + 2.f * alphsc * alphsc * xsat * xsat
                                - 5.f * alphsc * alphsc * alphsc * xsat * xsat * xsat) / (1.f + gamsc);
 
         /* snow / graupel collecting cloud water :1698-1725 */
-        if (L_qc[k] && mvd_c[k] > D0c) {
+        if (L_qc[k] && mvd_c > D0c) {
             xDs = 0.0f;
-            if (L_qs[k]) xDs = smoc[k] / smob[k];
+            if (L_qs[k]) xDs = smoc / smob;
             if (xDs > D0s) {
                 idx = 1 + (int)(NBINS * log((double)xDs / T->Ds[0]) / log(T->Ds[NBINS - 1] / T->Ds[0]));
                 idx = imin(idx, NBINS);
-                int ic = (int)(mvd_c[k] * 1.E6f); ic = imax(1, imin(ic, NBINS));
+                int ic = (int)(mvd_c * 1.E6f); ic = imax(1, imin(ic, NBINS));
                 Ef_sw = (float)T->t_Efsw[(idx - 1) + NBINS * (ic - 1)];
-                prs_scw[k] = rhof[k] * T->t1_qs_qc * Ef_sw * rc[k] * smoe[k];
+                prs_scw = rhof * T->t1_qs_qc * Ef_sw * rc[k] * smoe;
             }
-            if (rg[k] >= T->r_g[0] && mvd_c[k] > D0c) {
+            if (rg[k] >= T->r_g[0] && mvd_c > D0c) {
                 xDg = (float)((double)(bm_g + mu_g + 1.f) * ilamg[k]);
-                vtg = (float)((double)(rhof[k] * av_g * cgg[5] * T->ogg3) * pow(ilamg[k], (double)bv_g));
-                stoke_g = mvd_c[k] * mvd_c[k] * vtg * rho_w / (9.f * visco[k] * xDg);
+                vtg = (float)((double)(rhof * av_g * cgg[5] * T->ogg3) * pow(ilamg[k], (double)bv_g));
+                stoke_g = mvd_c * mvd_c * vtg * rho_w / (9.f * visco * xDg);
                 if (xDg > D0g) {
                     if (stoke_g >= 0.4f && stoke_g <= 10.f) Ef_gw = 0.55f * d_log10f(2.51f * stoke_g);
                     else if (stoke_g < 0.4f) Ef_gw = 0.0f;
                     else if (stoke_g > 10.f) Ef_gw = 0.77f;
-                    prg_gcw[k] = (double)(rhof[k] * T->t1_qg_qc * Ef_gw * rc[k]) * N0_g[k] * pow(ilamg[k], (double)cge[8]);
+                    prg_gcw = (double)(rhof * T->t1_qg_qc * Ef_gw * rc[k]) * N0_g[k] * pow(ilamg[k], (double)cge[8]);
                 }
             }
         }
@@ -387,65 +367,65 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         if (rr[k] >= T->r_r[0]) {
             if (rs[k] >= T->r_s[0]) {
                 if (temp[k] < T_0) {
-                    prr_rcs[k] = -(T4S(tmr_racs2) + T4S(tcr_sacr2) + T4S(tmr_racs1) + T4S(tcr_sacr1));
-                    prs_rcs[k] = T4S(tmr_racs2) + T4S(tcr_sacr2) - T4S(tcs_racs1) - T4S(tms_sacr1);
-                    prg_rcs[k] = T4S(tmr_racs1) + T4S(tcr_sacr1) + T4S(tcs_racs1) + T4S(tms_sacr1);
-                    prr_rcs[k] = fmax((double)(-rr[k] * odts), prr_rcs[k]);
-                    prs_rcs[k] = fmax((double)(-rs[k] * odts), prs_rcs[k]);
-                    prg_rcs[k] = fmin((double)((rr[k] + rs[k]) * odts), prg_rcs[k]);
-                    pnr_rcs[k] = T4S(tnr_racs1) + T4S(tnr_racs2) + T4S(tnr_sacr1) + T4S(tnr_sacr2);
+                    prr_rcs = -(T4S(tmr_racs2) + T4S(tcr_sacr2) + T4S(tmr_racs1) + T4S(tcr_sacr1));
+                    prs_rcs = T4S(tmr_racs2) + T4S(tcr_sacr2) - T4S(tcs_racs1) - T4S(tms_sacr1);
+                    prg_rcs = T4S(tmr_racs1) + T4S(tcr_sacr1) + T4S(tcs_racs1) + T4S(tms_sacr1);
+                    prr_rcs = fmax((double)(-rr[k] * odts), prr_rcs);
+                    prs_rcs = fmax((double)(-rs[k] * odts), prs_rcs);
+                    prg_rcs = fmin((double)((rr[k] + rs[k]) * odts), prg_rcs);
+                    pnr_rcs = T4S(tnr_racs1) + T4S(tnr_racs2) + T4S(tnr_sacr1) + T4S(tnr_sacr2);
                 } else {
-                    prs_rcs[k] = -T4S(tcs_racs1) - T4S(tms_sacr1) + T4S(tmr_racs2) + T4S(tcr_sacr2);
-                    prs_rcs[k] = fmax((double)(-rs[k] * odts), prs_rcs[k]);
-                    prr_rcs[k] = -prs_rcs[k];
-                    pnr_rcs[k] = T4S(tnr_racs2) + T4S(tnr_sacr2);
+                    prs_rcs = -T4S(tcs_racs1) - T4S(tms_sacr1) + T4S(tmr_racs2) + T4S(tcr_sacr2);
+                    prs_rcs = fmax((double)(-rs[k] * odts), prs_rcs);
+                    prr_rcs = -prs_rcs;
+                    pnr_rcs = T4S(tnr_racs2) + T4S(tnr_sacr2);
                 }
-                pnr_rcs[k] = fmin((double)(nr[k] * odts), pnr_rcs[k]);
+                pnr_rcs = fmin((double)(nr[k] * odts), pnr_rcs);
             }
             if (rg[k] >= T->r_g[0]) {
                 if (temp[k] < T_0) {
-                    prg_rcg[k] = T4G(tmr_racg) + T4G(tcr_gacr);
-                    prg_rcg[k] = fmin((double)(rr[k] * odts), prg_rcg[k]);
-                    prr_rcg[k] = -prg_rcg[k];
-                    pnr_rcg[k] = T4G(tnr_racg) + T4G(tnr_gacr);
-                    pnr_rcg[k] = fmin((double)(nr[k] * odts), pnr_rcg[k]);
+                    prg_rcg = T4G(tmr_racg) + T4G(tcr_gacr);
+                    prg_rcg = fmin((double)(rr[k] * odts), prg_rcg);
+                    prr_rcg = -prg_rcg;
+                    pnr_rcg = T4G(tnr_racg) + T4G(tnr_gacr);
+                    pnr_rcg = fmin((double)(nr[k] * odts), pnr_rcg);
                 } else {
-                    prr_rcg[k] = T4G(tcg_racg);
-                    prr_rcg[k] = fmin((double)(rg[k] * odts), prr_rcg[k]);
-                    prg_rcg[k] = -prr_rcg[k];
+                    prr_rcg = T4G(tcg_racg);
+                    prr_rcg = fmin((double)(rg[k] * odts), prr_rcg);
+                    prg_rcg = -prr_rcg;
                 }
             }
         }
 
         if (temp[k] < T_0) {      /* :1789-1949 sub-zero processes */
             vts_boost[k] = 1.0f;
-            rate_max = (qv[k] - qvsi[k]) * rho[k] * odts * 0.999f;
+            rate_max = (qv[k] - qvsi) * rho[k] * odts * 0.999f;
             if (rr[k] > T->r_r[0]) {
-                prg_rfz[k] = T3R(tpg_qrfz) * odts;
-                pri_rfz[k] = T3R(tpi_qrfz) * odts;
-                pni_rfz[k] = T3R(tni_qrfz) * odts;
-                pnr_rfz[k] = T3R(tnr_qrfz) * odts;
-                pnr_rfz[k] = fmin((double)(nr[k] * odts), pnr_rfz[k]);
+                prg_rfz = T3R(tpg_qrfz) * odts;
+                pri_rfz = T3R(tpi_qrfz) * odts;
+                pni_rfz = T3R(tni_qrfz) * odts;
+                pnr_rfz = T3R(tnr_qrfz) * odts;
+                pnr_rfz = fmin((double)(nr[k] * odts), pnr_rfz);
             } else if (rr[k] > R1 && temp[k] < HGFR) {
-                pri_rfz[k] = rr[k] * odts;
-                pnr_rfz[k] = nr[k] * odts;
-                pni_rfz[k] = pnr_rfz[k];
+                pri_rfz = rr[k] * odts;
+                pnr_rfz = nr[k] * odts;
+                pni_rfz = pnr_rfz;
             }
             if (rc[k] > T->r_c[0]) {
-                pri_wfz[k] = T2C(tpi_qcfz) * odts;
-                pri_wfz[k] = fmin((double)(rc[k] * odts), pri_wfz[k]);
-                pni_wfz[k] = T2C(tni_qcfz) * odts;
-                pni_wfz[k] = fmin(fmin((double)(Nt_c * odts), pri_wfz[k] / (double)(2.f * xm0i)), pni_wfz[k]);
+                pri_wfz = T2C(tpi_qcfz) * odts;
+                pri_wfz = fmin((double)(rc[k] * odts), pri_wfz);
+                pni_wfz = T2C(tni_qcfz) * odts;
+                pni_wfz = fmin(fmin((double)(Nt_c * odts), pri_wfz / (double)(2.f * xm0i)), pni_wfz);
             } else if (rc[k] > R1 && temp[k] < HGFR) {
-                pri_wfz[k] = rc[k] * odts;
-                pni_wfz[k] = fmin(fmin((double)(Nt_c * odts), pri_wfz[k] / (double)(2.f * xm0i)), pni_wfz[k]);
+                pri_wfz = rc[k] * odts;
+                pni_wfz = fmin(fmin((double)(Nt_c * odts), pri_wfz / (double)(2.f * xm0i)), pni_wfz);
             }
-            if ((ssati[k] >= 0.25f) || (ssatw[k] > eps && temp[k] < 261.15f)) {
+            if ((ssati >= 0.25f) || (ssatw > eps && temp[k] < 261.15f)) {
                 xnc = fminf(250.E3f, T->TNO * d_expf(TH_ATO * (T_0 - temp[k])));
-                xni = (float)((double)ni[k] + (pni_rfz[k] + pni_wfz[k]) * (double)dtsave);
-                pni_inu[k] = 0.5f * (xnc - xni + fabsf(xnc - xni)) * odts;
-                pri_inu[k] = fmin((double)rate_max, (double)xm0i * pni_inu[k]);
-                pni_inu[k] = pri_inu[k] / (double)xm0i;
+                xni = (float)((double)ni[k] + (pni_rfz + pni_wfz) * (double)dtsave);
+                pni_inu = 0.5f * (xnc - xni + fabsf(xnc - xni)) * odts;
+                pri_inu = fmin((double)rate_max, (double)xm0i * pni_inu);
+                pni_inu = pri_inu / (double)xm0i;
             }
             if (L_qi[k]) {
                 lami = d_powf(am_i * cig[1] * T->oig1 * ni[k] / ri[k], T->obmi);
@@ -453,42 +433,42 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
                 xDi = (float)fmax((double)T->D0i, (double)(bm_i + mu_i + 1.f) * ilami);
                 xmi = am_i * (xDi * xDi * xDi);
                 oxmi = 1.f / xmi;
-                pri_ide[k] = (double)(C_cube * t1_subl * diffu[k] * ssati[k] * rvs * T->oig1 * cig[4] * ni[k]) * ilami;
-                if (pri_ide[k] < 0.0) {
-                    pri_ide[k] = fmax(fmax((double)(-ri[k] * odts), pri_ide[k]), (double)rate_max);
-                    pni_ide[k] = pri_ide[k] * (double)oxmi;
-                    pni_ide[k] = fmax((double)(-ni[k] * odts), pni_ide[k]);
+                pri_ide = (double)(C_cube * t1_subl * diffu * ssati * rvs * T->oig1 * cig[4] * ni[k]) * ilami;
+                if (pri_ide < 0.0) {
+                    pri_ide = fmax(fmax((double)(-ri[k] * odts), pri_ide), (double)rate_max);
+                    pni_ide = pri_ide * (double)oxmi;
+                    pni_ide = fmax((double)(-ni[k] * odts), pni_ide);
                 } else {
-                    pri_ide[k] = fmin(pri_ide[k], (double)rate_max);
-                    prs_ide[k] = (1.0 - T2I(tpi_ide)) * pri_ide[k];
-                    pri_ide[k] = T2I(tpi_ide) * pri_ide[k];
+                    pri_ide = fmin(pri_ide, (double)rate_max);
+                    prs_ide = (1.0 - T2I(tpi_ide)) * pri_ide;
+                    pri_ide = T2I(tpi_ide) * pri_ide;
                 }
                 if ((idx_i == NTB_I) || (xDi > 5.0f * D0s)) {
-                    prs_iau[k] = ri[k] * .99f * odts;
-                    pni_iau[k] = ni[k] * .95f * odts;
+                    prs_iau = ri[k] * .99f * odts;
+                    pni_iau = ni[k] * .95f * odts;
                 } else if (xDi < 0.1f * D0s) {
-                    prs_iau[k] = 0.; pni_iau[k] = 0.;
+                    prs_iau = 0.; pni_iau = 0.;
                 } else {
-                    prs_iau[k] = T2I(tps_iaus) * odts;
-                    prs_iau[k] = fmin((double)(ri[k] * .99f * odts), prs_iau[k]);
-                    pni_iau[k] = T2I(tni_iaus) * odts;
-                    pni_iau[k] = fmin((double)(ni[k] * .95f * odts), pni_iau[k]);
+                    prs_iau = T2I(tps_iaus) * odts;
+                    prs_iau = fmin((double)(ri[k] * .99f * odts), prs_iau);
+                    pni_iau = T2I(tni_iaus) * odts;
+                    pni_iau = fmin((double)(ni[k] * .95f * odts), pni_iau);
                 }
             }
             if (L_qs[k]) {
                 C_snow = T->C_sqrd + (tempc + 15.f) * (T->C_cubes - T->C_sqrd) / (-30.f + 15.f);
                 C_snow = fmaxf(T->C_sqrd, fminf(C_snow, T->C_cubes));
-                prs_sde[k] = C_snow * t1_subl * diffu[k] * ssati[k] * rvs
-                             * (T->t1_qs_sd * smo1[k] + T->t2_qs_sd * rhof2[k] * vsc2[k] * smof[k]);
-                if (prs_sde[k] < 0.) prs_sde[k] = fmax(fmax((double)(-rs[k] * odts), prs_sde[k]), (double)rate_max);
-                else prs_sde[k] = fmin(prs_sde[k], (double)rate_max);
+                prs_sde = C_snow * t1_subl * diffu * ssati * rvs
+                             * (T->t1_qs_sd * smo1 + T->t2_qs_sd * rhof2 * vsc2 * smof);
+                if (prs_sde < 0.) prs_sde = fmax(fmax((double)(-rs[k] * odts), prs_sde), (double)rate_max);
+                else prs_sde = fmin(prs_sde, (double)rate_max);
             }
-            if (L_qg[k] && ssati[k] < -eps) {
-                prg_gde[k] = (double)(C_cube * t1_subl * diffu[k] * ssati[k] * rvs) * N0_g[k]
+            if (L_qg[k] && ssati < -eps) {
+                prg_gde = (double)(C_cube * t1_subl * diffu * ssati * rvs) * N0_g[k]
                              * ((double)T->t1_qg_sd * pow(ilamg[k], (double)cge[9])
-                                + (double)(T->t2_qg_sd * vsc2[k] * rhof2[k]) * pow(ilamg[k], (double)cge[10]));
-                if (prg_gde[k] < 0.) prg_gde[k] = fmax(fmax((double)(-rg[k] * odts), prg_gde[k]), (double)rate_max);
-                else prg_gde[k] = fmin(prg_gde[k], (double)rate_max);
+                                + (double)(T->t2_qg_sd * vsc2 * rhof2) * pow(ilamg[k], (double)cge[10]));
+                if (prg_gde < 0.) prg_gde = fmax(fmax((double)(-rg[k] * odts), prg_gde), (double)rate_max);
+                else prg_gde = fmin(prg_gde, (double)rate_max);
             }
             if (L_qi[k]) {
                 lami = d_powf(am_i * cig[1] * T->oig1 * ni[k] / ri[k], T->obmi);
@@ -497,133 +477,123 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
                 xmi = am_i * (xDi * xDi * xDi);
                 oxmi = 1.f / xmi;
                 if (rs[k] >= T->r_s[0]) {
-                    prs_sci[k] = T->t1_qs_qi * rhof[k] * T->Ef_si * ri[k] * smoe[k];
-                    pni_sci[k] = prs_sci[k] * (double)oxmi;
+                    prs_sci = T->t1_qs_qi * rhof * T->Ef_si * ri[k] * smoe;
+                    pni_sci = prs_sci * (double)oxmi;
                 }
                 if (rr[k] >= T->r_r[0] && mvd_r[k] > 4.f * xDi) {
-                    lamr = 1. / ilamr[k];
-                    pri_rci[k] = (double)(rhof[k] * T->t1_qr_qi * T->Ef_ri * ri[k]) * N0_r[k] * pow(lamr + (double)fv_r, -(double)cre[8]);
-                    pnr_rci[k] = (double)(rhof[k] * T->t1_qr_qi * T->Ef_ri * ni[k]) * N0_r[k] * pow(lamr + (double)fv_r, -(double)cre[8]);
-                    pni_rci[k] = pri_rci[k] * (double)oxmi;
-                    prr_rci[k] = (double)(rhof[k] * T->t2_qr_qi * T->Ef_ri * ni[k]) * N0_r[k] * pow(lamr + (double)fv_r, -(double)cre[7]);
-                    prr_rci[k] = fmin((double)(rr[k] * odts), prr_rci[k]);
-                    prg_rci[k] = pri_rci[k] + prr_rci[k];
+                    lamr = 1. / ilamr;
+                    pri_rci = (double)(rhof * T->t1_qr_qi * T->Ef_ri * ri[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[8]);
+                    pnr_rci = (double)(rhof * T->t1_qr_qi * T->Ef_ri * ni[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[8]);
+                    pni_rci = pri_rci * (double)oxmi;
+                    prr_rci = (double)(rhof * T->t2_qr_qi * T->Ef_ri * ni[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[7]);
+                    prr_rci = fmin((double)(rr[k] * odts), prr_rci);
+                    prg_rci = pri_rci + prr_rci;
                 }
             }
-            if (prg_gcw[k] > (double)eps && tempc > -8.0f) {
+            if (prg_gcw > (double)eps && tempc > -8.0f) {
                 tf = 0.f;
                 if (tempc >= -5.0f && tempc < -3.0f) tf = 0.5f * (-3.0f - tempc);
                 else if (tempc > -8.0f && tempc < -5.0f) tf = 0.33333333f * (8.0f + tempc);
-                pni_ihm[k] = (double)(3.5E8f * tf) * prg_gcw[k];
-                pri_ihm[k] = (double)xm0i * pni_ihm[k];
-                prs_ihm[k] = prs_scw[k] / (prs_scw[k] + prg_gcw[k]) * pri_ihm[k];
-                prg_ihm[k] = prg_gcw[k] / (prs_scw[k] + prg_gcw[k]) * pri_ihm[k];
+                pni_ihm = (double)(3.5E8f * tf) * prg_gcw;
+                pri_ihm = (double)xm0i * pni_ihm;
+                prs_ihm = prs_scw / (prs_scw + prg_gcw) * pri_ihm;
+                prg_ihm = prg_gcw / (prs_scw + prg_gcw) * pri_ihm;
             }
-            if (prs_scw[k] > (double)5.0f * prs_sde[k] && prs_sde[k] > (double)eps) {
-                r_frac = (float)fmin(30.0, prs_scw[k] / prs_sde[k]);
+            if (prs_scw > (double)5.0f * prs_sde && prs_sde > (double)eps) {
+                r_frac = (float)fmin(30.0, prs_scw / prs_sde);
                 g_frac = fminf(0.75f, 0.05f + (r_frac - 5.f) * .028f);
                 vts_boost[k] = fminf(1.5f, 1.1f + (r_frac - 5.f) * .016f);
-                prg_scw[k] = (double)g_frac * prs_scw[k];
-                prs_scw[k] = (double)(1.f - g_frac) * prs_scw[k];
+                prg_scw = (double)g_frac * prs_scw;
+                prs_scw = (double)(1.f - g_frac) * prs_scw;
             }
         } else {                  /* :1953-2005 melting */
             if (L_qs[k]) {
-                prr_sml[k] = (tempc * tcond[k] - lvap0 * diffu[k] * delQvs[k])
-                             * (T->t1_qs_me * smo1[k] + T->t2_qs_me * rhof2[k] * vsc2[k] * smof[k]);
-                prr_sml[k] = prr_sml[k] + (double)(4218.f * olfus * tempc) * (prr_rcs[k] + prs_scw[k]);
-                prr_sml[k] = fmin((double)(rs[k] * odts), fmax(0., prr_sml[k]));
-                pnr_sml[k] = (double)(smo0[k] / rs[k]) * prr_sml[k] * (double)d_powf(10.0f, -0.75f * tempc);
-                pnr_sml[k] = fmin((double)(smo0[k] * odts), pnr_sml[k]);
-                if (tempc > 3.5f || rs[k] < 0.005E-3f) pnr_sml[k] = 0.0;
-                if (ssati[k] < 0.f) {
-                    prs_sde[k] = T->C_cubes * t1_subl * diffu[k] * ssati[k] * rvs
-                                 * (T->t1_qs_sd * smo1[k] + T->t2_qs_sd * rhof2[k] * vsc2[k] * smof[k]);
-                    prs_sde[k] = fmax((double)(-rs[k] * odts), prs_sde[k]);
+                prr_sml = (tempc * tcond - lvap0 * diffu * delQvs)
+                             * (T->t1_qs_me * smo1 + T->t2_qs_me * rhof2 * vsc2 * smof);
+                prr_sml = prr_sml + (double)(4218.f * olfus * tempc) * (prr_rcs + prs_scw);
+                prr_sml = fmin((double)(rs[k] * odts), fmax(0., prr_sml));
+                pnr_sml = (double)(smo0 / rs[k]) * prr_sml * (double)d_powf(10.0f, -0.75f * tempc);
+                pnr_sml = fmin((double)(smo0 * odts), pnr_sml);
+                if (tempc > 3.5f || rs[k] < 0.005E-3f) pnr_sml = 0.0;
+                if (ssati < 0.f) {
+                    prs_sde = T->C_cubes * t1_subl * diffu * ssati * rvs
+                                 * (T->t1_qs_sd * smo1 + T->t2_qs_sd * rhof2 * vsc2 * smof);
+                    prs_sde = fmax((double)(-rs[k] * odts), prs_sde);
                 }
             }
             if (L_qg[k]) {
-                prr_gml[k] = (double)(tempc * tcond[k] - lvap0 * diffu[k] * delQvs[k]) * N0_g[k]
+                prr_gml = (double)(tempc * tcond - lvap0 * diffu * delQvs) * N0_g[k]
                              * ((double)T->t1_qg_me * pow(ilamg[k], (double)cge[9])
-                                + (double)(T->t2_qg_me * rhof2[k] * vsc2[k]) * pow(ilamg[k], (double)cge[10]));
-                prr_gml[k] = fmin((double)(rg[k] * odts), fmax(0., prr_gml[k]));
-                pnr_gml[k] = N0_g[k] * (double)cgg[1] * pow(ilamg[k], (double)cge[1]) / (double)rg[k]
-                             * prr_gml[k] * (double)d_powf(10.0f, -1.5f * tempc);
-                if (tempc > 7.5f || rg[k] < 0.005E-3f) pnr_gml[k] = 0.0;
-                if (ssati[k] < 0.f) {
-                    prg_gde[k] = (double)(C_cube * t1_subl * diffu[k] * ssati[k] * rvs) * N0_g[k]
+                                + (double)(T->t2_qg_me * rhof2 * vsc2) * pow(ilamg[k], (double)cge[10]));
+                prr_gml = fmin((double)(rg[k] * odts), fmax(0., prr_gml));
+                pnr_gml = N0_g[k] * (double)cgg[1] * pow(ilamg[k], (double)cge[1]) / (double)rg[k]
+                             * prr_gml * (double)d_powf(10.0f, -1.5f * tempc);
+                if (tempc > 7.5f || rg[k] < 0.005E-3f) pnr_gml = 0.0;
+                if (ssati < 0.f) {
+                    prg_gde = (double)(C_cube * t1_subl * diffu * ssati * rvs) * N0_g[k]
                                  * ((double)T->t1_qg_sd * pow(ilamg[k], (double)cge[9])
-                                    + (double)(T->t2_qg_sd * vsc2[k] * rhof2[k]) * pow(ilamg[k], (double)cge[10]));
-                    prg_gde[k] = fmax((double)(-rg[k] * odts), prg_gde[k]);
+                                    + (double)(T->t2_qg_sd * vsc2 * rhof2) * pow(ilamg[k], (double)cge[10]));
+                    prg_gde = fmax((double)(-rg[k] * odts), prg_gde);
                 }
             }
             if (dt > 120.f) {
-                prr_rcw[k] = prr_rcw[k] + prs_scw[k] + prg_gcw[k];
-                prs_scw[k] = 0.; prg_gcw[k] = 0.;
+                prr_rcw = prr_rcw + prs_scw + prg_gcw;
+                prs_scw = 0.; prg_gcw = 0.;
             }
         }
-    }
-
-    /* oracle/thompson_column_part2.inc -- continuation of th_column(): mp_thompson.f90:2012-2844 */
-
-    /* ---- :2015-2110 do not deplete more than exists ---- */
-    for (k = kts; k <= kte; ++k) {
-        sump = (float)(pri_inu[k] + pri_ide[k] + prs_ide[k] + prs_sde[k] + prg_gde[k]);
-        rate_max = (qv[k] - qvsi[k]) * odts * 0.999f;
+            sump = (float)(pri_inu + pri_ide + prs_ide + prs_sde + prg_gde);
+        rate_max = (qv[k] - qvsi) * odts * 0.999f;
         if ((sump > eps && sump > rate_max) || (sump < -eps && sump < rate_max)) {
             ratio = rate_max / sump;
-            pri_inu[k] *= ratio; pri_ide[k] *= ratio; pni_ide[k] *= ratio; prs_ide[k] *= ratio; prs_sde[k] *= ratio; prg_gde[k] *= ratio;
+            pri_inu *= ratio; pri_ide *= ratio; pni_ide *= ratio; prs_ide *= ratio; prs_sde *= ratio; prg_gde *= ratio;
         }
-        sump = (float)(-prr_wau[k] - pri_wfz[k] - prr_rcw[k] - prs_scw[k] - prg_scw[k] - prg_gcw[k]);
+        sump = (float)(-prr_wau - pri_wfz - prr_rcw - prs_scw - prg_scw - prg_gcw);
         rate_max = -rc[k] * odts;
         if (sump < rate_max && L_qc[k]) {
             ratio = rate_max / sump;
-            prr_wau[k] *= ratio; pri_wfz[k] *= ratio; prr_rcw[k] *= ratio; prs_scw[k] *= ratio; prg_scw[k] *= ratio; prg_gcw[k] *= ratio;
+            prr_wau *= ratio; pri_wfz *= ratio; prr_rcw *= ratio; prs_scw *= ratio; prg_scw *= ratio; prg_gcw *= ratio;
         }
-        sump = (float)(pri_ide[k] - prs_iau[k] - prs_sci[k] - pri_rci[k]);
+        sump = (float)(pri_ide - prs_iau - prs_sci - pri_rci);
         rate_max = -ri[k] * odts;
         if (sump < rate_max && L_qi[k]) {
             ratio = rate_max / sump;
-            pri_ide[k] *= ratio; prs_iau[k] *= ratio; prs_sci[k] *= ratio; pri_rci[k] *= ratio;
+            pri_ide *= ratio; prs_iau *= ratio; prs_sci *= ratio; pri_rci *= ratio;
         }
-        sump = (float)(-prg_rfz[k] - pri_rfz[k] - prr_rci[k] + prr_rcs[k] + prr_rcg[k]);
+        sump = (float)(-prg_rfz - pri_rfz - prr_rci + prr_rcs + prr_rcg);
         rate_max = -rr[k] * odts;
         if (sump < rate_max && L_qr[k]) {
             ratio = rate_max / sump;
-            prg_rfz[k] *= ratio; pri_rfz[k] *= ratio; prr_rci[k] *= ratio; prr_rcs[k] *= ratio; prr_rcg[k] *= ratio;
+            prg_rfz *= ratio; pri_rfz *= ratio; prr_rci *= ratio; prr_rcs *= ratio; prr_rcg *= ratio;
         }
-        sump = (float)(prs_sde[k] - prs_ihm[k] - prr_sml[k] + prs_rcs[k]);
+        sump = (float)(prs_sde - prs_ihm - prr_sml + prs_rcs);
         rate_max = -rs[k] * odts;
         if (sump < rate_max && L_qs[k]) {
             ratio = rate_max / sump;
-            prs_sde[k] *= ratio; prs_ihm[k] *= ratio; prr_sml[k] *= ratio; prs_rcs[k] *= ratio;
+            prs_sde *= ratio; prs_ihm *= ratio; prr_sml *= ratio; prs_rcs *= ratio;
         }
-        sump = (float)(prg_gde[k] - prg_ihm[k] - prr_gml[k] + prg_rcg[k]);
+        sump = (float)(prg_gde - prg_ihm - prr_gml + prg_rcg);
         rate_max = -rg[k] * odts;
         if (sump < rate_max && L_qg[k]) {
             ratio = rate_max / sump;
-            prg_gde[k] *= ratio; prg_ihm[k] *= ratio; prr_gml[k] *= ratio; prg_rcg[k] *= ratio;
+            prg_gde *= ratio; prg_ihm *= ratio; prr_gml *= ratio; prg_rcg *= ratio;
         }
-        pri_ihm[k] = prs_ihm[k] + prg_ihm[k];
-        ratio = (float)fmin(fabs(prr_rcg[k]), fabs(prg_rcg[k]));
-        prr_rcg[k] = ratio * copysignf(1.0f, (float)prr_rcg[k]);
-        prg_rcg[k] = -prr_rcg[k];
+        pri_ihm = prs_ihm + prg_ihm;
+        ratio = (float)fmin(fabs(prr_rcg), fabs(prg_rcg));
+        prr_rcg = ratio * copysignf(1.0f, (float)prr_rcg);
+        prg_rcg = -prr_rcg;
         if (temp[k] > T_0) {
-            ratio = (float)fmin(fabs(prr_rcs[k]), fabs(prs_rcs[k]));
-            prr_rcs[k] = ratio * copysignf(1.0f, (float)prr_rcs[k]);
-            prs_rcs[k] = -prr_rcs[k];
+            ratio = (float)fmin(fabs(prr_rcs), fabs(prs_rcs));
+            prr_rcs = ratio * copysignf(1.0f, (float)prr_rcs);
+            prs_rcs = -prr_rcs;
         }
-    }
-
-    /* ---- :2116-2236 tendencies ---- */
-    for (k = kts; k <= kte; ++k) {
-        orho = 1.f / rho[k];
-        lfus2 = lsub - lvap[k];
-        qvten[k] = (float)(qvten[k] + (-pri_inu[k] - pri_ide[k] - prs_ide[k] - prs_sde[k] - prg_gde[k]) * orho);
-        qcten[k] = (float)(qcten[k] + (-prr_wau[k] - pri_wfz[k] - prr_rcw[k] - prs_scw[k] - prg_scw[k] - prg_gcw[k]) * orho);
-        qiten[k] = (float)(qiten[k] + (pri_inu[k] + pri_ihm[k] + pri_wfz[k] + pri_rfz[k] + pri_ide[k]
-                                       - prs_iau[k] - prs_sci[k] - pri_rci[k]) * orho);
-        niten[k] = (float)(niten[k] + (pni_inu[k] + pni_ihm[k] + pni_wfz[k] + pni_rfz[k] + pni_ide[k]
-                                       - pni_iau[k] - pni_sci[k] - pni_rci[k]) * orho);
+            orho = 1.f / rho[k];
+        lfus2 = lsub - lvap;
+        qvten[k] = (float)(qvten[k] + (-pri_inu - pri_ide - prs_ide - prs_sde - prg_gde) * orho);
+        qcten[k] = (float)(qcten[k] + (-prr_wau - pri_wfz - prr_rcw - prs_scw - prg_scw - prg_gcw) * orho);
+        qiten[k] = (float)(qiten[k] + (pri_inu + pri_ihm + pri_wfz + pri_rfz + pri_ide
+                                       - prs_iau - prs_sci - pri_rci) * orho);
+        niten[k] = (float)(niten[k] + (pni_inu + pni_ihm + pni_wfz + pni_rfz + pni_ide
+                                       - pni_iau - pni_sci - pni_rci) * orho);
         xri = fmaxf(R1, (qi1d[k] + qiten[k] * dtsave) * rho[k]);
         xni = fmaxf(R2, (ni1d[k] + niten[k] * dtsave) * rho[k]);
         if (xri > R1) {
@@ -643,10 +613,10 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         xni = fmaxf(0.f, (ni1d[k] + niten[k] * dtsave) * rho[k]);
         if (xni > 250.E3f) niten[k] = (250.E3f - ni1d[k] * rho[k]) * odts * orho;
 
-        qrten[k] = (float)(qrten[k] + (prr_wau[k] + prr_rcw[k] + prr_sml[k] + prr_gml[k] + prr_rcs[k] + prr_rcg[k]
-                                       - prg_rfz[k] - pri_rfz[k] - prr_rci[k]) * orho);
-        nrten[k] = (float)(nrten[k] + (pnr_wau[k] + pnr_sml[k] + pnr_gml[k]
-                                       - (pnr_rfz[k] + pnr_rcr[k] + pnr_rcg[k] + pnr_rcs[k] + pnr_rci[k])) * orho);
+        qrten[k] = (float)(qrten[k] + (prr_wau + prr_rcw + prr_sml + prr_gml + prr_rcs + prr_rcg
+                                       - prg_rfz - pri_rfz - prr_rci) * orho);
+        nrten[k] = (float)(nrten[k] + (pnr_wau + pnr_sml + pnr_gml
+                                       - (pnr_rfz + pnr_rcr + pnr_rcg + pnr_rcs + pnr_rci)) * orho);
         xrr = fmaxf(R1, (qr1d[k] + qrten[k] * dtsave) * rho[k]);
         xnr = fmaxf(R2, (nr1d[k] + nrten[k] * dtsave) * rho[k]);
         if (xrr > R1) {
@@ -665,40 +635,41 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             }
         } else { qrten[k] = -qr1d[k] * odts; nrten[k] = -nr1d[k] * odts; }
 
-        qsten[k] = (float)(qsten[k] + (prs_iau[k] + prs_sde[k] + prs_sci[k] + prs_scw[k] + prs_rcs[k] + prs_ide[k]
-                                       - prs_ihm[k] - prr_sml[k]) * orho);
-        qgten[k] = (float)(qgten[k] + (prg_scw[k] + prg_rfz[k] + prg_gde[k] + prg_rcg[k] + prg_gcw[k] + prg_rci[k]
-                                       + prg_rcs[k] - prg_ihm[k] - prr_gml[k]) * orho);
+        qsten[k] = (float)(qsten[k] + (prs_iau + prs_sde + prs_sci + prs_scw + prs_rcs + prs_ide
+                                       - prs_ihm - prr_sml) * orho);
+        qgten[k] = (float)(qgten[k] + (prg_scw + prg_rfz + prg_gde + prg_rcg + prg_gcw + prg_rci
+                                       + prg_rcs - prg_ihm - prr_gml) * orho);
         if (temp[k] < T_0) {
-            tten[k] = (float)(tten[k] + ((double)(lsub * ocp[k]) * (pri_inu[k] + pri_ide[k] + prs_ide[k] + prs_sde[k] + prg_gde[k])
-                              + (double)(lfus2 * ocp[k]) * (pri_wfz[k] + pri_rfz[k] + prg_rfz[k] + prs_scw[k] + prg_scw[k] + prg_gcw[k]
-                                                             + prg_rcs[k] + prs_rcs[k] + prr_rci[k] + prg_rcg[k])) * orho * 1);
+            tten[k] = (float)(tten[k] + ((double)(lsub * ocp) * (pri_inu + pri_ide + prs_ide + prs_sde + prg_gde)
+                              + (double)(lfus2 * ocp) * (pri_wfz + pri_rfz + prg_rfz + prs_scw + prg_scw + prg_gcw
+                                                             + prg_rcs + prs_rcs + prr_rci + prg_rcg)) * orho * 1);
         } else {
-            tten[k] = (float)(tten[k] + ((double)(TH_lfus * ocp[k]) * (-prr_sml[k] - prr_gml[k] - prr_rcg[k] - prr_rcs[k])
-                              + (double)(lsub * ocp[k]) * (prs_sde[k] + prg_gde[k])) * orho * 1);
+            tten[k] = (float)(tten[k] + ((double)(TH_lfus * ocp) * (-prr_sml - prr_gml - prr_rcg - prr_rcs)
+                              + (double)(lsub * ocp) * (prs_sde + prg_gde)) * orho * 1);
         }
-    }
-
-    /* ---- :2241-2318 update to TAU+1 ---- */
+        }
     for (k = kts; k <= kte; ++k) {
+        float rhof, rhof2, qvs, ssatw, diffu, visco, vsc2, tcond, lvt2, smo2 = 0.f, smod = 0.f;
+        double ilamr, N0_r, prw_vcd = 0, prv_rev = 0, pnr_rev = 0;
+        (void)rhof2; (void)smod; (void)prv_rev;
         temp[k] = t1d[k] + dt * tten[k];
         otemp = 1.f / temp[k];
         tempc = temp[k] - 273.15f;
         qv[k] = fmaxf(1.E-10f, qv1d[k] + dt * qvten[k]);
         rho[k] = 0.622f * pres[k] / (TH_RR2 * temp[k] * (qv[k] + 0.622f));
-        rhof[k] = sqrtf(TH_rho_not / rho[k]);
-        rhof2[k] = sqrtf(rhof[k]);
-        qvs[k] = rslf(pres[k], temp[k]);
-        ssatw[k] = qv[k] / qvs[k] - 1.f;
-        if (fabsf(ssatw[k]) < eps) ssatw[k] = 0.0f;
-        diffu[k] = 2.11E-5f * d_powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
-        if (tempc >= 0.0f) visco[k] = (1.718f + 0.0049f * tempc) * 1.0E-5f;
-        else visco[k] = (1.718f + 0.0049f * tempc - 1.2E-5f * tempc * tempc) * 1.0E-5f;
-        vsc2[k] = sqrtf(rho[k] / visco[k]);
+        rhof = sqrtf(TH_rho_not / rho[k]);
+        rhof2 = sqrtf(rhof);
+        qvs = rslf(pres[k], temp[k]);
+        ssatw = qv[k] / qvs - 1.f;
+        if (fabsf(ssatw) < eps) ssatw = 0.0f;
+        diffu = 2.11E-5f * d_powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
+        if (tempc >= 0.0f) visco = (1.718f + 0.0049f * tempc) * 1.0E-5f;
+        else visco = (1.718f + 0.0049f * tempc - 1.2E-5f * tempc * tempc) * 1.0E-5f;
+        vsc2 = sqrtf(rho[k] / visco);
         lvap[k] = lvap0 + (2106.0f - 4218.0f) * tempc;
-        tcond[k] = (5.69f + 0.0168f * tempc) * 1.0E-5f * 418.936f;
+        tcond = (5.69f + 0.0168f * tempc) * 1.0E-5f * 418.936f;
         ocp[k] = 1.f / (TH_Cp2 * (1.f + 0.887f * qv[k]));
-        lvt2[k] = lvap[k] * lvap[k] * ocp[k] * oRv * otemp * otemp;
+        lvt2 = lvap[k] * lvap[k] * ocp[k] * oRv * otemp * otemp;
 
         if ((qc1d[k] + qcten[k] * dt) > R1) { rc[k] = (qc1d[k] + qcten[k] * dt) * rho[k]; L_qc[k] = 1; }
         else { rc[k] = R1; L_qc[k] = 0; }
@@ -727,29 +698,93 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         else { rs[k] = R1; L_qs[k] = 0; }
         if ((qg1d[k] + qgten[k] * dt) > R1) { rg[k] = (qg1d[k] + qgten[k] * dt) * rho[k]; L_qg[k] = 1; }
         else { rg[k] = R1; L_qg[k] = 0; }
-    }
-
-    /* ---- :2325-2374 snow moments again (smob, smo2, smoc, smod) ---- */
-    for (k = kts; k <= kte; ++k) {
-        if (!L_qs[k]) continue;
+            if (L_qs[k]) {
         tc0 = fminf(-0.1f, temp[k] - 273.15f);
         smob[k] = rs[k] * T->oams;
-        if (TH_bm_s > (2.0f - 1.e-3f) && TH_bm_s < (2.0f + 1.e-3f)) smo2[k] = smob[k];
+        if (TH_bm_s > (2.0f - 1.e-3f) && TH_bm_s < (2.0f + 1.e-3f)) smo2 = smob[k];
         else {
             loga_ = snow_poly_f(sa, tc0, TH_bm_s); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, TH_bm_s);
-            smo2[k] = d_powf(smob[k] / a_, 1.f / b_);
+            smo2 = d_powf(smob[k] / a_, 1.f / b_);
         }
         loga_ = snow_poly_f(sa, tc0, T->cse[0]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[0]);
-        smoc[k] = a_ * d_powf(smo2[k], b_);
+        smoc[k] = a_ * d_powf(smo2, b_);
         loga_ = snow_poly_f(sa, tc0, T->cse[13]); a_ = d_powf(10.0f, loga_); b_ = snow_poly_f(sb, tc0, T->cse[13]);
-        smod[k] = a_ * d_powf(smo2[k], b_);
-    }
-
+        smod = a_ * d_powf(smo2, b_);
+            }
+        /* input of the second graupel chain (:2381-2385) must see the TAU+1 state of THIS point in the sequence */
+        xslw_arr[k] = (temp[k] < 270.65f && L_qr[k] && mvd_r[k] > 100.E-6f) ? 4.01f + d_log10f(mvd_r[k]) : 0.01f;
+        lamr = d_powf(am_r * crg[2] * T->org2 * nr[k] / rr[k], T->obmr);
+        ilamr = 1. / lamr;
+        mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
+        N0_r = (double)(nr[k] * T->org2) * pow(lamr, (double)cre[1]);
+            if ((ssatw > eps) || (ssatw < -eps && L_qc[k])) {
+            clap = (qv[k] - qvs) / (1.f + lvt2 * qvs);
+            for (n = 1; n <= 3; ++n) {
+                fcd = qvs * d_expf(lvt2 * clap) - qv[k] + clap;
+                dfcd = qvs * lvt2 * d_expf(lvt2 * clap) + 1.f;
+                clap = clap - fcd / dfcd;
+            }
+            xrc = rc[k] + clap;
+            if (xrc > 0.0f) prw_vcd = clap * odt;
+            else prw_vcd = -rc[k] / rho[k] * odts;
+            qcten[k] = (float)(qcten[k] + prw_vcd);
+            qvten[k] = (float)(qvten[k] - prw_vcd);
+            tten[k] = (float)(tten[k] + (double)(lvap[k] * ocp[k]) * prw_vcd * 1);
+            rc[k] = fmaxf(R1, (qc1d[k] + dt * qcten[k]) * rho[k]);
+            qv[k] = fmaxf(1.E-10f, qv1d[k] + dt * qvten[k]);
+            temp[k] = t1d[k] + dt * tten[k];
+            rho[k] = 0.622f * pres[k] / (TH_RR2 * temp[k] * (qv[k] + 0.622f));
+            qvs = rslf(pres[k], temp[k]);
+            ssatw = qv[k] / qvs - 1.f;
+        }
+            if ((ssatw < -eps) && L_qr[k] && (!(prw_vcd > 0.))) {
+            tempc = temp[k] - 273.15f;
+            otemp = 1.f / temp[k];
+            rhof = sqrtf(TH_rho_not / rho[k]);
+            rhof2 = sqrtf(rhof);
+            diffu = 2.11E-5f * d_powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
+            if (tempc >= 0.0f) visco = (1.718f + 0.0049f * tempc) * 1.0E-5f;
+            else visco = (1.718f + 0.0049f * tempc - 1.2E-5f * tempc * tempc) * 1.0E-5f;
+            vsc2 = sqrtf(rho[k] / visco);
+            lvap[k] = lvap0 + (2106.0f - 4218.0f) * tempc;
+            tcond = (5.69f + 0.0168f * tempc) * 1.0E-5f * 418.936f;
+            ocp[k] = 1.f / (TH_Cp2 * (1.f + 0.887f * qv[k]));
+            rvs = rho[k] * qvs;
+            rvs_p = rvs * otemp * (lvap[k] * otemp * oRv - 1.f);
+            rvs_pp = rvs * (otemp * (lvap[k] * otemp * oRv - 1.f) * otemp * (lvap[k] * otemp * oRv - 1.f)
+                            + (-2.f * lvap[k] * otemp * otemp * otemp * oRv) + otemp * otemp);
+            gamsc = lvap[k] * diffu / tcond * rvs_p;
+            alphsc = 0.5f * (gamsc / (1.f + gamsc)) * (gamsc / (1.f + gamsc)) * rvs_pp / rvs_p * rvs / rvs_p;
+            alphsc = fmaxf(1.E-9f, alphsc);
+            xsat = fminf(-1.E-9f, ssatw);
+            t1_evap = 2.f * PI2 * (1.0f - alphsc * xsat + 2.f * alphsc * alphsc * xsat * xsat
+                                   - 5.f * alphsc * alphsc * alphsc * xsat * xsat * xsat) / (1.f + gamsc);
+            lamr = 1. / ilamr;
+            if (qv[k] / qvs < 0.95f && rr[k] / rho[k] <= 1.E-8f) {
+                prv_rev = rr[k] / rho[k] * odts;
+            } else {
+                prv_rev = (double)(t1_evap * diffu * (-ssatw)) * N0_r * (double)rvs
+                             * ((double)T->t1_qr_ev * pow(ilamr, (double)cre[9])
+                                + (double)(T->t2_qr_ev * vsc2 * rhof2) * pow(lamr + (double)(0.5f * fv_r), -(double)cre[10]));
+                rate_max = fminf((rr[k] / rho[k] * odts), (qvs - qv[k]) * odts);
+                prv_rev = fmin((double)rate_max, prv_rev / (double)rho[k]);
+            }
+            pnr_rev = fmin((double)(nr[k] * 0.99f / rho[k] * odts), prv_rev * (double)nr[k] / (double)rr[k]);
+            qrten[k] = (float)(qrten[k] - prv_rev);
+            qvten[k] = (float)(qvten[k] + prv_rev);
+            nrten[k] = (float)(nrten[k] - pnr_rev);
+            tten[k] = (float)(tten[k] - (double)(lvap[k] * ocp[k]) * prv_rev * 1);
+            rr[k] = fmaxf(R1, (qr1d[k] + dt * qrten[k]) * rho[k]);
+            qv[k] = fmaxf(1.E-10f, qv1d[k] + dt * qvten[k]);
+            nr[k] = fmaxf(R2, (nr1d[k] + dt * nrten[k]) * rho[k]);
+            temp[k] = t1d[k] + dt * tten[k];
+            rho[k] = 0.622f * pres[k] / (TH_RR2 * temp[k] * (qv[k] + 0.622f));
+        }
+        }
     /* ---- :2379-2396 graupel intercept/slope again ---- */
     N0_min = TH_gonv_max;
     for (k = kte; k >= kts; --k) {
-        if (temp[k] < 270.65f && L_qr[k] && mvd_r[k] > 100.E-6f) xslw1 = 4.01f + d_log10f(mvd_r[k]);
-        else xslw1 = 0.01f;
+        xslw1 = xslw_arr[k];
         ygra1 = 4.31f + d_log10f(fmaxf(5.E-5f, rg[k]));
         zans1 = 3.1f + (100.f / (300.f * xslw1 * ygra1 / (10.f / xslw1 + 1.f + 0.25f * ygra1) + 30.f + 10.f * ygra1));
         N0_exp = d_powf(10.f, zans1);
@@ -759,88 +794,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         lam_exp = pow(N0_exp * am_g * cgg[0] / rg[k], (double)T->oge1);
         lamg = lam_exp * d_powf(cgg[2] * T->ogg2 * T->ogg1, T->obmg);
         ilamg[k] = 1. / lamg;
-        N0_g[k] = N0_exp / (cgg[1] * lam_exp) * pow(lamg, (double)cge[1]);
-    }
-    /* ---- :2403-2408 rain ---- */
-    for (k = kte; k >= kts; --k) {
-        lamr = d_powf(am_r * crg[2] * T->org2 * nr[k] / rr[k], T->obmr);
-        ilamr[k] = 1. / lamr;
-        mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
-        N0_r[k] = (double)(nr[k] * T->org2) * pow(lamr, (double)cre[1]);
-    }
-
-    /* ---- :2414-2440 cloud water condensation / evaporation (3 Newton-Raphson iterations) ---- */
-    for (k = kts; k <= kte; ++k) {
-        if ((ssatw[k] > eps) || (ssatw[k] < -eps && L_qc[k])) {
-            clap = (qv[k] - qvs[k]) / (1.f + lvt2[k] * qvs[k]);
-            for (n = 1; n <= 3; ++n) {
-                fcd = qvs[k] * d_expf(lvt2[k] * clap) - qv[k] + clap;
-                dfcd = qvs[k] * lvt2[k] * d_expf(lvt2[k] * clap) + 1.f;
-                clap = clap - fcd / dfcd;
-            }
-            xrc = rc[k] + clap;
-            if (xrc > 0.0f) prw_vcd[k] = clap * odt;
-            else prw_vcd[k] = -rc[k] / rho[k] * odts;
-            qcten[k] = (float)(qcten[k] + prw_vcd[k]);
-            qvten[k] = (float)(qvten[k] - prw_vcd[k]);
-            tten[k] = (float)(tten[k] + (double)(lvap[k] * ocp[k]) * prw_vcd[k] * 1);
-            rc[k] = fmaxf(R1, (qc1d[k] + dt * qcten[k]) * rho[k]);
-            qv[k] = fmaxf(1.E-10f, qv1d[k] + dt * qvten[k]);
-            temp[k] = t1d[k] + dt * tten[k];
-            rho[k] = 0.622f * pres[k] / (TH_RR2 * temp[k] * (qv[k] + 0.622f));
-            qvs[k] = rslf(pres[k], temp[k]);
-            ssatw[k] = qv[k] / qvs[k] - 1.f;
-        }
-    }
-
-    /* ---- :2446-2505 rain evaporation ---- */
-    for (k = kts; k <= kte; ++k) {
-        if ((ssatw[k] < -eps) && L_qr[k] && (!(prw_vcd[k] > 0.))) {
-            tempc = temp[k] - 273.15f;
-            otemp = 1.f / temp[k];
-            rhof[k] = sqrtf(TH_rho_not / rho[k]);
-            rhof2[k] = sqrtf(rhof[k]);
-            diffu[k] = 2.11E-5f * d_powf(temp[k] / 273.15f, 1.94f) * (101325.f / pres[k]);
-            if (tempc >= 0.0f) visco[k] = (1.718f + 0.0049f * tempc) * 1.0E-5f;
-            else visco[k] = (1.718f + 0.0049f * tempc - 1.2E-5f * tempc * tempc) * 1.0E-5f;
-            vsc2[k] = sqrtf(rho[k] / visco[k]);
-            lvap[k] = lvap0 + (2106.0f - 4218.0f) * tempc;
-            tcond[k] = (5.69f + 0.0168f * tempc) * 1.0E-5f * 418.936f;
-            ocp[k] = 1.f / (TH_Cp2 * (1.f + 0.887f * qv[k]));
-            rvs = rho[k] * qvs[k];
-            rvs_p = rvs * otemp * (lvap[k] * otemp * oRv - 1.f);
-            rvs_pp = rvs * (otemp * (lvap[k] * otemp * oRv - 1.f) * otemp * (lvap[k] * otemp * oRv - 1.f)
-                            + (-2.f * lvap[k] * otemp * otemp * otemp * oRv) + otemp * otemp);
-            gamsc = lvap[k] * diffu[k] / tcond[k] * rvs_p;
-            alphsc = 0.5f * (gamsc / (1.f + gamsc)) * (gamsc / (1.f + gamsc)) * rvs_pp / rvs_p * rvs / rvs_p;
-            alphsc = fmaxf(1.E-9f, alphsc);
-            xsat = fminf(-1.E-9f, ssatw[k]);
-            t1_evap = 2.f * PI2 * (1.0f - alphsc * xsat + 2.f * alphsc * alphsc * xsat * xsat
-                                   - 5.f * alphsc * alphsc * alphsc * xsat * xsat * xsat) / (1.f + gamsc);
-            lamr = 1. / ilamr[k];
-            if (qv[k] / qvs[k] < 0.95f && rr[k] / rho[k] <= 1.E-8f) {
-                prv_rev[k] = rr[k] / rho[k] * odts;
-            } else {
-                prv_rev[k] = (double)(t1_evap * diffu[k] * (-ssatw[k])) * N0_r[k] * (double)rvs
-                             * ((double)T->t1_qr_ev * pow(ilamr[k], (double)cre[9])
-                                + (double)(T->t2_qr_ev * vsc2[k] * rhof2[k]) * pow(lamr + (double)(0.5f * fv_r), -(double)cre[10]));
-                rate_max = fminf((rr[k] / rho[k] * odts), (qvs[k] - qv[k]) * odts);
-                prv_rev[k] = fmin((double)rate_max, prv_rev[k] / (double)rho[k]);
-            }
-            pnr_rev[k] = fmin((double)(nr[k] * 0.99f / rho[k] * odts), prv_rev[k] * (double)nr[k] / (double)rr[k]);
-            qrten[k] = (float)(qrten[k] - prv_rev[k]);
-            qvten[k] = (float)(qvten[k] + prv_rev[k]);
-            nrten[k] = (float)(nrten[k] - pnr_rev[k]);
-            tten[k] = (float)(tten[k] - (double)(lvap[k] * ocp[k]) * prv_rev[k] * 1);
-            rr[k] = fmaxf(R1, (qr1d[k] + dt * qrten[k]) * rho[k]);
-            qv[k] = fmaxf(1.E-10f, qv1d[k] + dt * qvten[k]);
-            nr[k] = fmaxf(R2, (nr1d[k] + dt * nrten[k]) * rho[k]);
-            temp[k] = t1d[k] + dt * tten[k];
-            rho[k] = 0.622f * pres[k] / (TH_RR2 * temp[k] * (qv[k] + 0.622f));
-        }
-    }
-
-    /* ---- :2515-2650 terminal fall speeds and sub-step counts ---- */
+    }    /* ---- :2515-2650 terminal fall speeds and sub-step counts ---- */
     nstep = 0;
     for (n = 0; n < 4; ++n) { onstep[n] = 1.0f; ksed1[n] = 0; }
     for (k = kte + 1; k >= kts; --k) { vtrk[k] = 0.f; vtnrk[k] = 0.f; vtik[k] = 0.f; vtnik[k] = 0.f; vtsk[k] = 0.f; vtgk[k] = 0.f; }
@@ -925,7 +879,6 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
     }
     if (ksed1[3] == kte) ksed1[3] = kte - 1;
     if (nstep > 0) onstep[3] = 1.f / (float)nstep;
-
     /* ---- :2660-2770 sedimentation ---- */
     nstep = (int)lroundf(1.f / onstep[0]);
     for (n = 1; n <= nstep; ++n) {
@@ -947,51 +900,50 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
     }
     nstep = (int)lroundf(1.f / onstep[1]);
     for (n = 1; n <= nstep; ++n) {
-        for (k = kte; k >= kts; --k) { sed_i[k] = vtik[k] * ri[k]; sed_n[k] = vtnik[k] * ni[k]; }
+        for (k = kte; k >= kts; --k) { sed_r[k] = vtik[k] * ri[k]; sed_n[k] = vtnik[k] * ni[k]; }
         k = kte;
         odzq = 1.f / dzq[k]; orho = 1.f / rho[k];
-        qiten[k] = qiten[k] - sed_i[k] * odzq * onstep[1] * orho;
+        qiten[k] = qiten[k] - sed_r[k] * odzq * onstep[1] * orho;
         niten[k] = niten[k] - sed_n[k] * odzq * onstep[1] * orho;
-        ri[k] = fmaxf(R1, ri[k] - sed_i[k] * odzq * dt * onstep[1]);
+        ri[k] = fmaxf(R1, ri[k] - sed_r[k] * odzq * dt * onstep[1]);
         ni[k] = fmaxf(R2, ni[k] - sed_n[k] * odzq * dt * onstep[1]);
         for (k = ksed1[1]; k >= kts; --k) {
             odzq = 1.f / dzq[k]; orho = 1.f / rho[k];
-            qiten[k] = qiten[k] + (sed_i[k + 1] - sed_i[k]) * odzq * onstep[1] * orho;
+            qiten[k] = qiten[k] + (sed_r[k + 1] - sed_r[k]) * odzq * onstep[1] * orho;
             niten[k] = niten[k] + (sed_n[k + 1] - sed_n[k]) * odzq * onstep[1] * orho;
-            ri[k] = fmaxf(R1, ri[k] + (sed_i[k + 1] - sed_i[k]) * odzq * dt * onstep[1]);
+            ri[k] = fmaxf(R1, ri[k] + (sed_r[k + 1] - sed_r[k]) * odzq * dt * onstep[1]);
             ni[k] = fmaxf(R2, ni[k] + (sed_n[k + 1] - sed_n[k]) * odzq * dt * onstep[1]);
         }
-        if (ri[kts] > R1 * 10.f) *pptice = *pptice + sed_i[kts] * dt * onstep[1];
+        if (ri[kts] > R1 * 10.f) *pptice = *pptice + sed_r[kts] * dt * onstep[1];
     }
     nstep = (int)lroundf(1.f / onstep[2]);
     for (n = 1; n <= nstep; ++n) {
-        for (k = kte; k >= kts; --k) sed_s[k] = vtsk[k] * rs[k];
+        for (k = kte; k >= kts; --k) sed_r[k] = vtsk[k] * rs[k];
         k = kte;
         odzq = 1.f / dzq[k]; orho = 1.f / rho[k];
-        qsten[k] = qsten[k] - sed_s[k] * odzq * onstep[2] * orho;
-        rs[k] = fmaxf(R1, rs[k] - sed_s[k] * odzq * dt * onstep[2]);
+        qsten[k] = qsten[k] - sed_r[k] * odzq * onstep[2] * orho;
+        rs[k] = fmaxf(R1, rs[k] - sed_r[k] * odzq * dt * onstep[2]);
         for (k = ksed1[2]; k >= kts; --k) {
             odzq = 1.f / dzq[k]; orho = 1.f / rho[k];
-            qsten[k] = qsten[k] + (sed_s[k + 1] - sed_s[k]) * odzq * onstep[2] * orho;
-            rs[k] = fmaxf(R1, rs[k] + (sed_s[k + 1] - sed_s[k]) * odzq * dt * onstep[2]);
+            qsten[k] = qsten[k] + (sed_r[k + 1] - sed_r[k]) * odzq * onstep[2] * orho;
+            rs[k] = fmaxf(R1, rs[k] + (sed_r[k + 1] - sed_r[k]) * odzq * dt * onstep[2]);
         }
-        if (rs[kts] > R1 * 10.f) *pptsnow = *pptsnow + sed_s[kts] * dt * onstep[2];
+        if (rs[kts] > R1 * 10.f) *pptsnow = *pptsnow + sed_r[kts] * dt * onstep[2];
     }
     nstep = (int)lroundf(1.f / onstep[3]);
     for (n = 1; n <= nstep; ++n) {
-        for (k = kte; k >= kts; --k) sed_g[k] = vtgk[k] * rg[k];
+        for (k = kte; k >= kts; --k) sed_r[k] = vtgk[k] * rg[k];
         k = kte;
         odzq = 1.f / dzq[k]; orho = 1.f / rho[k];
-        qgten[k] = qgten[k] - sed_g[k] * odzq * onstep[3] * orho;
-        rg[k] = fmaxf(R1, rg[k] - sed_g[k] * odzq * dt * onstep[3]);
+        qgten[k] = qgten[k] - sed_r[k] * odzq * onstep[3] * orho;
+        rg[k] = fmaxf(R1, rg[k] - sed_r[k] * odzq * dt * onstep[3]);
         for (k = ksed1[3]; k >= kts; --k) {
             odzq = 1.f / dzq[k]; orho = 1.f / rho[k];
-            qgten[k] = qgten[k] + (sed_g[k + 1] - sed_g[k]) * odzq * onstep[3] * orho;
-            rg[k] = fmaxf(R1, rg[k] + (sed_g[k + 1] - sed_g[k]) * odzq * dt * onstep[3]);
+            qgten[k] = qgten[k] + (sed_r[k + 1] - sed_r[k]) * odzq * onstep[3] * orho;
+            rg[k] = fmaxf(R1, rg[k] + (sed_r[k + 1] - sed_r[k]) * odzq * dt * onstep[3]);
         }
-        if (rg[kts] > R1 * 10.f) *pptgraul = *pptgraul + sed_g[kts] * dt * onstep[3];
+        if (rg[kts] > R1 * 10.f) *pptgraul = *pptgraul + sed_r[kts] * dt * onstep[3];
     }
-
     /* ---- :2777-2794 instant melt / freeze ---- */
     for (k = kts; k <= kte; ++k) {
         xri = fmaxf(0.0f, qi1d[k] + qiten[k] * dt);
@@ -1010,7 +962,6 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             tten[k] = tten[k] + lfus2 * ocp[k] * xrc * odt * 1;
         }
     }
-
     /* ---- :2800-2842 apply tendencies ---- */
     for (k = kts; k <= kte; ++k) {
         t1d[k] = t1d[k] + tten[k] * dt;
@@ -1044,9 +995,10 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         qg1d[k] = qg1d[k] + qgten[k] * dt;
         if (qg1d[k] <= R1) qg1d[k] = 0.0f;
     }
-    (void)rgvm; (void)sed_s; (void)sed_g; (void)sed_i; (void)xnc; (void)sump;
+    (void)rgvm; (void)xnc; (void)sump;
 
 }
+
 
 template <int KMAX>
 __global__ void __launch_bounds__(64)
