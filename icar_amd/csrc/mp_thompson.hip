@@ -15,12 +15,21 @@
 #include "ctx.h"
 #include "thompson_state.h"
 #include <cmath>
+#include <cstdlib>
 
 const ThState *icar_thompson_device_state(icar_hip_ctx *c);
 const ThState *icar_thompson_host_state(icar_hip_ctx *c);
 
 namespace {
-__device__ __forceinline__ float d_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+// x**y for the positive bases the scheme uses: exp(y*log(x)) in FP64 (relative error ~1e-14, i.e. the
+// float result is the correctly rounded one with probability 1 - 1e-7); three times cheaper than pow().
+__device__ __forceinline__ double d_pow(double x, double y)
+{
+    if (y == 0.0) return 1.0;
+    if (x > 0.0) return exp(y * log(x));
+    return pow(x, y);                       // 0, negative and NaN bases keep libm semantics
+}
+__device__ __forceinline__ float d_powf(float x, float y) { return (float)d_pow((double)x, (double)y); }
 __device__ __forceinline__ float d_expf(float x) { return (float)exp((double)x); }
 __device__ __forceinline__ float d_log10f(float x) { return (float)log10((double)x); }
 
@@ -209,10 +218,10 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         N0_exp = fmax((double)TH_gonv_min, fmin(N0_exp, (double)TH_gonv_max));
         N0_min = fmin(N0_exp, N0_min);
         N0_exp = N0_min;
-        lam_exp = pow(N0_exp * am_g * cgg[0] / rg[k], (double)T->oge1);
+        lam_exp = d_pow(N0_exp * am_g * cgg[0] / rg[k], (double)T->oge1);
         lamg = lam_exp * d_powf(cgg[2] * T->ogg2 * T->ogg1, T->obmg);
         ilamg[k] = 1. / lamg;
-        N0_g[k] = N0_exp / (cgg[1] * lam_exp) * pow(lamg, (double)cge[1]);
+        N0_g[k] = N0_exp / (cgg[1] * lam_exp) * d_pow(lamg, (double)cge[1]);
     }
     for (k = kts; k <= kte; ++k) {
         double prr_wau = 0, prr_rcw = 0, prr_rcs = 0, prr_rcg = 0, prr_sml = 0, prr_gml = 0, prr_rci = 0, pnr_wau = 0, pnr_rcs = 0, pnr_rcg = 0, pnr_rci = 0, pnr_sml = 0, pnr_gml = 0, pnr_rcr = 0, pnr_rfz = 0, pri_inu = 0, pni_inu = 0, pri_ihm = 0, pni_ihm = 0, pri_wfz = 0, pni_wfz = 0, pri_rfz = 0, pni_rfz = 0, pri_ide = 0, pni_ide = 0, pri_rci = 0, pni_rci = 0, pni_sci = 0, pni_iau = 0, prs_iau = 0, prs_sci = 0, prs_rcs = 0, prs_scw = 0, prs_sde = 0, prs_ihm = 0, prs_ide = 0, prg_scw = 0, prg_rfz = 0, prg_gde = 0, prg_gcw = 0, prg_rci = 0, prg_rcs = 0, prg_rcg = 0, prg_ihm = 0;
@@ -267,7 +276,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         lamr = d_powf(am_r * crg[2] * T->org2 * nr[k] / rr[k], T->obmr);
         ilamr = 1. / lamr;
         mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
-        N0_r = (double)(nr[k] * T->org2) * pow(lamr, (double)cre[1]);
+        N0_r = (double)(nr[k] * T->org2) * d_pow(lamr, (double)cre[1]);
             if (L_qr[k] && mvd_r[k] > D0r) {
             Ef_rr = 2.0f - d_expf(2300.0f * (mvd_r[k] - 1600.0E-6f));
             pnr_rcr = Ef_rr * 4.f * nr[k] * rr[k];
@@ -295,7 +304,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             int ic = (int)(mvd_c * 1.E6f);
             ic = imax(1, imin(ic, NBINS));          /* the reference does not bound this index */
             Ef_rw = (float)T->t_Efrw[(idx - 1) + NBINS * (ic - 1)];
-            prr_rcw = (double)(rhof * T->t1_qr_qc * Ef_rw * rc[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[8]);
+            prr_rcw = (double)(rhof * T->t1_qr_qc * Ef_rw * rc[k]) * N0_r * d_pow(lamr + (double)fv_r, -(double)cre[8]);
             prr_rcw = fmin((double)(rc[k] * odts), prr_rcw);
         }
             }
@@ -313,7 +322,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             idx_r = dec_index_f(rr[k], T->nir2); idx_r = imax(1, imin(idx_r, NTB_R));
             lamr = 1. / ilamr;
             lam_exp = lamr * cube_f(crg[2] * T->org2 * T->org1);
-            N0_exp = (double)(T->org1 * rr[k] / am_r) * pow(lam_exp, (double)cre[0]);
+            N0_exp = (double)(T->org1 * rr[k] / am_r) * d_pow(lam_exp, (double)cre[0]);
             idx_r1 = dec_index_d(N0_exp, T->nir3); idx_r1 = imax(1, imin(idx_r1, NTB_R1));
         } else { idx_r = 1; idx_r1 = NTB_R1; }
         if (rs[k] > T->r_s[0]) { idx_s = dec_index_f(rs[k], T->nis2); idx_s = imax(1, imin(idx_s, NTB_S)); } else idx_s = 1;
@@ -321,7 +330,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             idx_g = dec_index_f(rg[k], T->nig2); idx_g = imax(1, imin(idx_g, NTB_G));
             lamg = 1. / ilamg[k];
             lam_exp = lamg * cube_f(cgg[2] * T->ogg2 * T->ogg1);
-            N0_exp = (double)(T->ogg1 * rg[k] / am_g) * pow(lam_exp, (double)cge[0]);
+            N0_exp = (double)(T->ogg1 * rg[k] / am_g) * d_pow(lam_exp, (double)cge[0]);
             idx_g1 = dec_index_d(N0_exp, T->nig3); idx_g1 = imax(1, imin(idx_g1, NTB_G1));
         } else { idx_g = 1; idx_g1 = NTB_G1; }
 
@@ -352,13 +361,13 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             }
             if (rg[k] >= T->r_g[0] && mvd_c > D0c) {
                 xDg = (float)((double)(bm_g + mu_g + 1.f) * ilamg[k]);
-                vtg = (float)((double)(rhof * av_g * cgg[5] * T->ogg3) * pow(ilamg[k], (double)bv_g));
+                vtg = (float)((double)(rhof * av_g * cgg[5] * T->ogg3) * d_pow(ilamg[k], (double)bv_g));
                 stoke_g = mvd_c * mvd_c * vtg * rho_w / (9.f * visco * xDg);
                 if (xDg > D0g) {
                     if (stoke_g >= 0.4f && stoke_g <= 10.f) Ef_gw = 0.55f * d_log10f(2.51f * stoke_g);
                     else if (stoke_g < 0.4f) Ef_gw = 0.0f;
                     else if (stoke_g > 10.f) Ef_gw = 0.77f;
-                    prg_gcw = (double)(rhof * T->t1_qg_qc * Ef_gw * rc[k]) * N0_g[k] * pow(ilamg[k], (double)cge[8]);
+                    prg_gcw = (double)(rhof * T->t1_qg_qc * Ef_gw * rc[k]) * N0_g[k] * d_pow(ilamg[k], (double)cge[8]);
                 }
             }
         }
@@ -465,8 +474,8 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             }
             if (L_qg[k] && ssati < -eps) {
                 prg_gde = (double)(C_cube * t1_subl * diffu * ssati * rvs) * N0_g[k]
-                             * ((double)T->t1_qg_sd * pow(ilamg[k], (double)cge[9])
-                                + (double)(T->t2_qg_sd * vsc2 * rhof2) * pow(ilamg[k], (double)cge[10]));
+                             * ((double)T->t1_qg_sd * d_pow(ilamg[k], (double)cge[9])
+                                + (double)(T->t2_qg_sd * vsc2 * rhof2) * d_pow(ilamg[k], (double)cge[10]));
                 if (prg_gde < 0.) prg_gde = fmax(fmax((double)(-rg[k] * odts), prg_gde), (double)rate_max);
                 else prg_gde = fmin(prg_gde, (double)rate_max);
             }
@@ -482,10 +491,10 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
                 }
                 if (rr[k] >= T->r_r[0] && mvd_r[k] > 4.f * xDi) {
                     lamr = 1. / ilamr;
-                    pri_rci = (double)(rhof * T->t1_qr_qi * T->Ef_ri * ri[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[8]);
-                    pnr_rci = (double)(rhof * T->t1_qr_qi * T->Ef_ri * ni[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[8]);
+                    pri_rci = (double)(rhof * T->t1_qr_qi * T->Ef_ri * ri[k]) * N0_r * d_pow(lamr + (double)fv_r, -(double)cre[8]);
+                    pnr_rci = (double)(rhof * T->t1_qr_qi * T->Ef_ri * ni[k]) * N0_r * d_pow(lamr + (double)fv_r, -(double)cre[8]);
                     pni_rci = pri_rci * (double)oxmi;
-                    prr_rci = (double)(rhof * T->t2_qr_qi * T->Ef_ri * ni[k]) * N0_r * pow(lamr + (double)fv_r, -(double)cre[7]);
+                    prr_rci = (double)(rhof * T->t2_qr_qi * T->Ef_ri * ni[k]) * N0_r * d_pow(lamr + (double)fv_r, -(double)cre[7]);
                     prr_rci = fmin((double)(rr[k] * odts), prr_rci);
                     prg_rci = pri_rci + prr_rci;
                 }
@@ -523,16 +532,16 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
             }
             if (L_qg[k]) {
                 prr_gml = (double)(tempc * tcond - lvap0 * diffu * delQvs) * N0_g[k]
-                             * ((double)T->t1_qg_me * pow(ilamg[k], (double)cge[9])
-                                + (double)(T->t2_qg_me * rhof2 * vsc2) * pow(ilamg[k], (double)cge[10]));
+                             * ((double)T->t1_qg_me * d_pow(ilamg[k], (double)cge[9])
+                                + (double)(T->t2_qg_me * rhof2 * vsc2) * d_pow(ilamg[k], (double)cge[10]));
                 prr_gml = fmin((double)(rg[k] * odts), fmax(0., prr_gml));
-                pnr_gml = N0_g[k] * (double)cgg[1] * pow(ilamg[k], (double)cge[1]) / (double)rg[k]
+                pnr_gml = N0_g[k] * (double)cgg[1] * d_pow(ilamg[k], (double)cge[1]) / (double)rg[k]
                              * prr_gml * (double)d_powf(10.0f, -1.5f * tempc);
                 if (tempc > 7.5f || rg[k] < 0.005E-3f) pnr_gml = 0.0;
                 if (ssati < 0.f) {
                     prg_gde = (double)(C_cube * t1_subl * diffu * ssati * rvs) * N0_g[k]
-                                 * ((double)T->t1_qg_sd * pow(ilamg[k], (double)cge[9])
-                                    + (double)(T->t2_qg_sd * vsc2 * rhof2) * pow(ilamg[k], (double)cge[10]));
+                                 * ((double)T->t1_qg_sd * d_pow(ilamg[k], (double)cge[9])
+                                    + (double)(T->t2_qg_sd * vsc2 * rhof2) * d_pow(ilamg[k], (double)cge[10]));
                     prg_gde = fmax((double)(-rg[k] * odts), prg_gde);
                 }
             }
@@ -716,7 +725,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         lamr = d_powf(am_r * crg[2] * T->org2 * nr[k] / rr[k], T->obmr);
         ilamr = 1. / lamr;
         mvd_r[k] = (float)((double)(3.0f + mu_r + 0.672f) / lamr);
-        N0_r = (double)(nr[k] * T->org2) * pow(lamr, (double)cre[1]);
+        N0_r = (double)(nr[k] * T->org2) * d_pow(lamr, (double)cre[1]);
             if ((ssatw > eps) || (ssatw < -eps && L_qc[k])) {
             clap = (qv[k] - qvs) / (1.f + lvt2 * qvs);
             for (n = 1; n <= 3; ++n) {
@@ -764,8 +773,8 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
                 prv_rev = rr[k] / rho[k] * odts;
             } else {
                 prv_rev = (double)(t1_evap * diffu * (-ssatw)) * N0_r * (double)rvs
-                             * ((double)T->t1_qr_ev * pow(ilamr, (double)cre[9])
-                                + (double)(T->t2_qr_ev * vsc2 * rhof2) * pow(lamr + (double)(0.5f * fv_r), -(double)cre[10]));
+                             * ((double)T->t1_qr_ev * d_pow(ilamr, (double)cre[9])
+                                + (double)(T->t2_qr_ev * vsc2 * rhof2) * d_pow(lamr + (double)(0.5f * fv_r), -(double)cre[10]));
                 rate_max = fminf((rr[k] / rho[k] * odts), (qvs - qv[k]) * odts);
                 prv_rev = fmin((double)rate_max, prv_rev / (double)rho[k]);
             }
@@ -791,7 +800,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         N0_exp = fmax((double)TH_gonv_min, fmin(N0_exp, (double)TH_gonv_max));
         N0_min = fmin(N0_exp, N0_min);
         N0_exp = N0_min;
-        lam_exp = pow(N0_exp * am_g * cgg[0] / rg[k], (double)T->oge1);
+        lam_exp = d_pow(N0_exp * am_g * cgg[0] / rg[k], (double)T->oge1);
         lamg = lam_exp * d_powf(cgg[2] * T->ogg2 * T->ogg1, T->obmg);
         ilamg[k] = 1. / lamg;
     }    /* ---- :2515-2650 terminal fall speeds and sub-step counts ---- */
@@ -803,9 +812,9 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
         rhof[k] = sqrtf(TH_rho_not / rho[k]);
         if (rr[k] > R1) {
             lamr = d_powf(am_r * crg[2] * T->org2 * nr[k] / rr[k], T->obmr);
-            vtr = (float)((double)(rhof[k] * TH_av_r * crg[5] * T->org3) * pow(lamr, (double)cre[2]) * pow(lamr + (double)fv_r, -(double)cre[5]));
+            vtr = (float)((double)(rhof[k] * TH_av_r * crg[5] * T->org3) * d_pow(lamr, (double)cre[2]) * d_pow(lamr + (double)fv_r, -(double)cre[5]));
             vtrk[k] = vtr;
-            vtr = (float)((double)(rhof[k] * TH_av_r * crg[6] / crg[11]) * pow(lamr, (double)cre[11]) * pow(lamr + (double)fv_r, -(double)cre[6]));
+            vtr = (float)((double)(rhof[k] * TH_av_r * crg[6] / crg[11]) * d_pow(lamr, (double)cre[11]) * d_pow(lamr + (double)fv_r, -(double)cre[6]));
             vtnrk[k] = vtr;
         } else { vtrk[k] = vtrk[k + 1]; vtnrk[k] = vtnrk[k + 1]; }
         if (fmaxf(vtrk[k], vtnrk[k]) > 1.E-3f) {
@@ -868,7 +877,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
     for (k = kte; k >= kts; --k) {
         vtg = 0.f;
         if (rg[k] > R1) {
-            vtg = (float)((double)(rhof[k] * av_g * cgg[5] * T->ogg3) * pow(ilamg[k], (double)bv_g));
+            vtg = (float)((double)(rhof[k] * av_g * cgg[5] * T->ogg3) * d_pow(ilamg[k], (double)bv_g));
             if (temp[k] > T_0) vtgk[k] = fmaxf(vtg, vtrk[k]); else vtgk[k] = vtg;
         } else vtgk[k] = vtgk[k + 1];
         if (vtgk[k] > 1.E-3f) {
@@ -1038,6 +1047,43 @@ k_thompson(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float 
         th[c] = t1d[k] / pii[c];
     }
 }
+
+#include "thompson_lane.inc"
+
+// one column per wave (4 columns per 256-thread block), one level per lane; see thompson_lane.inc
+__global__ void __launch_bounds__(256)
+k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
+                float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
+                float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
+                double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
+                float dt, int i0, int i1, int j0, int k0, int nk)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = i0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = j0 + blockIdx.y;
+    if (i > i1) return;                                   // wave-uniform
+    const int kk = lane < nk ? lane : nk - 1;
+    const int c = d.idx(i, k0 + kk, j);
+    const float pi_ = pii[c];
+    float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
+          qg1d = qg[c], ni1d = ni[c], nr1d = nr[c];
+    float pptrain = 0.f, pptsnow = 0.f, pptgraul = 0.f, pptice = 0.f;
+    th_column_lane(T, lane, nk, dt, dz1d, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d, p1d, pptrain, pptsnow, pptgraul, pptice);
+    if (lane == 0) {
+        const int c2 = i + d.nx * j;
+        const float rainnc = 0.f + pptrain + pptsnow + pptgraul + pptice;
+        const float snownc = 0.f + pptsnow + pptice;
+        const float graupelnc = 0.f + pptgraul;
+        rain_acc[c2] = rain_acc[c2] + rainnc;
+        snow_acc[c2] = snow_acc[c2] + snownc;
+        graupel_acc[c2] = graupel_acc[c2] + graupelnc;
+    }
+    if (lane < nk) {
+        qv[c] = (qv1d < 1.E-7f) ? 1.E-7f : qv1d;          // :997-1010
+        qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
+        th[c] = t1d / pi_;
+    }
+}
 }  // namespace
 
 int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
@@ -1065,7 +1111,13 @@ int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
     dim3 g((i_end - its + 1 + 63) / 64, j_end - jts + 1), b(64);
 #define LAUNCH(K) hipLaunchKernelGGL((k_thompson<K>), g, b, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, \
                                      dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk)
-    if (nk <= 40) LAUNCH(40);
+    static const bool column_per_lane = getenv("ICAR_HIP_THOMPSON_COLUMN_PER_LANE") != nullptr;   // A/B switch for profiling
+    if (nk <= 64 && !column_per_lane) {
+        dim3 gl((i_end - its + 1 + 3) / 4, j_end - jts + 1), bl(256);
+        hipLaunchKernelGGL(k_thompson_lane, gl, bl, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga,
+                           dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk);
+    }
+    else if (nk <= 40) LAUNCH(40);
     else if (nk <= 64) LAUNCH(64);
     else if (nk <= 96) LAUNCH(96);
     else { icar_set_error("thompson: more than 96 levels are not supported by this build"); return 1; }
