@@ -1051,7 +1051,7 @@ k_thompson(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float 
 #include "thompson_lane.inc"
 
 // one column per wave (4 columns per 256-thread block), one level per lane; see thompson_lane.inc
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)   // 4 waves/SIMD (128 VGPRs, 252 B spill) measured best of 2..8: 7.2/6.0/5.6/6.2/6.3/9.2 ms
 k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
