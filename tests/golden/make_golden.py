@@ -34,7 +34,12 @@ CASES = {
                                   vars=["water_vapor"], summary_only=1),
     "mp_simple_40x36x20": dict(kind="mps", nx=40, ny=36, nz=20, hill=1000.0, moist=1.6, cool=0.4, dt=40.0, nsteps=8),
     "mp_simple_snow_30x20x30": dict(kind="mps", nx=30, ny=20, nz=30, hill=500.0, moist=2.5, cool=1.5, dt=60.0, nsteps=8),
+    "thompson_warm_24x12x30": dict(kind="th", nx=24, ny=12, nz=30, hill=1000.0, moist=1.6, cool=1.0, dt=40.0, nsteps=12),
+    "thompson_cold_20x10x40": dict(kind="th", nx=20, ny=10, nz=40, hill=1000.0, moist=2.0, cool=2.0, dt=60.0, nsteps=25),
+    "thompson_longdt_16x8x40": dict(kind="th", nx=16, ny=8, nz=40, hill=1000.0, moist=2.5, cool=3.0, dt=130.0, nsteps=30),
+    "thompson_tables": dict(kind="thtab"),
 }
+TH_KEYS = ["water_vapor", "cloud_water", "rain", "cloud_ice", "snow", "graupel", "ice_number", "rain_number", "potential_temperature"]
 
 
 INPUTS_ADV = ["u", "v", "w", "density", "jacobian", "jacobian_u", "jacobian_v", "jacobian_w", "advection_dz", "dz_levels"]
@@ -71,6 +76,34 @@ def run_case(name):
                 out["in_" + n] = c[n]
         # inputs fingerprint so a drift of icar_amd.ideal is detected rather than silently re-baselined
         out["input_sum"] = np.float64(sum(float(c[n].astype(np.float64).sum()) for n in p["vars"]))
+    elif p["kind"] == "thtab":
+        # the reference's own lookup tables: fingerprints + probed entries (the tables total 85 MB)
+        import hashlib
+        ref.thompson_init(workdir=os.environ.get("ICAR_THOMPSON_CACHE", "/tmp/oracle/run"))
+        out = {}
+        rng = np.random.default_rng(7)
+        for tname in ref.THOMPSON_TABLES:
+            t = ref.thompson_table(tname)
+            idx = np.sort(rng.choice(t.size, size=min(64, t.size), replace=False))
+            out["sha_" + tname] = np.array(hashlib.sha256(t.tobytes()).hexdigest())
+            out["idx_" + tname] = idx; out["val_" + tname] = t[idx]; out["sum_" + tname] = np.float64(t.sum())
+    elif p["kind"] == "th":
+        nx, ny, nz = p["nx"], p["ny"], p["nz"]
+        ref.thompson_init(workdir=os.environ.get("ICAR_THOMPSON_CACHE", "/tmp/oracle/run"))
+        c = ideal.make_case(nx, ny, nz, hill_height=p["hill"], noise=0.01)
+        s = {k: c[k].copy() for k in TH_KEYS + ["exner", "pressure", "dz_mass"]}
+        s["water_vapor"] = (s["water_vapor"] * np.float32(p["moist"])).astype(np.float32)
+        ins = {"in_" + k: s[k].copy() for k in s}
+        acc = {k: np.zeros((ny, nx), np.float32) for k in ("rainnc", "rainncv", "snownc", "graupelnc", "sr")}
+        for _ in range(p["nsteps"]):
+            ref.thompson(s["water_vapor"], s["cloud_water"], s["rain"], s["cloud_ice"], s["snow"], s["graupel"], s["ice_number"],
+                         s["rain_number"], s["potential_temperature"], s["exner"], s["pressure"], s["dz_mass"], p["dt"],
+                         acc["rainnc"], acc["rainncv"], acc["snownc"], acc["graupelnc"], acc["sr"],
+                         1, nx, 1, ny, 1, nz, 2, nx - 1, 2, ny - 1, 1, nz)
+            s["potential_temperature"] -= np.float32(p["cool"])
+        out = {k: s[k] for k in TH_KEYS}
+        out.update({k: acc[k] for k in ("rainnc", "snownc", "graupelnc")})
+        out.update(ins)
     else:
         nx, ny, nz = p["nx"], p["ny"], p["nz"]
         c = ideal.make_case(nx, ny, nz, hill_height=p["hill"], noise=0.01)
