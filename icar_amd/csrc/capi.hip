@@ -23,9 +23,9 @@ static bool field_is_2dd(int f) { return f == ICAR_F_PRECIPITATION || f == ICAR_
 size_t icar_field_count(const icar_hip_ctx *c, int f)
 {
     const size_t nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
-    if (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U) return (nx + 1) * nz * ny;
-    if (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V) return nx * nz * (ny + 1);
-    if (field_is_2dd(f)) return nx * ny;
+    if (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U || f == ICAR_F_DZDX) return (nx + 1) * nz * ny;
+    if (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V || f == ICAR_F_DZDY) return nx * nz * (ny + 1);
+    if (field_is_2dd(f) || f == ICAR_F_SURFACE_PRESSURE) return nx * ny;
     return nx * nz * ny;
 }
 
@@ -279,6 +279,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     drain_timers(c);
     for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->field[f]) hipFree(c->field[f]);
     for (int f = 0; f < ICAR_N_ADVECTABLE; ++f) if (c->alt[f]) hipFree(c->alt[f]);
+    for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->dqdt[f]) hipFree(c->dqdt[f]);
     float *scr[] = {c->U, c->V, c->W, c->Wdz, c->q2, c->u2, c->v2, c->w2, c->d_red};
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
@@ -413,6 +414,35 @@ int icar_hip_max_courant(icar_hip_ctx *c, float dx, const float *dz_levels, floa
     if (!c || !dz_levels || !out) { icar_set_error("max_courant: null argument"); return 1; }
     if (c->d.nz > 4096) { icar_set_error("max_courant: nz too large"); return 1; }
     return icar_max_courant_run(c, dx, dz_levels, out);
+}
+
+int icar_hip_diagnostic_update(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_diagnostic_update_run(c);
+}
+
+int icar_hip_dqdt_upload(icar_hip_ctx *c, int f, const void *host)
+{
+    if (!c || !host) { icar_set_error("dqdt_upload: null argument"); return 1; }
+    if (f < 0 || f >= ICAR_N_FIELDS || field_is_2dd(f)) { icar_set_error("dqdt_upload: bad field"); return 1; }
+    const size_t bytes = icar_field_count(c, f) * sizeof(float);
+    if (!c->dqdt[f]) HIPCHK(hipMalloc(&c->dqdt[f], bytes));
+    HIPCHK(hipMemcpyAsync(c->dqdt[f], host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int icar_hip_apply_forcing(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn)
+{
+    if (!c || (n > 0 && (!fields || !fb))) { icar_set_error("apply_forcing: null argument"); return 1; }
+    return icar_apply_forcing_run(c, dt, fields, fb, n, w, e, s, nn);
+}
+
+int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
+{
+    if (!c || (n > 0 && !fields)) { icar_set_error("enforce_limits: null argument"); return 1; }
+    return icar_enforce_limits_run(c, fields, n);
 }
 
 int icar_hip_balance_uvw(icar_hip_ctx *c, float dx)

@@ -31,6 +31,7 @@ struct icar_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     void *field[ICAR_N_FIELDS] = {nullptr};
+    float *dqdt[ICAR_N_FIELDS] = {nullptr};    // variable_t%dqdt_3d mirrors (apply_forcing)
     // advection scratch (A1-A5)
     float *U = nullptr, *V = nullptr, *W = nullptr, *Wdz = nullptr;
     float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
@@ -69,6 +70,9 @@ int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int
 int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out);
 int icar_balance_uvw_run(icar_hip_ctx *c, float dx);
+int icar_diagnostic_update_run(icar_hip_ctx *c);
+int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);
+int icar_enforce_limits_run(icar_hip_ctx *c, const int *fields, int n);
 int icar_thompson_init_run(icar_hip_ctx *c, const float *params, const int *flags);
 int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
                       int ids, int ide, int jds, int jde, int kds, int kde);

@@ -1,0 +1,164 @@
+// icar_amd/csrc/step.hip -- the streaming kernels that sit between the hot kernels inside step():
+// rows T3 (diagnostic_update, src/main/time_step.f90:49-198) and F1 (apply_forcing / enforce_limits,
+// src/objects/domain_obj.f90:2383-2448, 2228-2243).  All HBM-bound, lanes along i.
+#include "ctx.h"
+#include <cmath>
+
+namespace {
+constexpr float Rd = 287.058f, cp = 1012.0f;     // src/constants/icar_constants.f90:391-393
+
+// (p/po)**(Rd/cp) evaluated in FP64 and rounded once ("Arithmetic")
+__device__ __forceinline__ float exner_function(float pressure)
+{   // atm_utilities.f90:682-691 ; po = 100000 (integer in the reference => p/100000.)
+    return (float)pow((double)(pressure / 100000.0f), (double)(Rd / cp));
+}
+
+__global__ void __launch_bounds__(256)
+k_diag_thermo(Dims d, const float *__restrict__ p, const float *__restrict__ th, float *__restrict__ exner,
+              float *__restrict__ p_i, float *__restrict__ psfc, float *__restrict__ T, float *__restrict__ T_i,
+              float *__restrict__ rho, const float *__restrict__ u, const float *__restrict__ v,
+              float *__restrict__ u_mass, float *__restrict__ v_mass)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
+    if (i >= d.nx || k >= d.nz) return;
+    const int c = d.idx(i, k, j);
+    const float pc = p[c];
+    const float ex = exner_function(pc);
+    exner[c] = ex;
+    const float t = th[c] * ex;                                   // :95
+    if (T) T[c] = t;
+    if (rho) rho[c] = pc / (Rd * t);                               // :101
+    // interface values (:88-98): level kms extrapolates from kms+1, others average with the level below
+    if (p_i || T_i) {
+        float pn, tn;
+        if (k == 0) {
+            const float p1 = p[c + d.sk];
+            const float t1 = th[c + d.sk] * exner_function(p1);
+            pn = pc + (pc - p1) / 2; tn = t + (t - t1) / 2;
+            if (psfc) psfc[i + d.nx * j] = pn;
+        } else {
+            const float pm = p[c - d.sk];
+            const float tm = th[c - d.sk] * exner_function(pm);
+            pn = (pm + pc) / 2; tn = (tm + t) / 2;
+        }
+        if (p_i) p_i[c] = pn;
+        if (T_i) T_i[c] = tn;
+    }
+    if (u_mass) { const int cu = i + (d.nx + 1) * (k + d.nz * j); u_mass[c] = (u[cu + 1] + u[cu]) / 2; }   // :105
+    if (v_mass) v_mass[c] = (v[c + d.sj] + v[c]) / 2;                                                       // :108
+}
+
+// w_real (:165-194): real vertical motion on interior cells, k-sequential through lastw
+__global__ void __launch_bounds__(64)
+k_diag_wreal(Dims d, const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
+             const float *__restrict__ dzdx, const float *__restrict__ dzdy, const float *__restrict__ jaco,
+             float *__restrict__ w_real)
+{
+    const int i = 1 + blockIdx.x * 64 + threadIdx.x, j = 1 + blockIdx.y;
+    if (i >= d.nx - 1) return;
+    float lastw = 0.0f;
+    const int nxu = d.nx + 1;
+    for (int k = 0; k < d.nz; ++k) {
+        const int c = d.idx(i, k, j);
+        const int cu = i + nxu * (k + d.nz * j);
+        const float uw0 = u[cu] * dzdx[cu], uw1 = u[cu + 1] * dzdx[cu + 1];          // uw(i), uw(i+1)
+        const float vw0 = v[c] * dzdy[c], vw1 = v[c + d.sj] * dzdy[c + d.sj];        // vw(j), vw(j+1)
+        const float currw = w[c];
+        w_real[c] = (uw0 + uw1) * 0.5f + (vw0 + vw1) * 0.5f + jaco[c] * (lastw + currw) * 0.5f;
+        lastw = currw;
+    }
+}
+
+struct ForceArgs { float *x[16]; const float *dq[16]; int stag[16]; int fb[16]; };
+
+__global__ void __launch_bounds__(256)
+k_apply_forcing(Dims d, ForceArgs a, double dt, int west, int east, int south, int north)
+{
+    const int m = blockIdx.z;
+    const int nxm = d.nx + (a.stag[m] == 1), nym = d.ny + (a.stag[m] == 2);
+    const size_t n = (size_t)nxm * d.nz * nym;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        bool doit = true;
+        if (a.fb[m]) {          // domain_obj.f90:2411-2423: W/E columns without the corner rows, S/N full rows
+            const int i = (int)(t % nxm), j = (int)(t / ((size_t)nxm * d.nz));
+            doit = (west && i == 0 && j > 0 && j < nym - 1) || (east && i == nxm - 1 && j > 0 && j < nym - 1)
+                || (south && j == 0) || (north && j == nym - 1);
+        }
+        if (doit) a.x[m][t] = (float)((double)a.x[m][t] + ((double)a.dq[m][t] * dt));   // REAL + REAL*REAL(8)
+    }
+}
+
+struct LimitArgs { float *x[16]; };
+__global__ void __launch_bounds__(256)
+k_enforce_limits(size_t n, LimitArgs a)
+{
+    float *x = a.x[blockIdx.y];
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x)
+        if (x[t] < 0) x[t] = 0;
+}
+}  // namespace
+
+int icar_diagnostic_update_run(icar_hip_ctx *c)
+{
+    const float *p = icar_field_f(c, ICAR_F_PRESSURE), *th = icar_field_f(c, ICAR_F_POTENTIAL_TEMPERATURE);
+    if (!p || !th) return 1;
+    float *ex = icar_field_f(c, ICAR_F_EXNER, false), *pi = icar_field_f(c, ICAR_F_PRESSURE_INTERFACE, false);
+    float *ps = icar_field_f(c, ICAR_F_SURFACE_PRESSURE, false), *T = icar_field_f(c, ICAR_F_TEMPERATURE, false);
+    float *Ti = icar_field_f(c, ICAR_F_TEMPERATURE_INTERFACE, false), *rho = icar_field_f(c, ICAR_F_DENSITY, false);
+    if (!ex || !pi || !ps || !T || !Ti || !rho) return 1;
+    const float *u = (const float *)c->field[ICAR_F_U], *v = (const float *)c->field[ICAR_F_V];
+    float *um = u ? icar_field_f(c, ICAR_F_U_MASS, false) : nullptr, *vm = v ? icar_field_f(c, ICAR_F_V_MASS, false) : nullptr;
+    ScopedTimer t(c, "diag");
+    dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
+    hipLaunchKernelGGL(k_diag_thermo, g, b, 0, c->stream, c->d, p, th, ex, pi, ps, T, Ti, rho, u, v, um, vm);
+    const float *w = (const float *)c->field[ICAR_F_W], *dzdx = (const float *)c->field[ICAR_F_DZDX];
+    const float *dzdy = (const float *)c->field[ICAR_F_DZDY], *jaco = (const float *)c->field[ICAR_F_JACOBIAN];
+    if (u && v && w && dzdx && dzdy && jaco) {
+        float *wr = icar_field_f(c, ICAR_F_W_REAL, false);
+        if (!wr) return 1;
+        dim3 g2((c->d.nx - 2 + 63) / 64, c->d.ny - 2), b2(64);
+        hipLaunchKernelGGL(k_diag_wreal, g2, b2, 0, c->stream, c->d, u, v, w, dzdx, dzdy, jaco, wr);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn)
+{
+    if (n <= 0) return 0;
+    if (n > 16) { icar_set_error("apply_forcing: at most 16 fields per call"); return 1; }
+    ForceArgs a;
+    for (int m = 0; m < n; ++m) {
+        const int f = fields[m];
+        if (f < 0 || f >= ICAR_N_FIELDS || f == ICAR_F_PRECIPITATION || f == ICAR_F_SNOWFALL || f == ICAR_F_GRAUPEL_ACC || f == ICAR_F_SURFACE_PRESSURE) {
+            icar_set_error("apply_forcing: only 3-D REAL(4) fields"); return 1;
+        }
+        a.x[m] = icar_field_f(c, f);
+        if (!a.x[m]) return 1;
+        if (!c->dqdt[f]) { icar_set_error("apply_forcing: dqdt of a listed field was never uploaded"); return 1; }
+        a.dq[m] = c->dqdt[f];
+        a.stag[m] = (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U || f == ICAR_F_DZDX) ? 1 : (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V || f == ICAR_F_DZDY) ? 2 : 0;
+        a.fb[m] = fb[m];
+    }
+    ScopedTimer t(c, "forcing");
+    dim3 g(2048, 1, n), b(256);
+    hipLaunchKernelGGL(k_apply_forcing, g, b, 0, c->stream, c->d, a, dt, w, e, s, nn);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int icar_enforce_limits_run(icar_hip_ctx *c, const int *fields, int n)
+{
+    if (n <= 0) return 0;
+    if (n > 16) { icar_set_error("enforce_limits: at most 16 fields per call"); return 1; }
+    LimitArgs a;
+    for (int m = 0; m < n; ++m) {
+        if (fields[m] < 0 || fields[m] >= ICAR_N_ADVECTABLE) { icar_set_error("enforce_limits: advectable scalars only"); return 1; }
+        a.x[m] = icar_field_f(c, fields[m]);
+        if (!a.x[m]) return 1;
+    }
+    dim3 g(2048, n), b(256);
+    hipLaunchKernelGGL(k_enforce_limits, g, b, 0, c->stream, c->n3, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

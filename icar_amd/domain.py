@@ -49,9 +49,9 @@ class domain_t:
             pass
 
     def shape(self, fid):
-        if fid in (F.U, F.JACOBIAN_U): return (self.ny, self.nz, self.nx + 1)
-        if fid in (F.V, F.JACOBIAN_V): return (self.ny + 1, self.nz, self.nx)
-        if fid in F.IS_2DD: return (self.ny, self.nx)
+        if fid in (F.U, F.JACOBIAN_U, F.DZDX): return (self.ny, self.nz, self.nx + 1)
+        if fid in (F.V, F.JACOBIAN_V, F.DZDY): return (self.ny + 1, self.nz, self.nx)
+        if fid in F.IS_2DD or fid == F.SURFACE_PRESSURE: return (self.ny, self.nx)
         return (self.ny, self.nz, self.nx)
 
     @staticmethod
@@ -75,6 +75,32 @@ class domain_t:
         a = np.empty(self.shape(fid), np.float64 if fid in F.IS_2DD else np.float32)
         check(lib().icar_hip_field_download(self.ctx, fid, a.ctypes.data_as(ctypes.c_void_p)), f"download {name}")
         return a
+
+    def set_dqdt(self, name, array):
+        """variable_t%dqdt_3d of a forced variable (same shape as the variable)."""
+        fid = self.fid(name)
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        if a.shape != self.shape(fid):
+            raise ValueError(f"dqdt {name}: shape {a.shape} != {self.shape(fid)}")
+        check(lib().icar_hip_dqdt_upload(self.ctx, fid, a.ctypes.data_as(ctypes.c_void_p)), f"dqdt_upload {name}")
+
+    def apply_forcing(self, dt_seconds, forced):
+        """domain%apply_forcing(dt) (domain_obj.f90:2383-2448). forced = [(name, force_boundaries), ...];
+        include ("w", False) like the reference's separate w update."""
+        ids = (ctypes.c_int * len(forced))(*[self.fid(n) for n, _ in forced])
+        fb = (ctypes.c_int * len(forced))(*[int(bool(b)) for _, b in forced])
+        g = self.grid
+        check(lib().icar_hip_apply_forcing(self.ctx, ctypes.c_double(dt_seconds), ids, fb, len(forced), int(g.west_boundary),
+                                           int(g.east_boundary), int(g.south_boundary), int(g.north_boundary)), "apply_forcing")
+
+    def enforce_limits(self, names):
+        """domain%enforce_limits (domain_obj.f90:2228-2243): clamp negatives to zero."""
+        ids = (ctypes.c_int * len(names))(*[self.fid(n) for n in names])
+        check(lib().icar_hip_enforce_limits(self.ctx, ids, len(names)), "enforce_limits")
+
+    def diagnostic_update(self):
+        """diagnostic_update(domain, options) (time_step.f90:49-198)."""
+        check(lib().icar_hip_diagnostic_update(self.ctx), "diagnostic_update")
 
     def fill(self, name, value):
         check(lib().icar_hip_field_fill(self.ctx, self.fid(name), ctypes.c_double(value)), f"fill {name}")

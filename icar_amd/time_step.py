@@ -27,21 +27,30 @@ def update_dt(domain, options, group=None, device=None):
     return min(seconds, 120.0)
 
 
-def step(domain, end_time, options, group=None, device=None):
-    """time_step.f90:440-551 for configurations 1-4 (rad/lsm/pbl/cu off): the operator-split loop
-         update_dt -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect.
-    diagnostic_update / apply_forcing are the rank-1 "next" row of SURVEY.md 8(f)."""
+def step(domain, end_time, options, group=None, device=None, forced=None, diagnostics=True):
+    """time_step.f90:440-551 for configurations 1-4 (rad/lsm/pbl/cu are no-ops there): the operator-split loop
+         update_dt -> diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
+         -> advect -> apply_forcing -> enforce_limits (last two sub-steps).
+    forced = [(member, force_boundaries), ...] with uploaded dqdt (domain.set_dqdt); None skips apply_forcing."""
+    from .constants import ADVECTION_ORDER
     nsteps = 0
     while domain.model_time_seconds < end_time:
         dt = update_dt(domain, options, group=group, device=device)
         if domain.model_time_seconds + dt > end_time:          # :469-471
             dt = end_time - domain.model_time_seconds
+        if diagnostics:
+            domain.diagnostic_update()                         # :474
         if dt > 1e-3:                                          # :483
             mp(domain, options, dt, halo=1)                    # :512
             domain.halo_send()                                 # :515
             mp(domain, options, dt, subset=1)                  # :523
             domain.halo_retrieve()                             # :526
             advect(domain, options, dt)                        # :529
+            if forced:
+                domain.apply_forcing(dt, forced)               # :534
+            if (end_time - domain.model_time_seconds) < dt * 2:    # :537-539
+                names = [n for n in ADVECTION_ORDER if options.vars_to_advect.get(n, 0) > 0]
+                domain.enforce_limits(names)
         domain.model_time_seconds += dt                        # :547
         nsteps += 1
     return nsteps

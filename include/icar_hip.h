@@ -58,7 +58,17 @@ enum icar_hip_field {
     ICAR_F_PRECIPITATION = 23,     /* domain%accumulated_precipitation%data_2dd  REAL(8) (nx,ny) */
     ICAR_F_SNOWFALL = 24,          /* domain%accumulated_snowfall%data_2dd       REAL(8) (nx,ny) */
     ICAR_F_GRAUPEL_ACC = 25,       /* domain%graupel%data_2dd                    REAL(8) (nx,ny) */
-    ICAR_N_FIELDS = 26
+    /* diagnostic_update outputs / inputs (src/main/time_step.f90:49-198) */
+    ICAR_F_PRESSURE_INTERFACE = 26,
+    ICAR_F_TEMPERATURE = 27,
+    ICAR_F_TEMPERATURE_INTERFACE = 28,
+    ICAR_F_U_MASS = 29,
+    ICAR_F_V_MASS = 30,
+    ICAR_F_W_REAL = 31,
+    ICAR_F_DZDX = 32,              /* domain%dzdx  (nx+1, nz, ny)           */
+    ICAR_F_DZDY = 33,              /* domain%dzdy  (nx, nz, ny+1)           */
+    ICAR_F_SURFACE_PRESSURE = 34,  /* domain%surface_pressure%data_2d  REAL(4) (nx,ny) */
+    ICAR_N_FIELDS = 35
 };
 
 enum { ICAR_ADV_UPWIND = 1, ICAR_ADV_MPDATA = 2 };   /* kADV_UPWIND / kADV_MPDATA, icar_constants.f90:341 */
@@ -125,6 +135,22 @@ int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, 
 /* ---- T2: CFL reduction for compute_dt (src/main/time_step.f90:217-330, cfl_strictness 3) -----
  * out = max over the tile of max(|u_i|,|u_i+1|)/dx + max(|v_j|,|v_j+1|)/dx + max(|w_k|,|w_k-1|)/dz_levels(k) */
 int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, float *out);
+
+/* ---- T3: diagnostic_update (src/main/time_step.f90:49-198) ------------------------------------
+ * exner=(p/1e5)^(Rd/cp), interface pressure/temperature, surface pressure, T=theta*exner,
+ * rho=p/(Rd T), u_mass, v_mass, w_real (uses DZDX, DZDY, JACOBIAN).  The optional column integrals
+ * (ivt/iwv/iwl/iwi) and 10 m winds are "not associated" here. */
+int icar_hip_diagnostic_update(icar_hip_ctx *ctx);
+
+/* ---- F1: apply_forcing / enforce_limits (src/objects/domain_obj.f90:2383-2448, 2228-2243) ----
+ * dqdt mirrors variable_t%dqdt_3d.  For each listed field: force_boundaries[i]!=0 -> only the true
+ * domain edges named by the west/east/south/north flags (W/E columns without corners, S/N full
+ * rows) get  x += dqdt*dt ; otherwise the whole field does (u, v, w, pressure ...).  dt is REAL(8)
+ * like time_delta_t%seconds(). */
+int icar_hip_dqdt_upload(icar_hip_ctx *ctx, int field, const void *host);
+int icar_hip_apply_forcing(icar_hip_ctx *ctx, double dt_seconds, const int *fields, const int *force_boundaries, int nfields,
+                           int west_boundary, int east_boundary, int south_boundary, int north_boundary);
+int icar_hip_enforce_limits(icar_hip_ctx *ctx, const int *fields, int nfields);
 
 /* ---- W1: balance_uvw (src/physics/wind.f90:81-169): w from the horizontal divergence ---------- */
 int icar_hip_balance_uvw(icar_hip_ctx *ctx, float dx);

@@ -101,3 +101,38 @@ def thompson(qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, dt, rainnc, rainncv
     lib().orc_thompson(_i(nx), _i(nz), _i(ny), _p(qv), _p(qc), _p(qr), _p(qi), _p(qs), _p(qg), _p(ni), _p(nr), _p(th),
                        _p(pii), _p(p), _p(dz), _f(dt), _p(rainnc), _p(rainncv), _p(snownc), _p(graupelnc), _p(sr),
                        *[_i(x) for x in (ids, ide, jds, jde, kds, kde, its, ite, jts, jte, kts, kte)])
+
+
+def diagnostic_update(p, th, u, v, w, dzdx, dzdy, jaco):
+    ny, nz, nx = p.shape
+    out = {k: np.zeros((ny, nz, nx), np.float32) for k in ("exner", "pressure_interface", "temperature", "temperature_interface",
+                                                          "density", "u_mass", "v_mass", "w_real")}
+    out["surface_pressure"] = np.zeros((ny, nx), np.float32)
+    lib().orc_diagnostic_update(_i(nx), _i(nz), _i(ny), _p(p), _p(th), _p(u), _p(v), _p(w), _p(dzdx), _p(dzdy), _p(jaco),
+                                _p(out["exner"]), _p(out["pressure_interface"]), _p(out["surface_pressure"]), _p(out["temperature"]),
+                                _p(out["temperature_interface"]), _p(out["density"]), _p(out["u_mass"]), _p(out["v_mass"]), _p(out["w_real"]))
+    return out
+
+
+def apply_forcing(x, dqdt, dt, force_boundaries, west, east, south, north):
+    nym, nz, nxm = x.shape
+    lib().orc_apply_forcing(_i(nxm), _i(nz), _i(nym), _p(x), _p(dqdt), ctypes.c_double(dt), _i(force_boundaries),
+                            _i(west), _i(east), _i(south), _i(north))
+
+
+def enforce_limits(x):
+    lib().orc_enforce_limits(ctypes.c_size_t(x.size), _p(x))
+
+
+def balance_uvw(u, v, ju, jv, jw, dz, dx):
+    ny, nz, nx = jw.shape
+    w = np.zeros((ny, nz, nx), np.float32)
+    lib().orc_balance_uvw(_i(nx), _i(nz), _i(ny), _p(u), _p(v), _p(w), _p(ju), _p(jv), _p(jw), _p(dz), _f(dx))
+    return w
+
+
+def max_courant(u, v, w, dz_levels, dx):
+    ny, nz, nx = w.shape
+    fn = lib().orc_max_courant
+    fn.restype = ctypes.c_float
+    return float(fn(_i(nx), _i(nz), _i(ny), _p(u), _p(v), _p(w), _p(np.ascontiguousarray(dz_levels, np.float32)), _f(dx)))

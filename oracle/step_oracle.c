@@ -1,0 +1,104 @@
+/* oracle/step_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT.
+ * CPU restatement of the streaming rows between the hot kernels of step():
+ *   diagnostic_update   src/main/time_step.f90:49-198
+ *   apply_forcing       src/objects/domain_obj.f90:2383-2448
+ *   enforce_limits      src/objects/domain_obj.f90:2228-2243
+ *   balance_uvw         src/physics/wind.f90:81-169 (+ calc_divergence :172-228)
+ *   compute_dt (3)      src/main/time_step.f90:264-289
+ * PARITY UNPINNED by execution: these procedures live in NetCDF/coarray-dependent units
+ * (domain_obj.f90, time_step.f90, wind.f90) that cannot be compiled in this image; the code below is
+ * restated from the source statement by statement.
+ */
+#include <math.h>
+#include <stddef.h>
+#define IDX(i,k,j) ((size_t)(i) + (size_t)nx*((size_t)(k) + (size_t)nz*(size_t)(j)))
+#define IDXU(i,k,j) ((size_t)(i) + (size_t)(nx+1)*((size_t)(k) + (size_t)nz*(size_t)(j)))
+
+extern int g_math_mode;
+static inline float st_powf(float x, float y) { return g_math_mode ? (float)pow((double)x, (double)y) : powf(x, y); }
+static const float Rd = 287.058f, cp = 1012.0f;
+
+void orc_diagnostic_update(int nx, int nz, int ny, const float *p, const float *th, const float *u, const float *v, const float *w,
+                           const float *dzdx, const float *dzdy, const float *jaco,
+                           float *exner, float *p_i, float *psfc, float *T, float *T_i, float *rho, float *u_mass, float *v_mass, float *w_real)
+{
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) for (int i = 0; i < nx; ++i) {
+        const size_t c = IDX(i, k, j);
+        exner[c] = st_powf(p[c] / 100000.0f, Rd / cp);          /* atm_utilities.f90:682-691 */
+        T[c] = th[c] * exner[c];
+    }
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) for (int i = 0; i < nx; ++i) {
+        const size_t c = IDX(i, k, j);
+        if (k == 0) {
+            p_i[c] = p[c] + (p[c] - p[IDX(i, 1, j)]) / 2;
+            T_i[c] = T[c] + (T[c] - T[IDX(i, 1, j)]) / 2;
+            psfc[i + (size_t)nx * j] = p_i[c];
+        } else {
+            p_i[c] = (p[IDX(i, k - 1, j)] + p[c]) / 2;
+            T_i[c] = (T[IDX(i, k - 1, j)] + T[c]) / 2;
+        }
+        rho[c] = p[c] / (Rd * T[c]);
+        u_mass[c] = (u[IDXU(i + 1, k, j)] + u[IDXU(i, k, j)]) / 2;
+        v_mass[c] = (v[IDX(i, k, j + 1)] + v[c]) / 2;
+    }
+    for (int j = 1; j < ny - 1; ++j) for (int i = 1; i < nx - 1; ++i) {
+        float lastw = 0;
+        for (int k = 0; k < nz; ++k) {
+            const size_t c = IDX(i, k, j);
+            const float uw0 = u[IDXU(i, k, j)] * dzdx[IDXU(i, k, j)], uw1 = u[IDXU(i + 1, k, j)] * dzdx[IDXU(i + 1, k, j)];
+            const float vw0 = v[c] * dzdy[c], vw1 = v[IDX(i, k, j + 1)] * dzdy[IDX(i, k, j + 1)];
+            const float currw = w[c];
+            w_real[c] = (uw0 + uw1) * 0.5f + (vw0 + vw1) * 0.5f + jaco[c] * (lastw + currw) * 0.5f;
+            lastw = currw;
+        }
+    }
+}
+
+/* x has extents (nxm, nz, nym) (staggered fields pass their own extents) */
+void orc_apply_forcing(int nxm, int nz, int nym, float *x, const float *dqdt, double dt, int force_boundaries,
+                       int west, int east, int south, int north)
+{
+    for (int j = 0; j < nym; ++j) for (int k = 0; k < nz; ++k) for (int i = 0; i < nxm; ++i) {
+        const size_t c = (size_t)i + (size_t)nxm * ((size_t)k + (size_t)nz * j);
+        int doit = 1;
+        if (force_boundaries)
+            doit = (west && i == 0 && j > 0 && j < nym - 1) || (east && i == nxm - 1 && j > 0 && j < nym - 1)
+                || (south && j == 0) || (north && j == nym - 1);
+        if (doit) x[c] = (float)((double)x[c] + ((double)dqdt[c] * dt));
+    }
+}
+
+void orc_enforce_limits(size_t n, float *x) { for (size_t c = 0; c < n; ++c) if (x[c] < 0) x[c] = 0; }
+
+void orc_balance_uvw(int nx, int nz, int ny, const float *u, const float *v, float *w, const float *ju, const float *jv,
+                     const float *jw, const float *dz, float dx)
+{
+    for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+        float wprev = 0, jwprev = 0;
+        for (int k = 0; k < nz; ++k) {
+            const size_t c = IDX(i, k, j);
+            const float du = u[IDXU(i + 1, k, j)] * ju[IDXU(i + 1, k, j)] - u[IDXU(i, k, j)] * ju[IDXU(i, k, j)];
+            const float dv = v[IDX(i, k, j + 1)] * jv[IDX(i, k, j + 1)] - v[c] * jv[c];
+            const float div = (du + dv) / dx;
+            float wk;
+            if (k == 0) wk = 0 - div * dz[c] / jw[c];
+            else wk = (wprev * jwprev - div * dz[c]) / jw[c];
+            w[c] = wk; wprev = wk; jwprev = jw[c];
+        }
+    }
+}
+
+float orc_max_courant(int nx, int nz, int ny, const float *u, const float *v, const float *w, const float *dzl, float dx)
+{
+    float m = 0;
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) {
+        const int zo = (k == 0) ? 0 : -1;
+        for (int i = 0; i < nx; ++i) {
+            const float cur = fmaxf(fabsf(u[IDXU(i, k, j)]), fabsf(u[IDXU(i + 1, k, j)])) / dx
+                            + fmaxf(fabsf(v[IDX(i, k, j)]), fabsf(v[IDX(i, k, j + 1)])) / dx
+                            + fmaxf(fabsf(w[IDX(i, k, j)]), fabsf(w[IDX(i, k + zo, j)])) / dzl[k];
+            m = fmaxf(m, cur);
+        }
+    }
+    return m;
+}

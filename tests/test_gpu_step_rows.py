@@ -1,0 +1,93 @@
+"""Rows T2, T3, F1, W1 on the GPU vs the CPU oracle (oracle/step_oracle.c), through the C ABI.
+FP32 streaming arithmetic in the reference's order => bit-exact (exner's pow is compared in the oracle's
+device-math mode, and within 1 ulp of the libm mode)."""
+import ctypes
+import numpy as np
+import pytest
+from icar_amd import ideal
+from icar_amd.capi import lib, check
+from icar_amd.options import options_t
+from icar_amd.time_step import compute_dt
+from util import single_image_domain, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def case(nx=70, ny=33, nz=14, seed=3):
+    c = ideal.make_case(nx, ny, nz, hill_height=900.0, noise=0.02, seed=seed)
+    rng = np.random.default_rng(seed)
+    c["u"] = (c["u"] + rng.standard_normal(c["u"].shape).astype(np.float32)).astype(np.float32)
+    c["v"] = (c["v"] + rng.standard_normal(c["v"].shape).astype(np.float32)).astype(np.float32)
+    c["dzdx"] = (0.05 * rng.standard_normal(c["u"].shape)).astype(np.float32)
+    c["dzdy"] = (0.05 * rng.standard_normal(c["v"].shape)).astype(np.float32)
+    return c
+
+
+def test_diagnostic_update(oracle):
+    c = case()
+    d = single_image_domain(c)
+    d.diagnostic_update()
+    oracle.set_math_mode(1)
+    try:
+        ref = oracle.diagnostic_update(c["pressure"], c["potential_temperature"], c["u"], c["v"], c["w"], c["dzdx"], c["dzdy"], c["jacobian"])
+    finally:
+        oracle.set_math_mode(0)
+    ref0 = oracle.diagnostic_update(c["pressure"], c["potential_temperature"], c["u"], c["v"], c["w"], c["dzdx"], c["dzdy"], c["jacobian"])
+    for k, want in ref.items():
+        got = d.get(k)
+        if k == "w_real":       # only interior cells are defined (time_step.f90:190)
+            got, want, w0 = got[1:-1, :, 1:-1], want[1:-1, :, 1:-1], ref0[k][1:-1, :, 1:-1]
+        else:
+            w0 = ref0[k]
+        assert bits_equal(got, want), f"{k}: {(got != want).sum()} differ"
+        np.testing.assert_allclose(got, w0, rtol=2e-7, atol=0)
+    d.close()
+
+
+def test_apply_forcing_and_enforce_limits(oracle):
+    c = case(40, 22, 9)
+    rng = np.random.default_rng(11)
+    for img, nimg in ((1, 1), (2, 4)):
+        from icar_amd.grid import grid_t
+        from icar_amd.domain import domain_t
+        g = grid_t().set_grid_dimensions(40, 22, 9, nimg, img) if nimg == 1 else grid_t().set_grid_dimensions(78, 42, 9, nimg, img)
+        nx, ny = g.ime - g.ims + 1, g.jme - g.jms + 1
+        cc = ideal.make_case(nx, ny, 9, hill_height=300.0, noise=0.02)
+        d = domain_t(g, device=0); d.load_case(cc)
+        dq = {n: (1e-3 * rng.standard_normal(d.shape(d.fid(n)))).astype(np.float32) * np.float32(np.abs(cc[k]).max())
+              for n, k in (("water_vapor", "water_vapor"), ("potential_temperature", "potential_temperature"), ("u", "u"), ("w", "w"), ("pressure", "pressure"))}
+        dq["w"] = (1e-3 * rng.standard_normal(cc["w"].shape)).astype(np.float32)
+        for n, a in dq.items():
+            d.set_dqdt(n, a)
+        forced = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("pressure", False), ("w", False)]
+        dt = 37.123456789
+        d.apply_forcing(dt, forced)
+        for n, fb in forced:
+            want = cc[n].copy()
+            oracle.apply_forcing(want, dq[n], dt, int(fb), int(g.west_boundary), int(g.east_boundary), int(g.south_boundary), int(g.north_boundary))
+            got = d.get(n)
+            assert bits_equal(got, want), (n, img)
+            assert (got != cc[n]).any()
+            if fb and nimg > 1:   # interior tile edges must not be forced
+                if not g.west_boundary: assert bits_equal(got[1:-1, :, 0], cc[n][1:-1, :, 0])
+                if not g.south_boundary: assert bits_equal(got[0, :, 1:-1], cc[n][0, :, 1:-1])
+        # enforce_limits
+        neg = cc["water_vapor"].copy(); neg[::3, ::2, ::5] *= -1
+        d.set("water_vapor", neg); d.enforce_limits(["water_vapor", "potential_temperature"])
+        want = neg.copy(); oracle.enforce_limits(want)
+        assert bits_equal(d.get("water_vapor"), want) and want.min() == 0
+        d.close()
+
+
+def test_balance_uvw_and_compute_dt(oracle):
+    c = case(66, 30, 12, seed=5)
+    d = single_image_domain(c)
+    check(lib().icar_hip_balance_uvw(d.ctx, ctypes.c_float(float(c["dx"]))), "balance_uvw")
+    w = d.get("w")
+    want = oracle.balance_uvw(c["u"], c["v"], c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], float(c["dx"]))
+    assert bits_equal(w, want) and np.abs(want).max() > 0
+    opt = options_t(); opt.parameters.dz_levels = c["dz_levels"]
+    dt = compute_dt(d, opt)
+    m = oracle.max_courant(c["u"], c["v"], w, c["dz_levels"], float(c["dx"]))
+    assert dt == float(np.float32(0.9) / np.float32(m))
+    d.close()
