@@ -359,6 +359,123 @@ k_mpdata_final(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// A4+A2 fused, second generation: every limited face is computed ONCE.
+//   x : lane computes its LEFT face, the right face comes from lane+1 by a wave shuffle; tiles
+//       overlap by one cell (63 outputs per 64 lanes) so no lane needs a second evaluation;
+//   z : a wave computes its BOTTOM face, the top face comes from the wave above through LDS; k-chunks
+//       overlap by one level (7 outputs per 8 waves);
+//   y : each thread marches FJB rows; the north face of row j is the south face of row j+1 and the
+//       j-direction neighbourhoods (q1, l, v2) roll through registers.
+// ------------------------------------------------------------------------------------------------
+#define FBY 8
+#define FJB 8
+template <bool RHO, bool FCT>
+__global__ void __launch_bounds__(64 * FBY)
+k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
+                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
+{
+    __shared__ float s_wb[FBY][64];
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    const int i = 1 + blockIdx.x * 63 + lane;
+    const int k = blockIdx.y * (FBY - 1) + ty;
+    const int j0 = 1 + blockIdx.z * FJB;
+    const int j1 = min(j0 + FJB - 1, d.ny - 2);
+    const int sk = d.sk, sj = d.sj;
+    const bool in_i = (i <= d.nx - 1), in_k = (k <= d.nz - 1);
+    const bool valid = in_i && in_k;
+    const bool wave_out = in_k && (ty <= FBY - 2 || k == d.nz - 1);          // wave-uniform
+    const bool do_out = wave_out && (lane <= 62) && (i <= d.nx - 2);
+    const bool bottom = (k == 0), top = (k == d.nz - 1);
+    const int ic = in_i ? i : d.nx - 1, kc = in_k ? k : d.nz - 1;            // clamped => all loads stay in bounds
+    const int cb = d.idx(ic, kc, 0);
+    for (int m = 0; m < nv; ++m) {
+        const float *__restrict__ q = q1in.p[m];
+        const float *__restrict__ l = qold.p[m];
+        const float *__restrict__ u2 = u2i.p[m];
+        const float *__restrict__ v2 = v2i.p[m];
+        const float *__restrict__ w2 = w2i.p[m];
+        // rolling y neighbourhood around row j: cells j-2..j+2, faces (j-1|j),(j|j+1),(j+1|j+2)
+        float qm2 = 0, qm1, q0, qp1, qp2 = 0, lm2 = 0, lm1, l0, lp1, lp2 = 0, vm1 = 0, v0, vp1, vp2 = 0;
+        float VS = 0, VN = 0;
+        {
+            const int c = cb + j0 * sj;
+            qm1 = q[c - sj]; q0 = q[c]; qp1 = q[c + sj]; lm1 = l[c - sj]; l0 = l[c]; lp1 = l[c + sj];
+            v0 = v2[c]; vp1 = v2[c + sj];
+            if (j0 - 2 >= 0) { qm2 = q[c - 2 * sj]; lm2 = l[c - 2 * sj]; vm1 = v2[c - sj]; }
+            if (FCT) VS = fct_limit(qm2, qm1, q0, qp1, lm2, lm1, l0, lp1, vm1, v0, vp1, j0 - 1 == 0, false, false);
+            else VS = v0;
+        }
+        for (int j = j0; j <= j1; ++j) {
+            const int c = cb + j * sj;
+            const bool lastn = (j + 1 == d.ny - 1);
+            // ---- all loads of this row up front, unconditional (clamped offsets) so they overlap ----
+            const int oj2 = lastn ? sj : 2 * sj;
+            qp2 = q[c + oj2]; lp2 = l[c + oj2]; vp2 = v2[c + oj2];
+            const bool xfirst = (ic - 1 == 0), xlast = (ic == d.nx - 1);
+            const int oxm = xfirst ? -1 : -2, oxp = xlast ? 0 : 1;
+            const float qxm2 = q[c + oxm], qxm1 = q[c - 1], qxp1 = q[c + oxp];
+            const float lxm2 = l[c + oxm], lxm1 = l[c - 1], lxp1 = l[c + oxp];
+            const float uxm = u2[c + (xfirst ? 0 : -1)], ux0 = u2[c], uxp = u2[c + oxp];
+            // z: face (k-1|k); cells k-2,k-1,k,k+1 ; faces stored at the lower cell
+            const bool zfirst = (kc - 1 <= 0), zlast = (kc == d.nz - 1);
+            const int ozm1 = bottom ? 0 : -sk, ozm2 = (kc >= 2) ? -2 * sk : ozm1, ozp = zlast ? 0 : sk;
+            const float qzm2 = q[c + ozm2], qzm1 = q[c + ozm1], qzp1 = q[c + ozp];
+            const float lzm2 = l[c + ozm2], lzm1 = l[c + ozm1], lzp1 = l[c + ozp];
+            const float wzm = w2[c + ozm2], wz0 = w2[c + ozm1], wzp = w2[c];
+            float UL = 0, WB = 0;
+            if (FCT) {
+                if (wave_out) {
+                    VN = fct_limit(qm1, q0, qp1, qp2, lm1, l0, lp1, lp2, v0, vp1, vp2, false, lastn, false);
+                    UL = fct_limit(qxm2, qxm1, q0, qxp1, lxm2, lxm1, l0, lxp1, uxm, ux0, uxp, xfirst, xlast, false);
+                }
+                if (!bottom) WB = fct_limit(qzm2, qzm1, q0, qzp1, lzm2, lzm1, l0, lzp1, wzm, wz0, wzp, zfirst, zlast, true);
+            } else {
+                VN = vp1; UL = ux0;
+                if (!bottom) WB = wz0;
+            }
+            const float UR = __shfl_down(UL, 1);
+            s_wb[ty][lane] = WB;
+            __syncthreads();
+            const float WT = (top || ty == FBY - 1) ? 0.0f : s_wb[ty + 1][lane];
+            __syncthreads();
+            if (do_out) {
+                const float r = RHO ? rho[c] : 1.0f;
+                const float ja = jaco[c];
+                const float den_h = ja * r;
+                const float den_v = dz[c] * ja * r;
+                const float f1r = flux1(q0, qxp1, UR);
+                const float f1l = flux1(qxm1, q0, UL);
+                const float f3 = flux1(q0, qp1, VN);
+                const float f4 = flux1(qm1, q0, VS);
+                float qq = q0 - ((f1r - f1l) + (f3 - f4)) / den_h;
+                if (bottom) qq = qq - flux1(q0, qzp1, WT) / den_v;
+                else if (top) qq = qq - (q0 * WT - flux1(qzm1, q0, WB)) / den_v;
+                else qq = qq - (flux1(q0, qzp1, WT) - flux1(qzm1, q0, WB)) / den_v;
+                out.p[m][c] = qq;
+            }
+            qm2 = qm1; qm1 = q0; q0 = qp1; qp1 = qp2; lm2 = lm1; lm1 = l0; l0 = lp1; lp1 = lp2;
+            vm1 = v0; v0 = vp1; vp1 = vp2; VS = VN;
+        }
+    }
+}
+
+// boundary ring of the new field := field after pass 1 (== field before the step), adv_mpdata.f90:63-65
+__global__ void __launch_bounds__(256)
+k_copy_ring(Dims d, CVarPtrs in, VarPtrs out, int nv)
+{
+    // ring cells: j in {0, ny-1} (full rows) and i in {0, nx-1}
+    const int nrow = 2 * d.nx * d.nz, ncol = 2 * d.nz * (d.ny - 2);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrow + ncol) return;
+    int i, k, j;
+    if (t < nrow) { i = t % d.nx; k = (t / d.nx) % d.nz; j = (t / (d.nx * d.nz)) ? d.ny - 1 : 0; }
+    else { const int s = t - nrow; k = s % d.nz; j = 1 + (s / d.nz) % (d.ny - 2); i = (s / (d.nz * (d.ny - 2))) ? d.nx - 1 : 0; }
+    const int c = d.idx(i, k, j);
+    for (int m = 0; m < nv; ++m) out.p[m][c] = in.p[m][c];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -452,7 +569,12 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
         if (advect_density) hipLaunchKernelGGL((k_mpdata_fluxes<true>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz);
         else                hipLaunchKernelGGL((k_mpdata_fluxes<false>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz);
         // limiter (l = q, q1 = q2) fused into the donor-cell pass q2 -> alt ; then q := alt
-#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final<R, F>), g, b, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz)
+        {
+            const int nring = 2 * c->d.nx * c->d.nz + 2 * c->d.nz * (c->d.ny - 2);
+            hipLaunchKernelGGL(k_copy_ring, dim3((nring + 255) / 256), dim3(256), 0, c->stream, c->d, q2c, alt, n);
+        }
+        const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + FJB - 1) / FJB), bf(64, FBY);
+#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final2<R, F>), gf, bf, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz)
         if (advect_density) { if (fct) FINAL(true, true); else FINAL(true, false); }
         else                { if (fct) FINAL(false, true); else FINAL(false, false); }
 #undef FINAL
