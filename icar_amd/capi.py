@@ -22,7 +22,21 @@ SYMBOLS = [
     "icar_hip_apply_forcing", "icar_hip_enforce_limits", "icar_hip_halo_count", "icar_hip_halo_pack",
     "icar_hip_halo_unpack", "icar_hip_timing_enable", "icar_hip_timing_read", "icar_hip_timing_reset",
     "icar_hip_last_error", "icar_hip_version",
+    "icar_hip_linwinds_setup", "icar_hip_linwinds_terrain_frequency", "icar_hip_linear_perturbation",
+    "icar_hip_linwinds_build_lut", "icar_hip_linwinds_lut_download", "icar_hip_linwinds_lut_upload",
+    "icar_hip_linwinds_perturbation_download", "icar_hip_linwinds_perturbation_upload", "icar_hip_spatial_winds",
 ]
+
+
+class lt_options_c(ctypes.Structure):          # struct icar_hip_lt_options (include/icar_hip.h)
+    _fields_ = [("buffer", ctypes.c_int), ("stability_window_size", ctypes.c_int), ("vert_smooth", ctypes.c_int),
+                ("variable_N", ctypes.c_int), ("smooth_nsq", ctypes.c_int),
+                ("max_stability", ctypes.c_float), ("min_stability", ctypes.c_float), ("N_squared", ctypes.c_float),
+                ("linear_contribution", ctypes.c_float), ("linear_update_fraction", ctypes.c_float),
+                ("dirmax", ctypes.c_float), ("dirmin", ctypes.c_float), ("spdmax", ctypes.c_float), ("spdmin", ctypes.c_float),
+                ("nsqmax", ctypes.c_float), ("nsqmin", ctypes.c_float),
+                ("n_dir_values", ctypes.c_int), ("n_nsq_values", ctypes.c_int), ("n_spd_values", ctypes.c_int),
+                ("minimum_layer_size", ctypes.c_float)]
 
 
 def lib():

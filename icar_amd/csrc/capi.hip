@@ -284,6 +284,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
     icar_thompson_free(c);
+    icar_linwinds_free(c);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -449,6 +450,74 @@ int icar_hip_balance_uvw(icar_hip_ctx *c, float dx)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
     return icar_balance_uvw_run(c, dx);
+}
+
+int icar_hip_linwinds_setup(icar_hip_ctx *c, const icar_hip_lt_options *opt, const float *global_terrain,
+                            int nx_global, int ny_global, int ids, int jds, float dx)
+{
+    if (!c || !opt || !global_terrain) { icar_set_error("linwinds_setup: null argument"); return 1; }
+    if (nx_global < 2 || ny_global < 2 || !(dx > 0)) { icar_set_error("linwinds_setup: bad global terrain size / dx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_setup_run(c, opt, global_terrain, nx_global, ny_global, ids, jds, dx);
+}
+
+int icar_hip_linwinds_terrain_frequency(icar_hip_ctx *c, double *out, size_t cap, int *fftnx, int *fftny)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_terrain_frequency(c, out, cap, fftnx, fftny);
+}
+
+int icar_hip_linear_perturbation(icar_hip_ctx *c, float U, float V, float Nsq, float z_bottom, float z_top,
+                                 float minimum_step, double *u_perturb, double *v_perturb)
+{
+    if (!c || !u_perturb || !v_perturb) { icar_set_error("linear_perturbation: null argument"); return 1; }
+    if (!(minimum_step > 0) || !(z_top > z_bottom)) { icar_set_error("linear_perturbation: need z_top > z_bottom and minimum_step > 0"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linear_perturbation_run(c, U, V, Nsq, z_bottom, z_top, minimum_step, u_perturb, v_perturb);
+}
+
+int icar_hip_linwinds_build_lut(icar_hip_ctx *c, const float *z_bottom, const float *z_top, int nz)
+{
+    if (!c || !z_bottom || !z_top) { icar_set_error("linwinds_build_lut: null argument"); return 1; }
+    for (int k = 0; k < nz; ++k) if (!(z_top[k] > z_bottom[k])) { icar_set_error("linwinds_build_lut: need z_top > z_bottom on every level"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_build_lut_run(c, z_bottom, z_top, nz);
+}
+
+int icar_hip_linwinds_lut_download(icar_hip_ctx *c, int comp, float *host)
+{
+    if (!c || !host) { icar_set_error("linwinds_lut_download: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_lut_copy(c, comp, host, 0);
+}
+
+int icar_hip_linwinds_lut_upload(icar_hip_ctx *c, int comp, const float *host)
+{
+    if (!c || !host) { icar_set_error("linwinds_lut_upload: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_lut_copy(c, comp, const_cast<float *>(host), 1);
+}
+
+int icar_hip_linwinds_perturbation_download(icar_hip_ctx *c, int comp, float *host)
+{
+    if (!c || !host) { icar_set_error("linwinds_perturbation_download: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_pert_copy(c, comp, host, 0);
+}
+
+int icar_hip_linwinds_perturbation_upload(icar_hip_ctx *c, int comp, const float *host)
+{
+    if (!c || !host) { icar_set_error("linwinds_perturbation_upload: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_pert_copy(c, comp, const_cast<float *>(host), 1);
+}
+
+int icar_hip_spatial_winds(icar_hip_ctx *c, int update)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_spatial_winds_run(c, update);
 }
 
 size_t icar_hip_halo_count(const icar_hip_ctx *c, int dir, int halo)

@@ -22,6 +22,7 @@ struct CVarPtrs { const float *p[ICAR_MAX_ADV]; };
 struct TimingGroup { double total_ms = 0; int launches = 0; };
 
 struct ThompsonTables;   // mp_thompson.hip
+struct LinWinds;         // linear_winds.hip
 
 struct icar_hip_ctx {
     int device = 0;
@@ -42,6 +43,7 @@ struct icar_hip_ctx {
     float *d_red = nullptr;              // small device scratch for reductions
     int *d_flag = nullptr;
     ThompsonTables *thompson = nullptr;
+    LinWinds *linwinds = nullptr;
     // timing
     bool timing = false;
     std::map<std::string, TimingGroup> timers;
@@ -77,4 +79,12 @@ int icar_thompson_init_run(icar_hip_ctx *c, const float *params, const int *flag
 int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
                       int ids, int ide, int jds, int jde, int kds, int kde);
 void icar_thompson_free(icar_hip_ctx *c);
+void icar_linwinds_free(icar_hip_ctx *c);
+int icar_linwinds_setup_run(icar_hip_ctx *c, const icar_hip_lt_options *o, const float *terrain, int nxg, int nyg, int ids, int jds, float dx);
+int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, float zb, float zt, float minimum_step, double *u_out, double *v_out);
+int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *zt, int nlev);
+int icar_linwinds_lut_copy(icar_hip_ctx *c, int comp, float *host, int to_dev);
+int icar_linwinds_pert_copy(icar_hip_ctx *c, int comp, float *host, int to_dev);
+int icar_linwinds_terrain_frequency(icar_hip_ctx *c, double *out, size_t cap, int *fnx, int *fny);
+int icar_spatial_winds_run(icar_hip_ctx *c, int update);
 int icar_thompson_table_download(icar_hip_ctx *c, const char *name, double *out, size_t cap, size_t *n_out);

@@ -1,0 +1,110 @@
+"""linear_theory_winds mirror (src/physics/linear_winds.f90): setup_linwinds, linear_perturb and the
+diagnostic entry points, same names / argument meaning as the reference; all arithmetic runs in
+libicar_hip (icar_amd/csrc/linear_winds.hip) -- nothing here computes."""
+import ctypes
+import numpy as np
+from .capi import lib, check, lt_options_c, IcarHipError
+
+
+def _c_options(lt):
+    lo, hi = lt.resolved()
+    return lt_options_c(buffer=int(lt.buffer), stability_window_size=int(lt.stability_window_size), vert_smooth=int(lt.vert_smooth),
+                        variable_N=int(lt.variable_N), smooth_nsq=int(lt.smooth_nsq), max_stability=lt.max_stability,
+                        min_stability=lt.min_stability, N_squared=lt.N_squared, linear_contribution=lt.linear_contribution,
+                        linear_update_fraction=lt.linear_update_fraction, dirmax=lt.dirmax, dirmin=lt.dirmin, spdmax=lt.spdmax,
+                        spdmin=lt.spdmin, nsqmax=hi, nsqmin=lo, n_dir_values=int(lt.n_dir_values), n_nsq_values=int(lt.n_nsq_values),
+                        n_spd_values=int(lt.n_spd_values), minimum_layer_size=lt.minimum_layer_size)
+
+
+def layer_bounds(z_column, terrain_height, dz_levels):
+    """layer_height -/+ dz_levels/2 of initialize_spatial_winds (:751-753), REAL(4) arithmetic.
+    z_column = domain%z%data_3d(ims,:,jms), terrain_height = domain%terrain%data_2d(ims,jms)."""
+    z = np.asarray(z_column, np.float32); dz = np.asarray(dz_levels, np.float32)
+    layer_height = z - np.float32(terrain_height)
+    return (layer_height - dz / np.float32(2)).astype(np.float32), (layer_height + dz / np.float32(2)).astype(np.float32)
+
+
+def setup_linwinds(domain, options, global_terrain, z_column=None, terrain_height=0.0, build=True):
+    """setup_linwinds(domain, options, reverse=.false., useDensity) (:1180-1309).
+    global_terrain: domain%global_terrain as numpy [ny_global, nx_global] (== Fortran (nx,ny)).
+    With spatial_linear_fields the LUT is generated here (initialize_spatial_winds) unless build=False
+    (e.g. when a cached LUT will be uploaded, read_LUT)."""
+    lt = options.lt_options
+    t = np.ascontiguousarray(global_terrain, np.float32)
+    nyg, nxg = t.shape
+    opt = _c_options(lt)
+    check(lib().icar_hip_linwinds_setup(domain.ctx, ctypes.byref(opt), t.ctypes.data_as(ctypes.c_void_p), nxg, nyg,
+                                        int(domain.ids), int(domain.jds), ctypes.c_float(domain.dx)), "linwinds_setup")
+    domain._linwinds_ready = True
+    if lt.spatial_linear_fields and build:
+        if options.parameters.space_varying_dz:
+            raise IcarHipError("linear wind LUT for space_varying_dz is not built on the device yet")
+        if z_column is None:                      # flat-terrain column: interfaces from dz_levels
+            dz = np.asarray(options.parameters.dz_levels, np.float32)[:domain.nz]
+            z_column = (np.cumsum(dz, dtype=np.float32) - dz / np.float32(2)).astype(np.float32)
+        zb, zt = layer_bounds(z_column, terrain_height, np.asarray(options.parameters.dz_levels, np.float32)[:domain.nz])
+        build_lut(domain, zb, zt)
+
+
+def build_lut(domain, z_bottom, z_top):
+    zb = np.ascontiguousarray(z_bottom, np.float32); zt = np.ascontiguousarray(z_top, np.float32)
+    check(lib().icar_hip_linwinds_build_lut(domain.ctx, zb.ctypes.data_as(ctypes.c_void_p), zt.ctypes.data_as(ctypes.c_void_p),
+                                            len(zb)), "linwinds_build_lut")
+
+
+def linear_perturb(domain, options, vsmooth=None, reverse=False, useDensity=False, update=False):
+    """linear_perturb(domain, options, vsmooth, reverse, useDensity, update) (:1311-1345).  The reference
+    forces rev=.False. whenever `reverse` is present; vsmooth comes from lt_options%vert_smooth at setup."""
+    if not getattr(domain, "_linwinds_ready", False):
+        raise IcarHipError("linear_perturb: call setup_linwinds(domain, options, global_terrain) first")
+    check(lib().icar_hip_spatial_winds(domain.ctx, int(bool(update))), "spatial_winds")
+
+
+def terrain_frequency(domain):
+    """domain%terrain_frequency as complex128 [fftny, fftnx]."""
+    nx, ny = ctypes.c_int(), ctypes.c_int()
+    check(lib().icar_hip_linwinds_terrain_frequency(domain.ctx, None, ctypes.c_size_t(0), ctypes.byref(nx), ctypes.byref(ny)), "tf size")
+    out = np.empty((ny.value, nx.value), np.complex128)
+    check(lib().icar_hip_linwinds_terrain_frequency(domain.ctx, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(out.size),
+                                                    ctypes.byref(nx), ctypes.byref(ny)), "terrain_frequency")
+    return out
+
+
+def linear_perturbation(domain, U, V, Nsq, z_bottom, z_top, minimum_step, shape):
+    """linear_perturbation (constant-z interface :239-276): real(u_perturb), real(v_perturb) as [fftny, fftnx]."""
+    u = np.empty(shape, np.float64); v = np.empty(shape, np.float64)
+    check(lib().icar_hip_linear_perturbation(domain.ctx, ctypes.c_float(U), ctypes.c_float(V), ctypes.c_float(Nsq),
+                                             ctypes.c_float(z_bottom), ctypes.c_float(z_top), ctypes.c_float(minimum_step),
+                                             u.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)), "linear_perturbation")
+    return u, v
+
+
+def _lut_shape(domain, options, comp):
+    lt = options.lt_options
+    nxc, nyc = (domain.nx + 1, domain.ny) if comp == 0 else (domain.nx, domain.ny + 1)
+    return (nyc, domain.nz, nxc, lt.n_nsq_values, lt.n_dir_values, lt.n_spd_values)     # C order of Fortran (spd,dir,nsq,i,k,j)
+
+
+def lut_download(domain, options, comp):
+    a = np.empty(_lut_shape(domain, options, comp), np.float32)
+    check(lib().icar_hip_linwinds_lut_download(domain.ctx, comp, a.ctypes.data_as(ctypes.c_void_p)), "lut_download")
+    return a
+
+
+def lut_upload(domain, options, comp, lut):
+    a = np.ascontiguousarray(lut, np.float32)
+    if a.shape != _lut_shape(domain, options, comp):
+        raise ValueError(f"LUT shape {a.shape} != {_lut_shape(domain, options, comp)}")
+    check(lib().icar_hip_linwinds_lut_upload(domain.ctx, comp, a.ctypes.data_as(ctypes.c_void_p)), "lut_upload")
+
+
+def perturbation_download(domain, comp):
+    shp = (domain.ny, domain.nz, domain.nx + 1) if comp == 0 else (domain.ny + 1, domain.nz, domain.nx)
+    a = np.empty(shp, np.float32)
+    check(lib().icar_hip_linwinds_perturbation_download(domain.ctx, comp, a.ctypes.data_as(ctypes.c_void_p)), "pert_download")
+    return a
+
+
+def perturbation_upload(domain, comp, arr):
+    a = np.ascontiguousarray(arr, np.float32)
+    check(lib().icar_hip_linwinds_perturbation_upload(domain.ctx, comp, a.ctypes.data_as(ctypes.c_void_p)), "pert_upload")

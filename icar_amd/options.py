@@ -36,6 +36,40 @@ class mp_options_type:                   # opt_types.f90:30-46, defaults options
 
 
 @dataclass
+class lt_options_type:                   # opt_types.f90 lt_options_type, defaults options_obj.f90:1447-1482
+    buffer: int = 50
+    stability_window_size: int = 10
+    vert_smooth: int = 10
+    variable_N: bool = True
+    smooth_nsq: bool = True
+    max_stability: float = 6e-4
+    min_stability: float = 1e-7
+    N_squared: float = 3e-5
+    linear_contribution: float = 1.0
+    linear_update_fraction: float = 0.2
+    spatial_linear_fields: bool = True
+    dirmax: float = float(np.float32(2) * np.float32(3.1415927))
+    dirmin: float = 0.0
+    spdmax: float = 30.0
+    spdmin: float = 0.0
+    nsqmax: float = None                 # log(max_stability) unless given (options_obj.f90:1474)
+    nsqmin: float = None                 # log(min_stability)
+    n_dir_values: int = 24
+    n_nsq_values: int = 5
+    n_spd_values: int = 6
+    minimum_layer_size: float = 100.0
+    read_LUT: bool = False
+    write_LUT: bool = True
+
+    def resolved(self):
+        """(nsqmin, nsqmax) in REAL(4): log() of the REAL(4) stability limits like the namelist defaults."""
+        import math
+        hi = np.float32(self.nsqmax) if self.nsqmax is not None else np.float32(math.log(float(np.float32(self.max_stability))))
+        lo = np.float32(self.nsqmin) if self.nsqmin is not None else np.float32(math.log(float(np.float32(self.min_stability))))
+        return float(lo), float(hi)
+
+
+@dataclass
 class parameter_options_type:            # opt_types.f90:188-326 (subset on the path)
     dx: float = 1000.0
     dz_levels: np.ndarray = None
@@ -45,6 +79,7 @@ class parameter_options_type:            # opt_types.f90:188-326 (subset on the 
     cfl_strictness: int = 3              # options_obj.f90:1051
     debug: bool = False
     ideal: bool = False
+    space_varying_dz: bool = False       # options_obj.f90:1936
 
 
 @dataclass
@@ -52,6 +87,7 @@ class options_t:
     physics: physics_type = field(default_factory=physics_type)
     adv_options: adv_options_type = field(default_factory=adv_options_type)
     mp_options: mp_options_type = field(default_factory=mp_options_type)
+    lt_options: lt_options_type = field(default_factory=lt_options_type)
     parameters: parameter_options_type = field(default_factory=parameter_options_type)
     vars_to_advect: dict = field(default_factory=dict)
     vars_to_allocate: dict = field(default_factory=dict)

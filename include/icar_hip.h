@@ -68,7 +68,10 @@ enum icar_hip_field {
     ICAR_F_DZDX = 32,              /* domain%dzdx  (nx+1, nz, ny)           */
     ICAR_F_DZDY = 33,              /* domain%dzdy  (nx, nz, ny+1)           */
     ICAR_F_SURFACE_PRESSURE = 34,  /* domain%surface_pressure%data_2d  REAL(4) (nx,ny) */
-    ICAR_N_FIELDS = 35
+    /* linear-theory winds (src/physics/linear_winds.f90:840-1127) */
+    ICAR_F_Z = 35,                 /* domain%z%data_3d (mass-level height)  */
+    ICAR_F_NSQUARED = 36,          /* domain%nsquared%data_3d               */
+    ICAR_N_FIELDS = 37
 };
 
 enum { ICAR_ADV_UPWIND = 1, ICAR_ADV_MPDATA = 2 };   /* kADV_UPWIND / kADV_MPDATA, icar_constants.f90:341 */
@@ -154,6 +157,51 @@ int icar_hip_enforce_limits(icar_hip_ctx *ctx, const int *fields, int nfields);
 
 /* ---- W1: balance_uvw (src/physics/wind.f90:81-169): w from the horizontal divergence ---------- */
 int icar_hip_balance_uvw(icar_hip_ctx *ctx, float dx);
+
+/* ---- W3: linear-theory wind look-up table (src/physics/linear_winds.f90) ----------------------
+ * options%lt_options (src/objects/options_obj.f90:1400-1530; defaults there: buffer 50, stability_window_size 10,
+ * vert_smooth 10, max/min_stability 6e-4/1e-7, N_squared 3e-5, linear_contribution 1, linear_update_fraction 0.2,
+ * dir 0..2pi x24, spd 0..30 x6, nsq log(min)..log(max) x5, minimum_layer_size 100). */
+typedef struct icar_hip_lt_options {
+    int buffer, stability_window_size, vert_smooth;
+    int variable_N, smooth_nsq;
+    float max_stability, min_stability, N_squared, linear_contribution, linear_update_fraction;
+    float dirmax, dirmin, spdmax, spdmin, nsqmax, nsqmin;
+    int n_dir_values, n_nsq_values, n_spd_values;
+    float minimum_layer_size;
+} icar_hip_lt_options;
+
+/* setup_linwinds (:1180-1225): buffered + edge-blended + smoothed terrain (add_buffer_topo :351-418, twice),
+ * forward 2-D FFT / (nx*ny), fftshift (single-precision temp, src/utilities/fftshift.f90:95-117), the wavenumber
+ * axes of initialize_linear_theory_data (:426-470), the LUT axes (:648-650) and zeroed hi_[uv]_perturbation.
+ * global_terrain is domain%global_terrain (nx_global, ny_global) Fortran order; ids/jds = global index of its first
+ * cell in the index space of the context's ims/jms (1 in the reference). */
+int icar_hip_linwinds_setup(icar_hip_ctx *ctx, const icar_hip_lt_options *opt, const float *global_terrain,
+                            int nx_global, int ny_global, int ids, int jds, float dx);
+/* domain%terrain_frequency as (re,im) pairs, (fftnx, fftny) Fortran order; out may be NULL to query the size. */
+int icar_hip_linwinds_terrain_frequency(icar_hip_ctx *ctx, double *out, size_t capacity_complex, int *fftnx, int *fftny);
+/* linear_perturbation (constant-z form, :239-276 -> linear_perturbation_at_height :181-237): real parts of
+ * lt_data%u_perturb / v_perturb on the (fftnx, fftny) grid, host buffers. */
+int icar_hip_linear_perturbation(icar_hip_ctx *ctx, float U, float V, float Nsq, float z_bottom, float z_top,
+                                 float minimum_step, double *u_perturb, double *v_perturb);
+/* initialize_spatial_winds (:596-830), constant-z branch: every (dir, spd, N^2) x level entry for this context's
+ * tile; z_bottom/z_top[nz] = layer_height -/+ dz_levels/2 (:751-753). */
+int icar_hip_linwinds_build_lut(icar_hip_ctx *ctx, const float *z_bottom, const float *z_top, int nz);
+/* hi_u_LUT / hi_v_LUT in the reference's index order (n_spd, n_dir, n_nsq, nx[+1], nz, ny[+1]) -- the order of the
+ * disk cache src/io/lt_lut_io.f90 -- component 0 = u, 1 = v.  upload replaces read_LUT (:659). */
+int icar_hip_linwinds_lut_download(icar_hip_ctx *ctx, int component, float *host);
+int icar_hip_linwinds_lut_upload(icar_hip_ctx *ctx, int component, const float *host);
+/* hi_u_perturbation / hi_v_perturbation (the relaxed perturbation state, :1263-1268), for restarts and tests. */
+int icar_hip_linwinds_perturbation_download(icar_hip_ctx *ctx, int component, float *host);
+int icar_hip_linwinds_perturbation_upload(icar_hip_ctx *ctx, int component, const float *host);
+
+/* ---- W2: spatial_winds (:840-1127, reverse=.false.) -------------------------------------------
+ * N^2 (calc_stability, src/utilities/atm_utilities.f90:401-467) -> clamp -> log -> vertical (+-vert_smooth) and
+ * horizontal (smooth_array ydim=3, src/utilities/array_utilities.f90:308-417) smoothing -> per cell bracket search
+ * and 8-corner interpolation of the LUTs -> relaxation of hi_[uv]_perturbation -> added to U/V (update=0) or to their
+ * dqdt_3d mirrors (update=1).  Reads POTENTIAL_TEMPERATURE, EXNER, Z, WATER_VAPOR and whichever of CLOUD_WATER,
+ * CLOUD_ICE, RAIN, SNOW are on the device ("associated"); writes NSQUARED. */
+int icar_hip_spatial_winds(icar_hip_ctx *ctx, int update);
 
 /* ---- H1: halo faces (src/objects/exchangeable_obj.f90:138-356) --------------------------------
  * dir: 0=north 1=south 2=east 3=west.  pack gathers what exchangeable%put_<dir> would PUT

@@ -136,3 +136,40 @@ def max_courant(u, v, w, dz_levels, dx):
     fn = lib().orc_max_courant
     fn.restype = ctypes.c_float
     return float(fn(_i(nx), _i(nz), _i(ny), _p(u), _p(v), _p(w), _p(np.ascontiguousarray(dz_levels, np.float32)), _f(dx)))
+
+
+# ---- W2: spatial_winds (oracle/wind_oracle.c) ---------------------------------------------------
+class _lt_opts(ctypes.Structure):
+    _fields_ = [("variable_N", ctypes.c_int), ("smooth_nsq", ctypes.c_int), ("N_squared", ctypes.c_float),
+                ("max_stability", ctypes.c_float), ("min_stability", ctypes.c_float),
+                ("linear_contribution", ctypes.c_float), ("linear_update_fraction", ctypes.c_float),
+                ("n_dir", ctypes.c_int), ("n_spd", ctypes.c_int), ("n_nsq", ctypes.c_int),
+                ("dir_values", ctypes.c_void_p), ("spd_values", ctypes.c_void_p), ("nsq_values", ctypes.c_void_p)]
+
+
+def spatial_winds(u3d, v3d, th, exner, z, qv, hydrometeors, u_lut, v_lut, u_pert, v_pert, opt, dirv, spdv, nsqv, vsmooth, winsz):
+    """orc_spatial_winds.  u3d (ny,nz,nx+1), v3d (ny+1,nz,nx) are updated in place (data_3d or dqdt_3d);
+    hydrometeors = (qc, qi, qr, qs) with None for "not associated"; LUTs in the reference's order, i.e. numpy
+    C-order [ny(+1), nz, nx(+1), n_nsq, n_dir, n_spd]; opt: dict.  Returns nsquared."""
+    ny, nz, nx = th.shape
+    nsq = np.zeros((ny, nz, nx), np.float32)
+    o = _lt_opts(int(opt["variable_N"]), int(opt["smooth_nsq"]), opt["N_squared"], opt["max_stability"], opt["min_stability"],
+                 opt["linear_contribution"], opt["linear_update_fraction"], len(dirv), len(spdv), len(nsqv),
+                 dirv.ctypes.data, spdv.ctypes.data, nsqv.ctypes.data)
+    qc, qi, qr, qs = hydrometeors
+    lib().orc_spatial_winds(_i(nx), _i(nz), _i(ny), _p(u3d), _p(v3d), _p(nsq), _p(th), _p(exner), _p(z), _p(qv),
+                            _p(qc), _p(qi), _p(qr), _p(qs), _p(u_lut), _p(v_lut), _p(u_pert), _p(v_pert),
+                            ctypes.byref(o), _i(vsmooth), _i(winsz))
+    return nsq
+
+
+def smooth_array_ydim3(a, w):
+    ny, nz, nx = a.shape
+    lib().orc_smooth_array_ydim3(_i(nx), _i(nz), _i(ny), _p(a), _i(w))
+    return a
+
+
+def calc_direction(u, v):
+    fn = lib().orc_calc_direction
+    fn.restype = ctypes.c_float
+    return float(fn(_f(u), _f(v)))
