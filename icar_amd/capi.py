@@ -23,7 +23,7 @@ SYMBOLS = [
     "icar_hip_halo_unpack", "icar_hip_timing_enable", "icar_hip_timing_read", "icar_hip_timing_reset",
     "icar_hip_last_error", "icar_hip_version",
     "icar_hip_linwinds_setup", "icar_hip_linwinds_terrain_frequency", "icar_hip_linear_perturbation",
-    "icar_hip_linwinds_build_lut", "icar_hip_linwinds_lut_download", "icar_hip_linwinds_lut_upload",
+    "icar_hip_linwinds_build_lut", "icar_hip_linwinds_build_lut_varying", "icar_hip_linwinds_lut_download", "icar_hip_linwinds_lut_upload",
     "icar_hip_linwinds_perturbation_download", "icar_hip_linwinds_perturbation_upload", "icar_hip_spatial_winds",
 ]
 

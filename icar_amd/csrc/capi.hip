@@ -485,6 +485,13 @@ int icar_hip_linwinds_build_lut(icar_hip_ctx *c, const float *z_bottom, const fl
     return icar_linwinds_build_lut_run(c, z_bottom, z_top, nz);
 }
 
+int icar_hip_linwinds_build_lut_varying(icar_hip_ctx *c, const float *z_bottom, const float *z_top, int nz)
+{
+    if (!c || !z_bottom || !z_top) { icar_set_error("linwinds_build_lut_varying: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_build_lut_varying_run(c, z_bottom, z_top, nz);
+}
+
 int icar_hip_linwinds_lut_download(icar_hip_ctx *c, int comp, float *host)
 {
     if (!c || !host) { icar_set_error("linwinds_lut_download: null argument"); return 1; }

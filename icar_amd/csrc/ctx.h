@@ -83,6 +83,7 @@ void icar_linwinds_free(icar_hip_ctx *c);
 int icar_linwinds_setup_run(icar_hip_ctx *c, const icar_hip_lt_options *o, const float *terrain, int nxg, int nyg, int ids, int jds, float dx);
 int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, float zb, float zt, float minimum_step, double *u_out, double *v_out);
 int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *zt, int nlev);
+int icar_linwinds_build_lut_varying_run(icar_hip_ctx *c, const float *zb3, const float *zt3, int nlev);
 int icar_linwinds_lut_copy(icar_hip_ctx *c, int comp, float *host, int to_dev);
 int icar_linwinds_pert_copy(icar_hip_ctx *c, int comp, float *host, int to_dev);
 int icar_linwinds_terrain_frequency(icar_hip_ctx *c, double *out, size_t cap, int *fnx, int *fny);

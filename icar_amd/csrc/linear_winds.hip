@@ -151,11 +151,11 @@ __global__ void k_lt_norm_shift(const double2 *__restrict__ in, double2 *__restr
 }
 
 // linear_perturbation_at_height (:198-231) for every sub-layer height of levels [lev0, lev0+nlev), summed over the
-// sub-layers of a level (see header), written at the ifftshift-ed position.  spec: [2][nlev][ny][nx].
+// sub-layers of a level (see header), written at the ifftshift-ed position.  spec: u planes [0,nlev), v planes [vplane0, vplane0+nlev).
 __global__ void __launch_bounds__(64)
 k_lt_spectral(const double2 *__restrict__ hhat, const float *__restrict__ k1, const float *__restrict__ l1, int nx, int ny,
               float U, float V, float Nsq, const float *__restrict__ zs, const int *__restrict__ nsteps, int max_steps,
-              int lev0, int nlev, double2 *__restrict__ spec)
+              int lev0, int nlev, double2 *__restrict__ spec, int vplane0)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
     if (i >= nx) return;
@@ -186,7 +186,7 @@ k_lt_spectral(const double2 *__restrict__ hhat, const float *__restrict__ k1, co
             vr += (double)(float)((double)l * ir); vi += (double)(float)((double)l * im);
         }
         spec[(size_t)lv * plane + o] = make_double2(ur, ui);
-        spec[(size_t)(nlev + lv) * plane + o] = make_double2(vr, vi);
+        spec[(size_t)(vplane0 + lv) * plane + o] = make_double2(vr, vi);
     }
 }
 
@@ -207,6 +207,56 @@ __global__ void k_lt_destagger(const double2 *__restrict__ spec, int fnx, int fn
         const int fi = buffer + a0 + i, fj = buffer + b0 + j - 1;
         const double s = sv[(size_t)fi + (size_t)fnx * fj].x / n + sv[(size_t)fi + (size_t)fnx * (fj + 1)].x / n;
         vlut[(size_t)i + (size_t)nx * ((size_t)(lev0 + lv) + (size_t)nz * j)] = (float)s / 2.0f;
+    }
+}
+
+// linear_perturbation_varyingz (:316-343) + destagger: the sub-layer solutions of one model level are weighted in
+// physical space by the fraction of [current_z +- step/2] that lies inside each column's layer.
+struct VaryZ {
+    const float *zb, *zt;      // global z_bottom / z_top (nxg, nz, nyg)
+    int nxg, nzg, nyg, level;
+    float start_z, end_z, step_size;
+    const float *cz; int nsub; // sub-layer centre heights of this level
+};
+
+__device__ __forceinline__ double lt_varying_point(const double2 *__restrict__ planes, size_t plane, size_t p, int fi, int fj, int buffer, const VaryZ &v)
+{
+    // internal_z_top / internal_z_bottom (:302-305): the field sits at 1-based (buffer : buffer+n-1)
+    const int gi = fi - (buffer - 1), gj = fj - (buffer - 1);
+    float izt = v.end_z, izb = v.start_z;
+    if (gi >= 0 && gi < v.nxg && gj >= 0 && gj < v.nyg) {
+        const size_t g = (size_t)gi + (size_t)v.nxg * ((size_t)v.level + (size_t)v.nzg * gj);
+        izt = v.zt[g]; izb = v.zb[g];
+    }
+    const float half = v.step_size / 2;
+    float layer_count = 0;
+    double acc = 0;
+    for (int s = 0; s < v.nsub; ++s) {
+        const float cz = v.cz[s];
+        const float frac = fmaxf(0.0f, ((fminf(half, cz - izb) + fminf(0.0f, izt - cz)) + fminf(half, izt - cz)) + fminf(0.0f, cz - izb)) / v.step_size;
+        layer_count = layer_count + frac;
+        acc = acc + planes[(size_t)s * plane + p].x * (double)frac;
+    }
+    return acc / (double)layer_count;
+}
+
+__global__ void k_lt_destagger_varying(const double2 *__restrict__ spec, int fnx, int fny, int maxsub, VaryZ vz,
+                                       int buffer, int a0, int b0, int nx, int nz, int ny, float *__restrict__ ulut, float *__restrict__ vlut)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    const size_t plane = (size_t)fnx * fny;
+    const double2 *su = spec, *sv = spec + (size_t)maxsub * plane;
+    if (i <= nx && j < ny) {
+        const int fi = buffer + a0 + i - 1, fj = buffer + b0 + j;
+        const double s = lt_varying_point(su, plane, (size_t)fi + (size_t)fnx * fj, fi, fj, buffer, vz)
+                       + lt_varying_point(su, plane, (size_t)fi + 1 + (size_t)fnx * fj, fi + 1, fj, buffer, vz);
+        ulut[(size_t)i + (size_t)(nx + 1) * ((size_t)vz.level + (size_t)nz * j)] = (float)s / 2.0f;
+    }
+    if (i < nx && j <= ny) {
+        const int fi = buffer + a0 + i, fj = buffer + b0 + j - 1;
+        const double s = lt_varying_point(sv, plane, (size_t)fi + (size_t)fnx * fj, fi, fj, buffer, vz)
+                       + lt_varying_point(sv, plane, (size_t)fi + (size_t)fnx * (fj + 1), fi, fj + 1, buffer, vz);
+        vlut[(size_t)i + (size_t)nx * ((size_t)vz.level + (size_t)nz * j)] = (float)s / 2.0f;
     }
 }
 
@@ -349,7 +399,7 @@ int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, f
     if (ensure_spec(w, plane * 4)) return 1;
     if (ensure_plan(w, 0, 2, c->stream)) return 1;
     k_lt_spectral<<<dim3((w->fftnx + 63) / 64, w->fftny), 64, 0, c->stream>>>(w->hhat, w->k1, w->l1, w->fftnx, w->fftny, U, V, Nsq,
-                                                                                   w->d_z, w->d_nsteps, w->max_steps, 0, 1, w->spec);
+                                                                                   w->d_z, w->d_nsteps, w->max_steps, 0, 1, w->spec, 1);
     HIPCHK(hipGetLastError());
     FFTCHK(hipfftExecZ2Z(w->plan[0], (hipfftDoubleComplex *)w->spec, (hipfftDoubleComplex *)w->spec, HIPFFT_BACKWARD));
     double *du = (double *)(w->spec + 2 * plane), *dv = du + plane;
@@ -406,7 +456,7 @@ int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *z
             const int slot = (nl == chunk) ? 0 : 1;
             if (ensure_plan(w, slot, 2 * nl, c->stream)) return 1;
             k_lt_spectral<<<dim3((w->fftnx + 63) / 64, w->fftny), 64, 0, c->stream>>>(w->hhat, w->k1, w->l1, w->fftnx, w->fftny, u, v, nsq,
-                                                                                           w->d_z, w->d_nsteps, w->max_steps, lev0, nl, w->spec);
+                                                                                           w->d_z, w->d_nsteps, w->max_steps, lev0, nl, w->spec, nl);
             FFTCHK(hipfftExecZ2Z(w->plan[slot], (hipfftDoubleComplex *)w->spec, (hipfftDoubleComplex *)w->spec, HIPFFT_BACKWARD));
             k_lt_destagger<<<dim3((nx + 1 + 63) / 64, ny + 1, nl), 64, 0, c->stream>>>(w->spec, w->fftnx, w->fftny, nl, lev0, w->d_nsteps, w->buffer,
                                                                                         w->a0, w->b0, nx, nz, ny,
@@ -416,6 +466,83 @@ int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *z
     HIPCHK(hipGetLastError());
     w->lut_ready = true;
     return 0;
+}
+
+// initialize_spatial_winds, space_varying_dz branch (:738-748): zb3/zt3 = global_z_interface - global_terrain
+// (+ global_dz_interface), (nx_global, nz, ny_global) Fortran order.
+int icar_linwinds_build_lut_varying_run(icar_hip_ctx *c, const float *zb3, const float *zt3, int nlev)
+{
+    LinWinds *w = c->linwinds;
+    if (!w) { icar_set_error("linwinds_build_lut_varying: call icar_hip_linwinds_setup first"); return 1; }
+    if (nlev != c->d.nz) { icar_set_error("linwinds_build_lut_varying: need one layer per model level"); return 1; }
+    ScopedTimer t(c, "lt_lut");
+    const int nxg = w->nxg, nyg = w->nyg;
+    // per level: start_z, end_z, step_size and the current_z sequence (:297-314), REAL(4)
+    std::vector<float> start_z(nlev), end_z(nlev), step(nlev);
+    std::vector<std::vector<float>> cz(nlev);
+    size_t maxsub = 1;
+    for (int z = 0; z < nlev; ++z) {
+        float mn = zb3[(size_t)nxg * z], mx = zt3[(size_t)nxg * z], md = mx - mn;
+        for (int j = 0; j < nyg; ++j) for (int i = 0; i < nxg; ++i) {
+            const size_t g = (size_t)i + (size_t)nxg * ((size_t)z + (size_t)nlev * j);
+            mn = std::min(mn, zb3[g]); mx = std::max(mx, zt3[g]); md = std::min(md, zt3[g] - zb3[g]);
+        }
+        start_z[z] = mn; end_z[z] = mx; step[z] = std::min(w->o.minimum_layer_size, md);
+        if (!(step[z] > 0)) { icar_set_error("linwinds_build_lut_varying: a layer has zero or negative thickness"); return 1; }
+        float current_z = mn + step[z] / 2;
+        while (current_z < mx) { cz[z].push_back(current_z); current_z = current_z + step[z]; }
+        if (cz[z].size() > 4096) { icar_set_error("linwinds_build_lut_varying: more than 4096 sub-layers in one level"); return 1; }
+        maxsub = std::max(maxsub, cz[z].size());
+    }
+    std::vector<float> flat; std::vector<int> off(nlev);
+    for (int z = 0; z < nlev; ++z) { off[z] = (int)flat.size(); flat.insert(flat.end(), cz[z].begin(), cz[z].end()); }
+    std::vector<int> ones(flat.size(), 1);
+    if (w->d_z) hipFree(w->d_z);
+    if (w->d_nsteps) hipFree(w->d_nsteps);
+    w->d_z = nullptr; w->d_nsteps = nullptr;
+    HIPCHK(hipMalloc(&w->d_z, std::max<size_t>(1, flat.size()) * sizeof(float))); HIPCHK(hipMalloc(&w->d_nsteps, std::max<size_t>(1, flat.size()) * sizeof(int)));
+    HIPCHK(hipMemcpy(w->d_z, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w->d_nsteps, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
+    w->max_steps = 1; w->nlev = (int)flat.size();
+    float *dzb = nullptr, *dzt = nullptr;
+    const size_t n3g = (size_t)nxg * nlev * nyg;
+    HIPCHK(hipMalloc(&dzb, n3g * sizeof(float))); HIPCHK(hipMalloc(&dzt, n3g * sizeof(float)));
+    HIPCHK(hipMemcpy(dzb, zb3, n3g * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dzt, zt3, n3g * sizeof(float), hipMemcpyHostToDevice));
+    int rc = 0;
+    do {
+        if ((rc = alloc_luts(c, w))) break;
+        const size_t plane = (size_t)w->fftnx * w->fftny;
+        if ((rc = ensure_spec(w, maxsub * 2 * plane))) break;
+        if ((rc = ensure_plan(w, 0, (int)(2 * maxsub), c->stream))) break;
+        HIPCHK(hipMemsetAsync(w->spec, 0, maxsub * 2 * plane * sizeof(double2), c->stream));
+        const int nd = w->o.n_dir_values, ns = w->o.n_spd_values, nn = w->o.n_nsq_values;
+        const int nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
+        const size_t ucells = icar_field_count(c, ICAR_F_U), vcells = icar_field_count(c, ICAR_F_V);
+        for (int ijk = 0; ijk < nd * ns * nn && !rc; ++ijk) {
+            const int ik = ijk / nn, j = ijk % nn, i = ik / ns, k = ik % ns;
+            const float u = sinf(w->dirv[i]) * w->spdv[k], v = cosf(w->dirv[i]) * w->spdv[k], nsq = expf(w->nsqv[j]);
+            if (u == 0 && v == 0) continue;
+            const size_t combo = (size_t)k + (size_t)ns * ((size_t)i + (size_t)nd * j);
+            for (int z = 0; z < nlev; ++z) {
+                const int nsub = (int)cz[z].size();
+                if (nsub == 0) continue;
+                // u planes at [0, nsub), v planes at [maxsub, maxsub+nsub): call the spectral kernel once per component block
+                k_lt_spectral<<<dim3((w->fftnx + 63) / 64, w->fftny), 64, 0, c->stream>>>(w->hhat, w->k1, w->l1, w->fftnx, w->fftny, u, v, nsq,
+                                                                                               w->d_z, w->d_nsteps, 1, off[z], nsub, w->spec, (int)maxsub);
+                if (fftchk(hipfftExecZ2Z(w->plan[0], (hipfftDoubleComplex *)w->spec, (hipfftDoubleComplex *)w->spec, HIPFFT_BACKWARD), "hipfftExecZ2Z")) { rc = 1; break; }
+                VaryZ vz{dzb, dzt, nxg, nlev, nyg, z, start_z[z], end_z[z], step[z], w->d_z + off[z], nsub};
+                k_lt_destagger_varying<<<dim3((nx + 1 + 63) / 64, ny + 1), 64, 0, c->stream>>>(w->spec, w->fftnx, w->fftny, (int)maxsub, vz, w->buffer,
+                                                                                                w->a0, w->b0, nx, nz, ny,
+                                                                                                w->lut[0] + combo * ucells, w->lut[1] + combo * vcells);
+            }
+        }
+        if (!rc && icar_hip_check(hipGetLastError(), "linwinds_build_lut_varying kernels")) rc = 1;
+        if (!rc && icar_hip_check(hipStreamSynchronize(c->stream), "linwinds_build_lut_varying sync")) rc = 1;
+    } while (0);
+    hipFree(dzb); hipFree(dzt);
+    if (!rc) w->lut_ready = true;
+    return rc;
 }
 
 int icar_linwinds_lut_copy(icar_hip_ctx *c, int comp, float *host, int to_dev)

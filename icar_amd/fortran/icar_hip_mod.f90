@@ -12,18 +12,29 @@ module icar_hip
   implicit none
   private
   public :: hip_ctx_t, hip_create, hip_destroy, hip_upload, hip_download, hip_upload_2dd, hip_download_2dd, &
-            hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync
+            hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
+            hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
-            ICAR_F_JACOBIAN_V, ICAR_F_JACOBIAN_W, ICAR_F_ADVECTION_DZ, ICAR_F_PRECIPITATION, ICAR_F_SNOWFALL, ICAR_F_GRAUPEL_ACC
+            ICAR_F_JACOBIAN_V, ICAR_F_JACOBIAN_W, ICAR_F_ADVECTION_DZ, ICAR_F_PRECIPITATION, ICAR_F_SNOWFALL, ICAR_F_GRAUPEL_ACC, &
+            ICAR_F_Z, ICAR_F_NSQUARED
 
   ! enum icar_hip_field (include/icar_hip.h)
   integer(c_int), parameter :: ICAR_F_WATER_VAPOR=0, ICAR_F_CLOUD_WATER=1, ICAR_F_RAIN=2, ICAR_F_SNOW=3, &
        ICAR_F_POTENTIAL_TEMPERATURE=4, ICAR_F_CLOUD_ICE=5, ICAR_F_GRAUPEL=6, ICAR_F_ICE_NUMBER=7, ICAR_F_RAIN_NUMBER=8, &
        ICAR_F_U=11, ICAR_F_V=12, ICAR_F_W=13, ICAR_F_PRESSURE=14, ICAR_F_EXNER=15, ICAR_F_DENSITY=16, ICAR_F_DZ_MASS=17, &
        ICAR_F_JACOBIAN=18, ICAR_F_JACOBIAN_U=19, ICAR_F_JACOBIAN_V=20, ICAR_F_JACOBIAN_W=21, ICAR_F_ADVECTION_DZ=22, &
-       ICAR_F_PRECIPITATION=23, ICAR_F_SNOWFALL=24, ICAR_F_GRAUPEL_ACC=25
+       ICAR_F_PRECIPITATION=23, ICAR_F_SNOWFALL=24, ICAR_F_GRAUPEL_ACC=25, ICAR_F_Z=35, ICAR_F_NSQUARED=36
+
+  !> struct icar_hip_lt_options == the members of options%lt_options the linear-wind path reads
+  type, bind(C) :: hip_lt_options_t
+     integer(c_int) :: buffer, stability_window_size, vert_smooth, variable_N, smooth_nsq
+     real(c_float)  :: max_stability, min_stability, N_squared, linear_contribution, linear_update_fraction
+     real(c_float)  :: dirmax, dirmin, spdmax, spdmin, nsqmax, nsqmin
+     integer(c_int) :: n_dir_values, n_nsq_values, n_spd_values
+     real(c_float)  :: minimum_layer_size
+  end type
 
   type :: hip_ctx_t
      type(c_ptr) :: p = c_null_ptr
@@ -68,6 +79,16 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_balance_uvw(ctx, dx) bind(C, name="icar_hip_balance_uvw")
        import; type(c_ptr), value :: ctx; real(c_float), value :: dx
+     end function
+     integer(c_int) function icar_hip_linwinds_setup(ctx, opt, terrain, nxg, nyg, ids, jds, dx) bind(C, name="icar_hip_linwinds_setup")
+       import; type(c_ptr), value :: ctx; type(hip_lt_options_t), intent(in) :: opt; real(c_float), intent(in) :: terrain(*)
+       integer(c_int), value :: nxg, nyg, ids, jds; real(c_float), value :: dx
+     end function
+     integer(c_int) function icar_hip_linwinds_build_lut(ctx, z_bottom, z_top, nz) bind(C, name="icar_hip_linwinds_build_lut")
+       import; type(c_ptr), value :: ctx; real(c_float), intent(in) :: z_bottom(*), z_top(*); integer(c_int), value :: nz
+     end function
+     integer(c_int) function icar_hip_spatial_winds(ctx, update) bind(C, name="icar_hip_spatial_winds")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: update
      end function
      type(c_ptr) function icar_hip_last_error() bind(C, name="icar_hip_last_error")
        import
@@ -195,5 +216,30 @@ contains
     type(hip_ctx_t), intent(in) :: ctx
     real, intent(in) :: dx
     call check(icar_hip_balance_uvw(ctx%p, real(dx,c_float)), "balance_uvw")
+  end subroutine
+
+  !> setup_linwinds (linear_winds.f90:1180): terrain spectrum, wavenumber axes, zeroed perturbation state
+  subroutine hip_setup_linwinds(ctx, lt, global_terrain, ids, jds, dx)
+    type(hip_ctx_t), intent(in) :: ctx
+    type(hip_lt_options_t), intent(in) :: lt
+    real(c_float), contiguous, intent(in) :: global_terrain(:,:)
+    integer, intent(in) :: ids, jds
+    real, intent(in) :: dx
+    call check(icar_hip_linwinds_setup(ctx%p, lt, global_terrain, int(size(global_terrain,1),c_int), &
+               int(size(global_terrain,2),c_int), int(ids,c_int), int(jds,c_int), real(dx,c_float)), "linwinds_setup")
+  end subroutine
+
+  !> initialize_spatial_winds (linear_winds.f90:596), constant-z layers: z_bottom/top = layer_height -/+ dz_levels/2
+  subroutine hip_linwinds_build_lut(ctx, z_bottom, z_top)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_float), intent(in) :: z_bottom(:), z_top(:)
+    call check(icar_hip_linwinds_build_lut(ctx%p, z_bottom, z_top, int(size(z_bottom),c_int)), "linwinds_build_lut")
+  end subroutine
+
+  !> spatial_winds (linear_winds.f90:840): update=.true. targets u/v dqdt_3d
+  subroutine hip_spatial_winds(ctx, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    logical, intent(in) :: update
+    call check(icar_hip_spatial_winds(ctx%p, merge(1_c_int, 0_c_int, update)), "spatial_winds")
   end subroutine
 end module icar_hip

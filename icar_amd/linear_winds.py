@@ -24,7 +24,8 @@ def layer_bounds(z_column, terrain_height, dz_levels):
     return (layer_height - dz / np.float32(2)).astype(np.float32), (layer_height + dz / np.float32(2)).astype(np.float32)
 
 
-def setup_linwinds(domain, options, global_terrain, z_column=None, terrain_height=0.0, build=True):
+def setup_linwinds(domain, options, global_terrain, z_column=None, terrain_height=0.0, build=True,
+                   global_z_bottom=None, global_z_top=None):
     """setup_linwinds(domain, options, reverse=.false., useDensity) (:1180-1309).
     global_terrain: domain%global_terrain as numpy [ny_global, nx_global] (== Fortran (nx,ny)).
     With spatial_linear_fields the LUT is generated here (initialize_spatial_winds) unless build=False
@@ -38,7 +39,11 @@ def setup_linwinds(domain, options, global_terrain, z_column=None, terrain_heigh
     domain._linwinds_ready = True
     if lt.spatial_linear_fields and build:
         if options.parameters.space_varying_dz:
-            raise IcarHipError("linear wind LUT for space_varying_dz is not built on the device yet")
+            # global_z_interface - global_terrain and + global_dz_interface, numpy [ny_global, nz, nx_global]
+            if global_z_bottom is None or global_z_top is None:
+                raise IcarHipError("space_varying_dz: pass global_z_bottom / global_z_top (ny_global, nz, nx_global)")
+            build_lut_varying(domain, global_z_bottom, global_z_top)
+            return
         if z_column is None:                      # flat-terrain column: interfaces from dz_levels
             dz = np.asarray(options.parameters.dz_levels, np.float32)[:domain.nz]
             z_column = (np.cumsum(dz, dtype=np.float32) - dz / np.float32(2)).astype(np.float32)
@@ -50,6 +55,12 @@ def build_lut(domain, z_bottom, z_top):
     zb = np.ascontiguousarray(z_bottom, np.float32); zt = np.ascontiguousarray(z_top, np.float32)
     check(lib().icar_hip_linwinds_build_lut(domain.ctx, zb.ctypes.data_as(ctypes.c_void_p), zt.ctypes.data_as(ctypes.c_void_p),
                                             len(zb)), "linwinds_build_lut")
+
+
+def build_lut_varying(domain, global_z_bottom, global_z_top):
+    zb = np.ascontiguousarray(global_z_bottom, np.float32); zt = np.ascontiguousarray(global_z_top, np.float32)
+    check(lib().icar_hip_linwinds_build_lut_varying(domain.ctx, zb.ctypes.data_as(ctypes.c_void_p), zt.ctypes.data_as(ctypes.c_void_p),
+                                                    zb.shape[1]), "linwinds_build_lut_varying")
 
 
 def linear_perturb(domain, options, vsmooth=None, reverse=False, useDensity=False, update=False):

@@ -187,6 +187,10 @@ int icar_hip_linear_perturbation(icar_hip_ctx *ctx, float U, float V, float Nsq,
 /* initialize_spatial_winds (:596-830), constant-z branch: every (dir, spd, N^2) x level entry for this context's
  * tile; z_bottom/z_top[nz] = layer_height -/+ dz_levels/2 (:751-753). */
 int icar_hip_linwinds_build_lut(icar_hip_ctx *ctx, const float *z_bottom, const float *z_top, int nz);
+/* same, options%parameters%space_varying_dz branch (:738-748 -> linear_perturbation_varyingz :280-344):
+ * z_bottom = global_z_interface - global_terrain, z_top = z_bottom + global_dz_interface, both
+ * (nx_global, nz, ny_global) Fortran order. */
+int icar_hip_linwinds_build_lut_varying(icar_hip_ctx *ctx, const float *z_bottom, const float *z_top, int nz);
 /* hi_u_LUT / hi_v_LUT in the reference's index order (n_spd, n_dir, n_nsq, nx[+1], nz, ny[+1]) -- the order of the
  * disk cache src/io/lt_lut_io.f90 -- component 0 = u, 1 = v.  upload replaces read_LUT (:659). */
 int icar_hip_linwinds_lut_download(icar_hip_ctx *ctx, int component, float *host);

@@ -84,6 +84,30 @@ def test_lut_build_vs_oracle(tile):
     d.close()
 
 
+def test_lut_build_space_varying_dz_vs_oracle():
+    nxg, nyg, nz, dx = 34, 30, 2, 1500.0
+    t = terrain(nxg, nyg, seed=6)
+    opt = options_t()
+    opt.lt_options = lt_options_type(buffer=5, n_dir_values=3, n_spd_values=2, n_nsq_values=2)
+    opt.parameters.dz_levels = np.array([100.0, 260.0], np.float32)
+    opt.parameters.space_varying_dz = True
+    # SLEVE-like layers: thinner over high terrain
+    squeeze = (1.0 - 0.25 * t / t.max()).astype(np.float32)                     # [nyg, nxg]
+    dz3 = (opt.parameters.dz_levels[None, :, None] * squeeze[:, None, :]).astype(np.float32)
+    zb3 = np.concatenate([np.zeros((nyg, 1, nxg), np.float32), np.cumsum(dz3, axis=1, dtype=np.float32)[:, :-1]], axis=1)
+    zt3 = (zb3 + dz3).astype(np.float32)
+    d = make_domain(nxg, nyg, nz, dx)
+    LW.setup_linwinds(d, opt, t, global_z_bottom=zb3, global_z_top=zt3)
+    tf, lt, buf = W.setup_linwinds(t.T.copy(), dx, 5)
+    zb = [zb3[:, z, :].T.copy() for z in range(nz)]; zt = [zt3[:, z, :].T.copy() for z in range(nz)]
+    ul, vl, *_ = W.build_lut(tf, lt, buf, zb, zt, lut_options(opt.lt_options), varying=True)
+    want_u = np.ascontiguousarray(ul.transpose(5, 4, 3, 2, 1, 0)); want_v = np.ascontiguousarray(vl.transpose(5, 4, 3, 2, 1, 0))
+    for got, want in ((LW.lut_download(d, opt, 0), want_u), (LW.lut_download(d, opt, 1), want_v)):
+        assert np.isfinite(got).all() and abs(want).max() > 0.05
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * abs(want).max())
+    d.close()
+
+
 def _run_spatial(oracle, moist, variable_N, update, smooth=True, passes=2):
     nx, ny, nz = 70, 37, 12
     a = atmosphere(nx, ny, nz, seed=5, moist=moist)
