@@ -11,7 +11,9 @@
 # debug prints; flang lowers that to prif_this_image_no_coarray, which oracle/ref_link_stubs.f90
 # answers with 1 -- the same single-image semantics as the reference CI's -fcoarray=single
 # build (.github/workflows/icar-main-commit.yml).  ref_link_stubs.c provides the flang-runtime
-# registration hook _FortranAAMDRegisterAllocator (no-op).  Neither stub does arithmetic.
+# registration hook _FortranAAMDRegisterAllocator (no-op).  num_images() (grid_obj.f90:163 only) is
+# answered with a value set by the shim so that the reference's own for_image= path yields every
+# tile of an N-image decomposition in one process.  No stub does arithmetic.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 R=${ICAR_REFERENCE:-/root/reference}/src
@@ -28,7 +30,7 @@ gcc -c -fPIC "$HERE/ref_link_stubs.c" -o ref_link_stubs_c.o
 for f in constants/icar_constants constants/wrf_constants utilities/time_delta_obj utilities/time_h \
          main/data_structures objects/opt_types objects/options_h utilities/assertions objects/grid_h \
          objects/meta_data_h objects/variable_h objects/variable_dict_h objects/exchangeable_h \
-         objects/boundary_h objects/domain_h physics/adv_mpdata physics/advect \
+         objects/boundary_h objects/domain_h objects/grid_obj physics/adv_mpdata physics/advect \
          physics/mp_simple physics/mp_thompson ; do
   o=$(basename $f).o
   if [ ! -f "$o" ] || [ "$R/$f.f90" -nt "$o" ]; then
@@ -39,7 +41,7 @@ $FC $FLAGS "$HERE/ref_shim.f90" -o ref_shim.o 2>&1 | grep -v "multi image Fortra
 OBJS="ref_shim.o ref_link_stubs.o ref_link_stubs_c.o \
     adv_mpdata.o advect.o mp_simple.o mp_thompson.o icar_constants.o wrf_constants.o data_structures.o \
     opt_types.o options_h.o domain_h.o grid_h.o variable_h.o variable_dict_h.o meta_data_h.o \
-    exchangeable_h.o boundary_h.o time_h.o time_delta_obj.o assertions.o"
+    exchangeable_h.o boundary_h.o time_h.o time_delta_obj.o assertions.o grid_obj.o"
 # The interface modules carry type-bound-procedure tables that point at bodies living in the
 # (uncompiled, NetCDF-dependent) *_obj.f90 submodules.  They are never called on this path; bind
 # each such dangling Fortran module symbol (_QM*) to address 0, which is what a static link with

@@ -110,3 +110,17 @@ def thompson_table(name):
     if m < 0:
         raise KeyError(name)
     return buf[:m].copy()
+
+
+GRID_MEMBERS = ["yimg", "ximg", "yimages", "ximages", "ims", "ime", "jms", "jme", "kms", "kme", "ns_halo_nx", "ew_halo_ny",
+                "halo_nz", "halo_size", "nx_global", "ny_global", "nx", "ny", "nz", "ids", "ide", "jds", "jde", "kds", "kde",
+                "its", "ite", "jts", "jte", "kts", "kte", "is2d", "is3d"]
+
+
+def grid(nx, ny, nz, nimages, image, nx_extra=0, ny_extra=0):
+    """The reference's grid_t%set_grid_dimensions(..., for_image=image) in an nimages-image run
+    (src/objects/grid_obj.f90:140-255) -> dict of its integer members."""
+    out = (ctypes.c_int * 33)()
+    lib().ref_grid(ctypes.c_int(nx), ctypes.c_int(ny), ctypes.c_int(nz), ctypes.c_int(nimages), ctypes.c_int(image),
+                   ctypes.c_int(nx_extra), ctypes.c_int(ny_extra), out)
+    return dict(zip(GRID_MEMBERS, list(out)))

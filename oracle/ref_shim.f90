@@ -19,6 +19,8 @@ module icar_ref_shim
   use options_interface, only: options_t
   use options_types,     only: mp_options_type
   use domain_interface,  only: domain_t
+  use grid_interface,    only: grid_t
+  use prif,              only: stub_num_images
   use adv_mpdata,        only: mpdata
   use adv_upwind,        only: upwind
   use module_mp_simple,  only: mp_simple_driver
@@ -176,4 +178,21 @@ contains
     end select
     ref_thompson_table = m
   end function
+
+  !> grid_t%set_grid_dimensions(nx, ny, nz, nx_extra, ny_extra, for_image=image) of an nimages-image run
+  !! (src/objects/grid_obj.f90:140-255).  out(1:33) = yimg,ximg,yimages,ximages, ims,ime,jms,jme,kms,kme,
+  !! ns_halo_nx,ew_halo_ny,halo_nz,halo_size, nx_global,ny_global, nx,ny,nz, ids,ide,jds,jde,kds,kde,
+  !! its,ite,jts,jte,kts,kte, is2d,is3d
+  subroutine ref_grid(nx, ny, nz, nimages, image, nx_extra, ny_extra, out) bind(C, name="ref_grid")
+    integer(c_int), value :: nx, ny, nz, nimages, image, nx_extra, ny_extra
+    integer(c_int), intent(out) :: out(33)
+    type(grid_t) :: g
+    stub_num_images = nimages
+    call g%set_grid_dimensions(nx, ny, nz, nx_extra=nx_extra, ny_extra=ny_extra, for_image=image)
+    stub_num_images = 1
+    out = [g%yimg, g%ximg, g%yimages, g%ximages, g%ims, g%ime, g%jms, g%jme, g%kms, g%kme, &
+           g%ns_halo_nx, g%ew_halo_ny, g%halo_nz, g%halo_size, g%nx_global, g%ny_global, g%nx, g%ny, g%nz, &
+           g%ids, g%ide, g%jds, g%jde, g%kds, g%kde, g%its, g%ite, g%jts, g%jte, g%kts, g%kte, &
+           merge(1, 0, g%is2d), merge(1, 0, g%is3d)]
+  end subroutine
 end module icar_ref_shim

@@ -57,3 +57,19 @@ def test_staggered_grids():
     gu = grid_t().set_grid_dimensions(512, 512, 40, 4, 1, nx_extra=1)
     g = grid_t().set_grid_dimensions(512, 512, 40, 4, 1)
     assert gu.ime == g.ime + 1 and gu.nx_global == 513
+
+
+def test_grid_matches_reference_golden():
+    """tests/golden/grid_tiles.npz: integer members of the reference's own grid_t (compiled grid_obj.f90) for every
+    image of 11 decompositions x 5 domains x {mass, u, v} grids -- bit-exact (integers)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "grid_tiles.npz"))
+    rows, members = z["rows"], [str(m) for m in z["members"]]
+    assert len(rows) > 2000
+    for r in rows:
+        nx, ny, nz, n, img, ex, ey = (int(v) for v in r[:7])
+        g = grid_t().set_grid_dimensions(nx, ny, nz, n, img, nx_extra=ex, ny_extra=ey)
+        for m, want in zip(members, r[7:]):
+            if m in ("is2d", "is3d"):
+                continue
+            assert getattr(g, m) == int(want), (nx, ny, nz, n, img, ex, ey, m, getattr(g, m), int(want))
