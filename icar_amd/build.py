@@ -29,7 +29,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "icar_hip.h"))
     objs = []
     for s in SOURCES:

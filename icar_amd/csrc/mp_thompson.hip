@@ -16,6 +16,7 @@
 #include "thompson_state.h"
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 const ThState *icar_thompson_device_state(icar_hip_ctx *c);
 const ThState *icar_thompson_host_state(icar_hip_ctx *c);
@@ -1068,7 +1069,8 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
           qg1d = qg[c], ni1d = ni[c], nr1d = nr[c];
     float pptrain = 0.f, pptsnow = 0.f, pptgraul = 0.f, pptice = 0.f;
-    th_column_lane(T, lane, nk, dt, dz1d, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d, p1d, pptrain, pptsnow, pptgraul, pptice);
+    WaveComm x(lane, nk);
+    th_column_lane(T, x, nk, dt, dz1d, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d, p1d, pptrain, pptsnow, pptgraul, pptice);
     if (lane == 0) {
         const int c2 = i + d.nx * j;
         const float rainnc = 0.f + pptrain + pptsnow + pptgraul + pptice;
@@ -1083,6 +1085,42 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
         qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
         th[c] = t1d / pi_;
     }
+}
+
+// floor(NT/nk) whole columns per block, thread = level*cpb + column (see thompson_lane.inc: BlockComm)
+template <int NT, int WPE>
+__global__ void __launch_bounds__(NT, WPE)      // WPE = waves per SIMD the register budget is sized for
+k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
+                float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
+                float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
+                double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
+                float dt, int i0, int i1, int j0, int k0, int nk, int cpb)
+{
+    __shared__ typename BlockComm<NT>::Shared sh;
+    const int first = i0 + blockIdx.x * cpb;                 // first column of this block
+    const int ncol = min(cpb, i1 - first + 1);               // columns present (block-uniform, >= 1)
+    BlockComm<NT> x(sh, threadIdx.x, ncol, nk);
+    const int j = j0 + blockIdx.y;
+    const int i = first + (x.active ? x.col : 0);
+    const int c = d.idx(i, k0 + x.k, j);
+    const float pi_ = pii[c];
+    float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
+          qg1d = qg[c], ni1d = ni[c], nr1d = nr[c];
+    float pptrain = 0.f, pptsnow = 0.f, pptgraul = 0.f, pptice = 0.f;
+    th_column_lane(T, x, nk, dt, dz1d, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d, p1d, pptrain, pptsnow, pptgraul, pptice);
+    if (!x.active) return;
+    if (x.k == 0) {
+        const int c2 = i + d.nx * j;
+        const float rainnc = 0.f + pptrain + pptsnow + pptgraul + pptice;
+        const float snownc = 0.f + pptsnow + pptice;
+        const float graupelnc = 0.f + pptgraul;
+        rain_acc[c2] = rain_acc[c2] + rainnc;
+        snow_acc[c2] = snow_acc[c2] + snownc;
+        graupel_acc[c2] = graupel_acc[c2] + graupelnc;
+    }
+    qv[c] = (qv1d < 1.E-7f) ? 1.E-7f : qv1d;              // :997-1010
+    qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
+    th[c] = t1d / pi_;
 }
 }  // namespace
 
@@ -1111,8 +1149,25 @@ int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
     dim3 g((i_end - its + 1 + 63) / 64, j_end - jts + 1), b(64);
 #define LAUNCH(K) hipLaunchKernelGGL((k_thompson<K>), g, b, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, \
                                      dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk)
-    static const bool column_per_lane = getenv("ICAR_HIP_THOMPSON_COLUMN_PER_LANE") != nullptr;   // A/B switch for profiling
-    if (nk <= 64 && !column_per_lane) {
+    // A/B switches for profiling: ICAR_HIP_THOMPSON=lane (column per lane, scratch arrays) | wave (column per wave)
+    const char *mode = getenv("ICAR_HIP_THOMPSON");
+    const bool want_lane = mode && !strcmp(mode, "lane"), want_wave = mode && !strcmp(mode, "wave");
+    const int ncols = i_end - its + 1;
+    // thread utilisation of each layout: whole columns packed into an NT-thread block vs one column per 64-lane wave
+    int best_nt = 0; float best_u = (nk <= 64) ? nk / 64.0f : 0.0f;
+    if (nk >= 8 && !want_wave && !want_lane)
+        for (int nt = 256; nt <= 1024; nt *= 2) {
+            const float u = (float)((nt / nk) * nk) / nt;
+            if (u > best_u + 0.02f) { best_u = u; best_nt = nt; }
+        }
+#define PACK(NT) { const int cpb = NT / nk; dim3 gp((ncols + cpb - 1) / cpb, j_end - jts + 1);                                                \
+                   hipLaunchKernelGGL((k_thompson_pack<NT, 4>), gp, dim3(NT), 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, \
+                                      dz, pa, sa, ga, dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk, cpb); }
+    if (best_nt == 256) PACK(256)
+    else if (best_nt == 512) PACK(512)
+    else if (best_nt == 1024) PACK(1024)
+#undef PACK
+    else if (nk <= 64 && !want_lane) {
         dim3 gl((i_end - its + 1 + 3) / 4, j_end - jts + 1), bl(256);
         hipLaunchKernelGGL(k_thompson_lane, gl, bl, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga,
                            dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk);
@@ -1120,7 +1175,7 @@ int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
     else if (nk <= 40) LAUNCH(40);
     else if (nk <= 64) LAUNCH(64);
     else if (nk <= 96) LAUNCH(96);
-    else { icar_set_error("thompson: more than 96 levels are not supported by this build"); return 1; }
+    else { icar_set_error("thompson: this many levels are not supported by this build"); return 1; }
 #undef LAUNCH
     HIPCHK(hipGetLastError());
     return 0;
