@@ -1087,21 +1087,19 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     }
 }
 
-// floor(NT/nk) whole columns per block, thread = level*cpb + column (see thompson_lane.inc: BlockComm)
-template <int NT, int WPE>
-__global__ void __launch_bounds__(NT, WPE)      // WPE = waves per SIMD the register budget is sized for
+// cpb whole columns per block (aligned to multiples of cpb in i), thread = level*cpb + column (thompson_lane.inc: BlockComm)
+__global__ void __launch_bounds__(1024, 4)      // any block size <= 1024; register budget for 4 waves per SIMD (128 VGPRs)
 k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
                 double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
-                float dt, int i0, int i1, int j0, int k0, int nk, int cpb)
+                float dt, int i0, int i1, int j0, int k0, int nk, int cpb, int ib0)
 {
-    __shared__ typename BlockComm<NT>::Shared sh;
-    const int first = i0 + blockIdx.x * cpb;                 // first column of this block
-    const int ncol = min(cpb, i1 - first + 1);               // columns present (block-uniform, >= 1)
-    BlockComm<NT> x(sh, threadIdx.x, ncol, nk);
+    extern __shared__ double lds_pack[];
+    const int first = (ib0 + blockIdx.x) * cpb;              // first column slot of this block (multiple of cpb)
+    BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nk, i0 - first, i1 - first);
     const int j = j0 + blockIdx.y;
-    const int i = first + (x.active ? x.col : 0);
+    const int i = x.active ? first + x.col : max(i0, min(i1, first));
     const int c = d.idx(i, k0 + x.k, j);
     const float pi_ = pii[c];
     float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
@@ -1152,21 +1150,25 @@ int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
     // A/B switches for profiling: ICAR_HIP_THOMPSON=lane (column per lane, scratch arrays) | wave (column per wave)
     const char *mode = getenv("ICAR_HIP_THOMPSON");
     const bool want_lane = mode && !strcmp(mode, "lane"), want_wave = mode && !strcmp(mode, "wave");
-    const int ncols = i_end - its + 1;
-    // thread utilisation of each layout: whole columns packed into an NT-thread block vs one column per 64-lane wave
-    int best_nt = 0; float best_u = (nk <= 64) ? nk / 64.0f : 0.0f;
-    if (nk >= 8 && !want_wave && !want_lane)
-        for (int nt = 256; nt <= 1024; nt *= 2) {
-            const float u = (float)((nt / nk) * nk) / nt;
-            if (u > best_u + 0.02f) { best_u = u; best_nt = nt; }
+    // Packed layout: cpb = floor(nt/nk) whole columns per nt-thread block.  nt is a multiple of 256 (4 waves per SIMD
+    // step): 320- or 640-thread blocks (5 / 10 waves) load the CU's SIMDs unevenly and measured 1.5x slower than 256.
+    // Thread utilisation vs one column per 64-lane wave decides; ties go to the smaller block / the wave kernel.
+    int cpb = 0, nt = 0; float best_u = (nk <= 64) ? nk / 64.0f : 0.0f;
+    if (nk >= 2 && !want_wave && !want_lane) {
+        const int force = getenv("ICAR_HIP_THOMPSON_CPB") ? atoi(getenv("ICAR_HIP_THOMPSON_CPB")) : 0;   // profiling only
+        if (force) { cpb = force; nt = (force * nk + 63) / 64 * 64; }
+        else for (int t = 256; t <= 1024; t *= 2) {
+            const float u = (float)((t / nk) * nk) / t;
+            if (u > best_u + (nt ? 0.10f : 0.02f)) { best_u = u; nt = t; cpb = t / nk; }   // bigger blocks only for a clear gain (barrier cost)
         }
-#define PACK(NT) { const int cpb = NT / nk; dim3 gp((ncols + cpb - 1) / cpb, j_end - jts + 1);                                                \
-                   hipLaunchKernelGGL((k_thompson_pack<NT, 4>), gp, dim3(NT), 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, \
-                                      dz, pa, sa, ga, dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk, cpb); }
-    if (best_nt == 256) PACK(256)
-    else if (best_nt == 512) PACK(512)
-    else if (best_nt == 1024) PACK(1024)
-#undef PACK
+        if (nt > 1024) { cpb = 0; nt = 0; }
+    }
+    if (cpb) {
+        const int i0 = its - c->ims, i1 = i_end - c->ims;
+        const int ib0 = i0 / cpb, nb = i1 / cpb - ib0 + 1;
+        hipLaunchKernelGGL(k_thompson_pack, dim3(nb, j_end - jts + 1), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
+                           qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, i0, i1, jts - c->jms, kts - c->kms, nk, cpb, ib0);
+    }
     else if (nk <= 64 && !want_lane) {
         dim3 gl((i_end - its + 1 + 3) / 4, j_end - jts + 1), bl(256);
         hipLaunchKernelGGL(k_thompson_lane, gl, bl, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga,

@@ -4,7 +4,9 @@ kernel + mean duration, as a markdown table.  Several CSVs (separate --pmc passe
 kernel name.  usage: summarize_pmc.py out.md a_counter_collection.csv [b_counter_collection.csv ...]
 
 Derived columns (MI355X: 256 CUs x 4 SIMDs, SQ_ACTIVE_INST_* in quad-cycles -- MI355X_MICROARCH.md):
-  VALUBusy% = 100 * 4 * SQ_ACTIVE_INST_VALU / 1024 / GRBM_GUI_ACTIVE      (gfx9 derived-metric formula)
+  VALUBusy% = 100 * 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)   (gfx9 derived-metric formula;
+              GRBM_GUI_ACTIVE is summed over the 8 XCDs: it reads 8 x 2.1 GHz x duration)
+  cyc/VALU  = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU   (average issue cycles per VALU instruction)
   HBM read GB/s  = 2 * FETCH_SIZE(KB) * 1024 / duration   (gfx950 correction: FETCH_SIZE counts 128-B requests as 64 B)
   HBM write GB/s = WRITE_SIZE(KB) * 1024 / duration       (uncalibrated)"""
 import csv
@@ -29,7 +31,9 @@ def main(out, files):
         m = {c: sum(v) / len(v) for c, v in val[k].items()}
         extra = {}
         if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
-            extra["VALUBusy%"] = 100 * 4 * m["SQ_ACTIVE_INST_VALU"] / 1024 / m["GRBM_GUI_ACTIVE"]
+            extra["VALUBusy%"] = 100 * 4 * m["SQ_ACTIVE_INST_VALU"] / 1024 / (m["GRBM_GUI_ACTIVE"] / 8)
+        if "SQ_INSTS_VALU" in m and "SQ_ACTIVE_INST_VALU" in m and m["SQ_INSTS_VALU"] > 0:
+            extra["cyc/VALU"] = 4 * m["SQ_ACTIVE_INST_VALU"] / m["SQ_INSTS_VALU"]
         if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m and m["SQ_WAVES"] > 0:
             extra["VALU/wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
         if "FETCH_SIZE" in m:
