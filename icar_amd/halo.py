@@ -32,14 +32,24 @@ class HaloComm:
         self.peers = {d: nb[_NAMES[d]] - 1 for d in _NAMES if nb[_NAMES[d]] is not None}
         self._send = {}
         self._recv = {}
+        self._hsend = {}
+        self._hrecv = {}
         self._reqs = []
         self._nf = None
+        self._stage = False
 
     def _buffers(self, tile, nfields):
         if self._nf != nfields:
             self._send = {d: tile.new_buffer(tile.halo_count(d, self.halo) * nfields) for d in self.peers}
             self._recv = {d: tile.new_buffer(tile.halo_count(d, self.halo) * nfields) for d in self.peers}
             self._nf = nfields
+            # gloo moves host memory only: device buffers are staged through pinned host tensors (what a coarray /
+            # MPI host without GPU-aware transport does).  RCCL takes the device buffers.
+            any_buf = next(iter(self._send.values()), None)
+            self._stage = (any_buf is not None and any_buf.is_cuda and dist.get_backend(self.group) == "gloo")
+            if self._stage:
+                self._hsend = {d: torch.empty(b.shape, dtype=b.dtype).pin_memory() for d, b in self._send.items()}
+                self._hrecv = {d: torch.empty(b.shape, dtype=b.dtype).pin_memory() for d, b in self._recv.items()}
 
     def send(self, tile, field_ids):
         """exchangeable%send for every variable: pack my edge planes, post send+recv per neighbour."""
@@ -49,11 +59,18 @@ class HaloComm:
         ops = []
         for d, peer in self.peers.items():
             tile.halo_pack(d, self.halo, field_ids, self._send[d])
+        sbuf, rbuf = self._send, self._recv
+        if self._stage:
+            if hasattr(tile, "synchronize"):
+                tile.synchronize()                      # pack kernels run on the context's stream
+            for d in self.peers:
+                self._hsend[d].copy_(self._send[d])
+            sbuf, rbuf = self._hsend, self._hrecv
         # deterministic global order of the P2P list avoids cross-rank deadlock in batch mode
         for d in sorted(self.peers):
             peer = self.peers[d]
-            ops.append(dist.P2POp(dist.isend, self._send[d], peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, self._recv[d], peer, group=self.group))
+            ops.append(dist.P2POp(dist.isend, sbuf[d], peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf[d], peer, group=self.group))
         self._reqs = dist.batch_isend_irecv(ops)
 
     def retrieve(self, tile, field_ids):
@@ -65,6 +82,9 @@ class HaloComm:
             r.wait()
         self._reqs = []
         for d in self.peers:
+            if self._stage:
+                self._recv[d].copy_(self._hrecv[d])
+                torch.cuda.synchronize()                # the copy ran on torch's stream, unpack runs on the context's
             tile.halo_unpack(d, self.halo, field_ids, self._recv[d])
 
 
