@@ -55,7 +55,7 @@ def build_tile(args, rank, world, device):
     mp_var_request(opt); adv_var_request(opt)
     comm = HaloComm(g, rank + 1) if world > 1 else None
     d = domain_t(g, device=device, dx=float(case["dx"]), image=rank + 1, comm=comm)
-    d.set_stream(torch.cuda.current_stream().cuda_stream)
+    d.bind_torch_stream()            # context kernels, torch ops and RCCL ordering all on one non-default stream
     d.load_case(case)
     d.exchange_vars = [n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0]
     mp_init(opt, d); adv_init(d, opt)
@@ -157,14 +157,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # ICAR_BENCH_BACKEND=gloo lets several ranks share one GPU (halo buffers staged through host memory): a functional
+    # check of the N>1 path on a 1-GPU box, never a performance number.  The driver's launches use RCCL.
+    backend = os.environ.get("ICAR_BENCH_BACKEND", "nccl")
+    dev_index = local if backend == "nccl" else local % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    red_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from icar_amd import capi
-    d, opt, case, g = build_tile(args, rank, world, local)
+    d, opt, case, g = build_tile(args, rank, world, dev_index)
     lib = capi.lib()
     nscal = sum(1 for v in opt.vars_to_advect.values() if v > 0)
 
@@ -175,21 +183,21 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(d, opt, device=device)
+        one_step(d, opt, device=red_device)
     barrier()
     lib.icar_hip_timing_enable(d.ctx, 1); lib.icar_hip_timing_reset(d.ctx)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dt = one_step(d, opt, device=device)
+        dt = one_step(d, opt, device=red_device)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     own_cells = (g.ite - g.its + 1) * (g.jte - g.jts + 1) * args.nz
-    cells_t = torch.tensor([float(own_cells)], dtype=torch.float64, device=device)
+    cells_t = torch.tensor([float(own_cells)], dtype=torch.float64, device=red_device)
     if world > 1:
         dist.all_reduce(cells_t)
     total_cells = float(cells_t.item())

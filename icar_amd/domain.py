@@ -114,7 +114,27 @@ class domain_t:
         check(lib().icar_hip_synchronize(self.ctx), "synchronize")
 
     def set_stream(self, stream_ptr):
+        """Run the context's kernels on the caller's HIP stream (0 / None = the context's own non-blocking stream)."""
         check(lib().icar_hip_set_stream(self.ctx, ctypes.c_void_p(stream_ptr)), "set_stream")
+        self._stream_ptr = int(stream_ptr) if stream_ptr else 0
+
+    def bind_torch_stream(self, stream=None):
+        """Put the context on a (non-default) torch stream and make it torch's current stream, so that RCCL's
+        send/recv -- which order themselves against torch's current stream -- are ordered with the pack / unpack
+        kernels without host synchronisation."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        self.set_stream(stream.cuda_stream)
+        self._torch_stream = stream
+        return stream
+
+    def needs_host_sync(self):
+        """True when the context's stream is not torch's current stream (then HaloComm synchronises on the host)."""
+        import torch
+        cur = torch.cuda.current_stream().cuda_stream
+        return not (getattr(self, "_stream_ptr", 0) and self._stream_ptr == cur)
 
     def load_case(self, case):
         """Upload every member present in an icar_amd.ideal case dict."""

@@ -60,6 +60,9 @@ class HaloComm:
         for d, peer in self.peers.items():
             tile.halo_pack(d, self.halo, field_ids, self._send[d])
         sbuf, rbuf = self._send, self._recv
+        self._host_sync = bool(getattr(tile, "needs_host_sync", lambda: False)()) and not self._stage
+        if self._host_sync:
+            tile.synchronize()                          # the pack kernels must be complete before RCCL reads the buffers
         if self._stage:
             if hasattr(tile, "synchronize"):
                 tile.synchronize()                      # pack kernels run on the context's stream
@@ -81,6 +84,8 @@ class HaloComm:
         for r in self._reqs:
             r.wait()
         self._reqs = []
+        if getattr(self, "_host_sync", False):
+            torch.cuda.current_stream().synchronize()   # r.wait() only blocks torch's stream; unpack runs on the context's
         for d in self.peers:
             if self._stage:
                 self._recv[d].copy_(self._hrecv[d])
