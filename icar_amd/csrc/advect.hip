@@ -25,6 +25,23 @@ __device__ __forceinline__ float flux1(float l, float r, float U)
 // ------------------------------------------------------------------------------------------------
 // A1: U_m, V_m, W_m (+ W_m/dz used by the pseudo-velocity step, adv_mpdata.f90:379)
 // ------------------------------------------------------------------------------------------------
+// XCD-aware block -> tile mapping.  Workgroups are handed to the 8 XCDs round-robin in linear-id order, and each XCD
+// has its own 4 MB L2.  Stencil kernels re-read the neighbouring j / k planes of the block next to them; with the
+// default mapping that neighbour runs on another XCD and every overlap plane is fetched from HBM again by each of
+// them.  Here XCD x works on the contiguous range [x*n/8, (x+1)*n/8) of the (i fastest, then k, then j) tile order, so
+// the blocks that share planes run on the same XCD close together in time and the overlap hits in L2.
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile()
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = n / 8;
+    if (id < per * 8) id = (id % 8) * per + id / 8;      // the n % 8 tail blocks keep their place
+    TileId t;
+    t.x = (int)(id % gx); t.y = (int)((id / gx) % gy); t.z = (int)(id / (gx * gy));
+    return t;
+}
+
 template <int SCHEME, bool RHO>
 __global__ void __launch_bounds__(BX * BY)
 k_setup_winds(Dims d, const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
@@ -32,9 +49,10 @@ k_setup_winds(Dims d, const float *__restrict__ u, const float *__restrict__ v, 
               const float *__restrict__ jw, const float *__restrict__ dz, float dt, float dx,
               float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float *__restrict__ Wdz)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
-    const int k = blockIdx.y * BY + threadIdx.y;
-    const int j = blockIdx.z;
+    const TileId tb = xcd_tile();
+    const int i = tb.x * BX + threadIdx.x;
+    const int k = tb.y * BY + threadIdx.y;
+    const int j = tb.z;
     if (i >= d.nx || k >= d.nz) return;
     const int c = d.idx(i, k, j);
     const float r0 = RHO ? rho[c] : 1.0f;
@@ -67,9 +85,10 @@ k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
               const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ W,
               const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
-    const int k = blockIdx.y * BY + threadIdx.y;
-    const int j = blockIdx.z;
+    const TileId tb = xcd_tile();
+    const int i = tb.x * BX + threadIdx.x;
+    const int k = tb.y * BY + threadIdx.y;
+    const int j = tb.z;
     if (i >= d.nx || k >= d.nz) return;
     const int c = d.idx(i, k, j);
     const bool interior = (i > 0) && (i < d.nx - 1) && (j > 0) && (j < d.ny - 1);
@@ -114,9 +133,10 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
                 const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ Wz,
                 const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
-    const int k = blockIdx.y * BY + threadIdx.y;
-    const int j = blockIdx.z;
+    const TileId tb = xcd_tile();
+    const int i = tb.x * BX + threadIdx.x;
+    const int k = tb.y * BY + threadIdx.y;
+    const int j = tb.z;
     if (i >= d.nx || k >= d.nz) return;
     const int c = d.idx(i, k, j);
     const int sk = d.sk, sj = d.sj;
@@ -233,57 +253,40 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
                                            float lm1, float l0, float l1, float l2,
                                            float Um, float U0, float Up, bool first, bool last, bool is_w)
 {
+    // adv_mpdata_FCT_core.f90:47-116 has one code path for U0 > 0 (beta_out of the left cell, beta_in of the right
+    // cell) and its mirror image for U0 < 0 (beta_in left, beta_out right).  The mirror image is the same formula
+    // applied to the negated fields and fluxes:  max(x) = -min(-x),  qmax - q = (-q) - min(-x),
+    // fin = max(0,fm) - min(0,f0) = max(0,-f0) - min(0,-fm).  Negation is exact and a-b == (-b)-(-a) bit for bit,
+    // so flipping the sign bits of the inputs when U0 < 0 and running the U0 > 0 path gives identical results
+    // without a divergent branch (antidiffusive velocities change sign from cell to cell).
     if (!(U0 > 0.0f) && !(U0 < 0.0f)) return U0;
-    const float f0 = flux1(q0, q1, U0);
-    if (U0 > 0.0f) {
-        float qmin_i, fout_i;
-        if (first) {
-            qmin_i = fminf(fminf(q0, q1), fminf(l0, l1));
-            fout_i = is_w ? fmaxf(0.f, f0) : 0.0f;
-        } else {
-            const float fm = flux1(qm1, q0, Um);
-            qmin_i = fminf(fminf(fminf(qm1, q0), fminf(q1, lm1)), fminf(l0, l1));
-            fout_i = fmaxf(0.f, f0) - fminf(0.f, fm);
-        }
-        float qmax_i2, fin_i2;
-        if (!last) {
-            const float fp = flux1(q1, q2, Up);
-            qmax_i2 = fmaxf(fmaxf(fmaxf(q0, q1), fmaxf(q2, l0)), fmaxf(l1, l2));
-            fin_i2 = fmaxf(0.f, f0) - fminf(0.f, fp);
-        } else {
-            qmax_i2 = fmaxf(fmaxf(q0, q1), l0);
-            fin_i2 = is_w ? (fmaxf(0.f, f0) - fminf(0.f, f0)) : 0.0f;
-        }
-        const float beta_out_i = (q0 - qmin_i) / (fout_i + 1e-15f);
-        const float beta_in_i2 = (qmax_i2 - q1) / (fin_i2 + 1e-15f);
-        return fminf(fminf(1.f, beta_in_i2), beta_out_i) * U0;
+    const unsigned sm = (U0 > 0.0f) ? 0u : 0x80000000u;
+#define SGN(x) __uint_as_float(__float_as_uint(x) ^ sm)
+    const float f0 = SGN(flux1(q0, q1, U0));
+    const float a0 = SGN(q0), a1 = SGN(q1), b0 = SGN(l0), b1 = SGN(l1);
+    float qmin_i, fout_i;
+    if (first) {
+        qmin_i = fminf(fminf(a0, a1), fminf(b0, b1));
+        fout_i = is_w ? fmaxf(0.f, f0) : 0.0f;
     } else {
-        float qmax_i, fin_i;
-        if (first) {
-            qmax_i = fmaxf(fmaxf(q0, q1), fmaxf(l0, l1));
-            fin_i = is_w ? (0.f - fminf(0.f, f0)) : 0.0f;
-        } else {
-            const float fm = flux1(qm1, q0, Um);
-            qmax_i = fmaxf(fmaxf(fmaxf(qm1, q0), fmaxf(q1, lm1)), fmaxf(l0, l1));
-            fin_i = fmaxf(0.f, fm) - fminf(0.f, f0);
-        }
-        float qmin_i2, fout_i2;
-        if (!last) {
-            const float fp = flux1(q1, q2, Up);
-            qmin_i2 = fminf(fminf(fminf(q0, q1), fminf(q2, l0)), fminf(l1, l2));
-            fout_i2 = fmaxf(0.f, fp) - fminf(0.f, f0);
-        } else {
-            qmin_i2 = fminf(fminf(q0, q1), l0);
-            fout_i2 = is_w ? (fmaxf(0.f, f0) - fminf(0.f, f0)) : 0.0f;
-        }
-        const float beta_in_i = (qmax_i - q0) / (fin_i + 1e-15f);
-        const float beta_out_i2 = (q1 - qmin_i2) / (fout_i2 + 1e-15f);
-        return fminf(fminf(1.f, beta_in_i), beta_out_i2) * U0;
+        const float fm = SGN(flux1(qm1, q0, Um));
+        qmin_i = fminf(fminf(fminf(SGN(qm1), a0), fminf(a1, SGN(lm1))), fminf(b0, b1));
+        fout_i = fmaxf(0.f, f0) - fminf(0.f, fm);
     }
+    float qmax_i2, fin_i2;
+    if (!last) {
+        const float fp = SGN(flux1(q1, q2, Up));
+        qmax_i2 = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(SGN(q2), b0)), fmaxf(b1, SGN(l2)));
+        fin_i2 = fmaxf(0.f, f0) - fminf(0.f, fp);
+    } else {
+        qmax_i2 = fmaxf(fmaxf(a0, a1), b0);
+        fin_i2 = is_w ? (fmaxf(0.f, f0) - fminf(0.f, f0)) : 0.0f;
+    }
+#undef SGN
+    const float beta_out_i = (a0 - qmin_i) / (fout_i + 1e-15f);
+    const float beta_in_i2 = (qmax_i2 - a1) / (fin_i2 + 1e-15f);
+    return fminf(fminf(1.f, beta_in_i2), beta_out_i) * U0;
 }
-
-// limited value of the face whose LEFT cell sits `off` elements before index cc along a line of
-// stride s; pos = line coordinate of the left cell, n = line length.
 __device__ __forceinline__ float limit_face(const float *__restrict__ q1f, const float *__restrict__ lf,
                                             const float *__restrict__ U2, int ca, int cface, int s,
                                             int pos, int n, bool is_w)
@@ -307,9 +310,10 @@ __global__ void __launch_bounds__(BX * BY)
 k_mpdata_final(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
 {
-    const int i = blockIdx.x * BX + threadIdx.x;
-    const int k = blockIdx.y * BY + threadIdx.y;
-    const int j = blockIdx.z;
+    const TileId tb = xcd_tile();
+    const int i = tb.x * BX + threadIdx.x;
+    const int k = tb.y * BY + threadIdx.y;
+    const int j = tb.z;
     if (i >= d.nx || k >= d.nz) return;
     const int c = d.idx(i, k, j);
     const int sk = d.sk, sj = d.sj;
@@ -378,9 +382,10 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
 {
     __shared__ float s_wb[FBY][64];
     const int lane = threadIdx.x, ty = threadIdx.y;
-    const int i = 1 + blockIdx.x * 63 + lane;
-    const int k = blockIdx.y * (FBY - 1) + ty;
-    const int j0 = 1 + blockIdx.z * FJB;
+    const TileId tb = xcd_tile();
+    const int i = 1 + tb.x * 63 + lane;
+    const int k = tb.y * (FBY - 1) + ty;
+    const int j0 = 1 + tb.z * FJB;
     const int j1 = min(j0 + FJB - 1, d.ny - 2);
     const int sk = d.sk, sj = d.sj;
     const bool in_i = (i <= d.nx - 1), in_k = (k <= d.nz - 1);
