@@ -19,7 +19,7 @@ def main(out, files):
     for f in files:
         seen = set()
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             val[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             key = (f, r["Dispatch_Id"])
             if key not in seen:
