@@ -2,6 +2,7 @@
 // rows T3 (diagnostic_update, src/main/time_step.f90:49-198) and F1 (apply_forcing / enforce_limits,
 // src/objects/domain_obj.f90:2383-2448, 2228-2243).  All HBM-bound, lanes along i.
 #include "ctx.h"
+#include "fp64_math.h"
 #include <cmath>
 
 namespace {
@@ -10,7 +11,8 @@ constexpr float Rd = 287.058f, cp = 1012.0f;     // src/constants/icar_constants
 // (p/po)**(Rd/cp) evaluated in FP64 and rounded once ("Arithmetic")
 __device__ __forceinline__ float exner_function(float pressure)
 {   // atm_utilities.f90:682-691 ; po = 100000 (integer in the reference => p/100000.)
-    return (float)pow((double)(pressure / 100000.0f), (double)(Rd / cp));
+    // (p/1e5)**(Rd/cp), p > 0: exp(y log x) in FP64 (|y log x| < 1 => relative error 2^-52), a third of ocml's pow()
+    return (float)d_exp((double)(Rd / cp) * d_log((double)(pressure / 100000.0f)));
 }
 
 __global__ void __launch_bounds__(256)
