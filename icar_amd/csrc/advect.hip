@@ -178,6 +178,7 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
 
     for (int m = 0; m < nv; ++m) {
         const float *__restrict__ q = qin.p[m];
+        float *__restrict__ u2m = u2o.p[m], *__restrict__ v2m = v2o.p[m], *__restrict__ w2m = w2o.p[m];
         const float q0 = q[c];
         // ---- U face (i-1 | i) : adv_mpdata.f90:134-168
         float r_u2 = 0.0f;
@@ -196,7 +197,7 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
             }
             r_u2 = val * 0.5f;
         }
-        u2o.p[m][c] = r_u2;
+        u2m[c] = r_u2;
         // ---- V face (j-1 | j) : :172-208
         float r_v2 = 0.0f;
         if (has_v) {
@@ -217,7 +218,7 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
             }
             r_v2 = val * 0.5f;
         }
-        v2o.p[m][c] = r_v2;
+        v2m[c] = r_v2;
         // ---- W face (k | k+1) : :214-249
         float r_w2 = 0.0f;
         if (has_w) {
@@ -238,7 +239,7 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
             }
             r_w2 = val * 0.5f * dzc;
         }
-        w2o.p[m][c] = r_w2;
+        w2m[c] = r_w2;
     }
 }
 

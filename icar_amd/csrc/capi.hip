@@ -388,6 +388,14 @@ int icar_hip_thompson(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
     return icar_thompson_run(c, dt, its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde);
 }
 
+int icar_hip_thompson_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte,
+                            int ids, int ide, int jds, int jde, int kds, int kde)
+{
+    if (!c || !tiles) { icar_set_error("thompson_tiles: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_thompson_run_tiles(c, dt, ntiles, tiles, kts, kte, ids, ide, jds, jde, kds, kde);
+}
+
 int icar_hip_thompson_table(icar_hip_ctx *c, const char *name, double *out, size_t capacity, size_t *count)
 {
     if (!c || !name) { icar_set_error("thompson_table: null argument"); return 1; }

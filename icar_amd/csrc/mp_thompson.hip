@@ -1097,18 +1097,25 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     }
 }
 
+struct ThTiles { int n, i0[4], i1[4], j0[4], ib0[4], nbx[4], off[5]; };
+
 // cpb whole columns per block (aligned to multiples of cpb in i), thread = level*cpb + column (thompson_lane.inc: BlockComm)
 __global__ void __launch_bounds__(1024, 4)      // any block size <= 1024; register budget for 4 waves per SIMD (128 VGPRs)
 k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
                 double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
-                float dt, int i0, int i1, int j0, int k0, int nk, int cpb, int ib0)
+                float dt, ThTiles tl, int k0, int nk, int cpb)
 {
     extern __shared__ double lds_pack[];
-    const int first = (ib0 + blockIdx.x) * cpb;              // first column slot of this block (multiple of cpb)
+    // several (its..ite, jts..jte) tiles in one launch (process_halo's four strips): block -> tile by prefix offsets
+    int t = 0;
+    while (t + 1 < tl.n && (int)blockIdx.x >= tl.off[t + 1]) ++t;
+    const int local = (int)blockIdx.x - tl.off[t];
+    const int i0 = tl.i0[t], i1 = tl.i1[t];
+    const int first = (tl.ib0[t] + local % tl.nbx[t]) * cpb;  // first column slot of this block (multiple of cpb)
     BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nk, i0 - first, i1 - first);
-    const int j = j0 + blockIdx.y;
+    const int j = tl.j0[t] + local / tl.nbx[t];
     const int i = x.active ? first + x.col : max(i0, min(i1, first));
     const int c = d.idx(i, k0 + x.k, j);
     const float pi_ = pii[c];
@@ -1132,18 +1139,14 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 }
 }  // namespace
 
-int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
-                      int ids, int ide, int jds, int jde, int kds, int kde)
+int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*tiles)[4], int kts, int kte,
+                            int ids, int ide, int jds, int jde, int kds, int kde)
 {
     (void)ids; (void)jds; (void)kds; (void)kde;
     const ThState *T = icar_thompson_device_state(c);
     if (!T) { icar_set_error("thompson: call icar_hip_thompson_init first"); return 1; }
-    if (its < c->ims || ite > c->ime || jts < c->jms || jte > c->jme || kts < c->kms || kte > c->kme) {
-        icar_set_error("thompson: tile outside memory bounds"); return 1;
-    }
-    const int i_end = ite < ide - 1 ? ite : ide - 1;      // :821-822
-    const int j_end = jte < jde - 1 ? jte : jde - 1;
-    if (i_end < its || j_end < jts || kte < kts) return 0;
+    if (ntiles < 1 || ntiles > 4) { icar_set_error("thompson: 1..4 tiles per call"); return 1; }
+    if (kts < c->kms || kte > c->kme || kte < kts) { icar_set_error("thompson: levels outside memory bounds"); return 1; }
     float *qv = icar_field_f(c, ICAR_F_WATER_VAPOR), *qc = icar_field_f(c, ICAR_F_CLOUD_WATER), *qr = icar_field_f(c, ICAR_F_RAIN);
     float *qi = icar_field_f(c, ICAR_F_CLOUD_ICE), *qs = icar_field_f(c, ICAR_F_SNOW), *qg = icar_field_f(c, ICAR_F_GRAUPEL);
     float *ni = icar_field_f(c, ICAR_F_ICE_NUMBER), *nr = icar_field_f(c, ICAR_F_RAIN_NUMBER);
@@ -1153,10 +1156,17 @@ int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
     double *ga = (double *)icar_field_f(c, ICAR_F_GRAUPEL_ACC, false);
     if (!qv || !qc || !qr || !qi || !qs || !qg || !ni || !nr || !th || !pii || !p || !dz || !pa || !sa || !ga) return 1;
     const int nk = kte - kts + 1;
-    ScopedTimer t(c, "mp");
-    dim3 g((i_end - its + 1 + 63) / 64, j_end - jts + 1), b(64);
-#define LAUNCH(K) hipLaunchKernelGGL((k_thompson<K>), g, b, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, \
-                                     dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk)
+    // clip every tile like mp_gt_driver does (:821-822) and drop the empty ones
+    int T4[4][4], nt_ = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int its = tiles[t][0], ite = tiles[t][1], jts = tiles[t][2], jte = tiles[t][3];
+        if (its < c->ims || ite > c->ime || jts < c->jms || jte > c->jme) { icar_set_error("thompson: tile outside memory bounds"); return 1; }
+        const int i_end = ite < ide - 1 ? ite : ide - 1, j_end = jte < jde - 1 ? jte : jde - 1;
+        if (i_end < its || j_end < jts) continue;
+        T4[nt_][0] = its; T4[nt_][1] = i_end; T4[nt_][2] = jts; T4[nt_][3] = j_end; ++nt_;
+    }
+    if (nt_ == 0) return 0;
+    ScopedTimer tm(c, "mp");
     // A/B switches for profiling: ICAR_HIP_THOMPSON=lane (column per lane, scratch arrays) | wave (column per wave)
     const char *mode = getenv("ICAR_HIP_THOMPSON");
     const bool want_lane = mode && !strcmp(mode, "lane"), want_wave = mode && !strcmp(mode, "wave");
@@ -1174,21 +1184,41 @@ int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
         if (nt > 1024) { cpb = 0; nt = 0; }
     }
     if (cpb) {
-        const int i0 = its - c->ims, i1 = i_end - c->ims;
-        const int ib0 = i0 / cpb, nb = i1 / cpb - ib0 + 1;
-        hipLaunchKernelGGL(k_thompson_pack, dim3(nb, j_end - jts + 1), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
-                           qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, i0, i1, jts - c->jms, kts - c->kms, nk, cpb, ib0);
+        // all tiles in ONE launch: process_halo's four 1-cell strips are latency-bound when launched one after another
+        ThTiles tl; tl.n = nt_; tl.off[0] = 0;
+        for (int t = 0; t < nt_; ++t) {
+            tl.i0[t] = T4[t][0] - c->ims; tl.i1[t] = T4[t][1] - c->ims; tl.j0[t] = T4[t][2] - c->jms;
+            tl.ib0[t] = tl.i0[t] / cpb; tl.nbx[t] = tl.i1[t] / cpb - tl.ib0[t] + 1;
+            tl.off[t + 1] = tl.off[t] + tl.nbx[t] * (T4[t][3] - T4[t][2] + 1);
+        }
+        hipLaunchKernelGGL(k_thompson_pack, dim3(tl.off[nt_]), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
+                           qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb);
+        HIPCHK(hipGetLastError());
+        return 0;
     }
-    else if (nk <= 64 && !want_lane) {
-        dim3 gl((i_end - its + 1 + 3) / 4, j_end - jts + 1), bl(256);
-        hipLaunchKernelGGL(k_thompson_lane, gl, bl, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga,
-                           dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk);
-    }
-    else if (nk <= 40) LAUNCH(40);
-    else if (nk <= 64) LAUNCH(64);
-    else if (nk <= 96) LAUNCH(96);
-    else { icar_set_error("thompson: this many levels are not supported by this build"); return 1; }
+    for (int t = 0; t < nt_; ++t) {
+        const int its = T4[t][0], i_end = T4[t][1], jts = T4[t][2], j_end = T4[t][3];
+        dim3 g((i_end - its + 1 + 63) / 64, j_end - jts + 1), b(64);
+#define LAUNCH(K) hipLaunchKernelGGL((k_thompson<K>), g, b, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, \
+                                     dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk)
+        if (nk <= 64 && !want_lane) {
+            dim3 gl((i_end - its + 1 + 3) / 4, j_end - jts + 1), bl(256);
+            hipLaunchKernelGGL(k_thompson_lane, gl, bl, 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga,
+                               dt, its - c->ims, i_end - c->ims, jts - c->jms, kts - c->kms, nk);
+        }
+        else if (nk <= 40) LAUNCH(40);
+        else if (nk <= 64) LAUNCH(64);
+        else if (nk <= 96) LAUNCH(96);
+        else { icar_set_error("thompson: this many levels are not supported by this build"); return 1; }
 #undef LAUNCH
+    }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte,
+                      int ids, int ide, int jds, int jde, int kds, int kde)
+{
+    const int tile[1][4] = {{its, ite, jts, jte}};
+    return icar_thompson_run_tiles(c, dt, 1, tile, kts, kte, ids, ide, jds, jde, kds, kde);
 }

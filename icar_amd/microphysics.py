@@ -81,8 +81,17 @@ def mp(domain, options, dt_in, halo=None, subset=None):
             for (a, b, c, d) in mp_tiles(g.its, g.ite, g.jts, g.jte, subset=subset):
                 _process_subdomain(domain, options, mp_dt, a, b, c, d, g.kts, kte)
         if halo is not None:
-            for (a, b, c, d) in mp_tiles(g.its, g.ite, g.jts, g.jte, halo=halo):
-                _process_subdomain(domain, options, mp_dt, a, b, c, d, g.kts, kte)
+            tiles = mp_tiles(g.its, g.ite, g.jts, g.jte, halo=halo)
+            if options.physics.microphysics == kMP_THOMPSON:
+                # process_halo's four strips in one launch (icar_hip_thompson_tiles)
+                tiles = [t for t in tiles if t[1] >= t[0] and t[3] >= t[2]]
+                arr = ((ctypes.c_int * 4) * len(tiles))(*[(ctypes.c_int * 4)(*t) for t in tiles])
+                if tiles:
+                    check(lib().icar_hip_thompson_tiles(domain.ctx, ctypes.c_float(mp_dt), len(tiles), arr, g.kts, kte,
+                                                        g.ids, g.ide, g.jds, g.jde, g.kds, g.kde), "icar_hip_thompson_tiles")
+            else:
+                for (a, b, c, d) in tiles:
+                    _process_subdomain(domain, options, mp_dt, a, b, c, d, g.kts, kte)
         if halo is None and subset is None:
             _process_subdomain(domain, options, mp_dt, g.its, g.ite, g.jts, g.jte, g.kts, kte)
 

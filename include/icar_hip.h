@@ -125,6 +125,12 @@ int icar_hip_thompson(icar_hip_ctx *ctx, float dt,
                       int its, int ite, int jts, int jte, int kts, int kte,
                       int ids, int ide, int jds, int jde, int kds, int kde);
 
+/* process_halo (src/physics/mp_driver.f90:609-658) calls process_subdomain -> mp_gt_driver once per strip; the four
+ * one-cell strips are latency-bound when launched one after another, so this entry runs up to 4 tiles
+ * {its,ite,jts,jte} (as icar_hip_mp_tiles returns them) in ONE launch.  Tiles must not overlap. */
+int icar_hip_thompson_tiles(icar_hip_ctx *ctx, float dt, int ntiles, const int tiles[][4], int kts, int kte,
+                            int ids, int ide, int jds, int jde, int kds, int kde);
+
 /* Download one Thompson lookup table by its reference name (tcg_racg ... t_Efsw, Fortran order) for
  * cross-checks against ICAR's own qr_acr_qg_mpt.dat / qr_acr_qs_mpt.dat / freezeH2O_mpt.dat caches
  * (src/physics/mp_thompson.f90:2870-2887).  out may be NULL to query the element count. */

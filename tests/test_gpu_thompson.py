@@ -177,3 +177,35 @@ def test_thompson_other_level_counts_vs_oracle(th_oracle, nz):
                         uniform_dz=150.0 if nz == 100 else None)
     assert ref["rain"].max() > 1e-6
     check_close(out, ref, rtol=1e-5, frac_allowed=1e-4, label=f"nz{nz}/mode1")
+
+
+def test_halo_strips_in_one_launch_equal_four_launches():
+    """icar_hip_thompson_tiles (process_halo's four strips in one launch) == four icar_hip_thompson calls."""
+    from icar_amd.microphysics import mp_tiles
+    nx, ny, nz = 50, 31, 40
+    c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.01)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(2.2)).astype(np.float32)
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    outs = []
+    for batched in (True, False):
+        d = single_image_domain(c); mp_init(opt, d); g = d.grid
+        for step in range(3):
+            if batched:
+                tiles = mp_tiles(g.its, g.ite, g.jts, g.jte, halo=1)
+                arr = ((ctypes.c_int * 4) * 4)(*[(ctypes.c_int * 4)(*t) for t in tiles])
+                check(lib().icar_hip_thompson_tiles(d.ctx, ctypes.c_float(60.0), 4, arr, g.kts, g.kte,
+                                                    g.ids, g.ide, g.jds, g.jde, g.kds, g.kde), "thompson_tiles")
+            else:
+                for (a, b, cc, dd) in mp_tiles(g.its, g.ite, g.jts, g.jte, halo=1):
+                    check(lib().icar_hip_thompson(d.ctx, ctypes.c_float(60.0), a, b, cc, dd, g.kts, g.kte,
+                                                  g.ids, g.ide, g.jds, g.jde, g.kds, g.kde), "thompson")
+            d.model_time_seconds += 60.0
+            d.set("potential_temperature", d.get("potential_temperature") - np.float32(2.0))
+        outs.append({k: d.get(m) for k, m in FIELDS.items()} | {"acc": d.get("accumulated_precipitation")})
+        d.close()
+    ring = np.zeros((ny, nx), bool); ring[1, 1:-1] = ring[-2, 1:-1] = True; ring[1:-1, 1] = ring[1:-1, -2] = True
+    assert (outs[0]["cloud_water"][:, 5, :][ring] > 0).any(), "the strips must have done some work"
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    inner = outs[0]["cloud_water"][2:-2, :, 2:-2]
+    assert inner.max() == 0.0, "only the halo ring is processed"
