@@ -17,6 +17,28 @@
 #define BX 64
 #define BY 4
 
+// Correctly rounded FP32 quotient at half the cost of the compiler's expansion (profiles/micro/divbench.hip: 21 vs 56
+// SIMD cycles per wave for the bare chain).  The expansion is  v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma,
+// v_div_fmas, v_div_fixup ; the scale / fmas / fixup steps only act when an operand or the quotient leaves the normal
+// range.  fdiv() runs the same rcp / fma / mul chain (Markstein: the last fma yields the correctly rounded quotient)
+// on the numerator pre-scaled by 2^64 -- an exact operation that keeps the two residuals normal for numerators down
+// to the smallest subnormal -- and scales the quotient back, exactly.  Branch-free, so independent divisions
+// interleave (a per-wave "take the IEEE path" branch was measured SLOWER than the IEEE division itself: it cuts the
+// basic block at every quotient).  Bit-identical to n / d when: |n| < 2^63, d normal with 2^-60 < |d| < 2^60 (here:
+// sums of field values plus 1e-10 / 1e-15, or metric factors), and the quotient is not subnormal (else it may differ
+// in the last subnormal digit, 1.4e-45); a -0 numerator gives +0 (the sign of a zero quotient is discarded by every
+// use on this path: flux1(), q - x with q != -0).
+__device__ __forceinline__ float fdiv(float n, float d)
+{
+    const float ns = n * 0x1p64f;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = ns * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, ns), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, ns), r, q);
+    return q * 0x1p-64f;
+}
+
 __device__ __forceinline__ float flux1(float l, float r, float U)
 {   // donor-cell flux, src/physics/adv_mpdata.f90:40
     return ((U + fabsf(U)) * l + (U - fabsf(U)) * r) / 2;
@@ -110,13 +132,13 @@ k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
         const float f1l = flux1(q[c - 1], q0, Ul);
         const float f3 = flux1(q0, q[c + d.sj], Vn);
         const float f4 = flux1(q[c - d.sj], q0, Vs);
-        float qq = q0 - ((f1r - f1l) + (f3 - f4)) / den_h;
+        float qq = q0 - fdiv((f1r - f1l) + (f3 - f4), den_h);
         if (bottom) {
-            qq = qq - flux1(q0, q[c + d.sk], Wt) / den_v;
+            qq = qq - fdiv(flux1(q0, q[c + d.sk], Wt), den_v);
         } else if (top) {
-            qq = qq - (q0 * Wt - flux1(q[c - d.sk], q0, Wb)) / den_v;
+            qq = qq - fdiv(q0 * Wt - flux1(q[c - d.sk], q0, Wb), den_v);
         } else {
-            qq = qq - (flux1(q0, q[c + d.sk], Wt) - flux1(q[c - d.sk], q0, Wb)) / den_v;
+            qq = qq - fdiv(flux1(q0, q[c + d.sk], Wt) - flux1(q[c - d.sk], q0, Wb), den_v);
         }
         out.p[m][c] = qq;
     }
@@ -184,16 +206,16 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
         float r_u2 = 0.0f;
         if (has_u) {
             const float lx = q[c - 1];
-            float val = au * (q0 - lx) / (q0 + lx + 1e-10f);
+            float val = fdiv(au * (q0 - lx), q0 + lx + 1e-10f);
             if (j_in) {
                 const float a = q[c + sj], b = q[c - sj], e = q[c - 1 + sj], f = q[c - 1 - sj];
-                const float eq = (a - b + e - f) / (a + b + e + f + 1e-10f);
-                val = val - cu_v * eq / Gsu;
+                const float eq = fdiv(a - b + e - f, a + b + e + f + 1e-10f);
+                val = val - fdiv(cu_v * eq, Gsu);
             }
             if (k_in) {
                 const float a = q[c + sk], b = q[c - sk], e = q[c - 1 + sk], f = q[c - 1 - sk];
-                const float eq = (a - b + e - f) / (a + b + e + f + 1e-10f);
-                val = val - cu_w * eq / Gsu;
+                const float eq = fdiv(a - b + e - f, a + b + e + f + 1e-10f);
+                val = val - fdiv(cu_w * eq, Gsu);
             }
             r_u2 = val * 0.5f;
         }
@@ -202,19 +224,19 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
         float r_v2 = 0.0f;
         if (has_v) {
             const float l = q[c - sj];
-            float val = av * (q0 - l) / (q0 + l + 1e-10f);
+            float val = fdiv(av * (q0 - l), q0 + l + 1e-10f);
             {
                 float eq = 0.0f;
                 if (i_in) {
                     const float a = q[c + 1 - sj], b = q[c - 1], e = q[c + 1], f = q[c - 1 - sj];
-                    eq = (a - b + e - f) / (e + a + b + f + 1e-10f);
+                    eq = fdiv(a - b + e - f, e + a + b + f + 1e-10f);
                 }
-                val = val - cv_u * eq / Gsv;
+                val = val - fdiv(cv_u * eq, Gsv);
             }
             if (k_in) {
                 const float a = q[c + sk - sj], b = q[c - sk], e = q[c + sk], f = q[c - sk - sj];
-                const float eq = (a - b + e - f) / (a + b + e + f + 1e-10f);
-                val = val - cv_w * eq / Gsv;
+                const float eq = fdiv(a - b + e - f, a + b + e + f + 1e-10f);
+                val = val - fdiv(cv_w * eq, Gsv);
             }
             r_v2 = val * 0.5f;
         }
@@ -223,19 +245,19 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
         float r_w2 = 0.0f;
         if (has_w) {
             const float r = q[c + sk];
-            float val = aw * (r - q0) / (r + q0 + 1e-10f);
+            float val = fdiv(aw * (r - q0), r + q0 + 1e-10f);
             {
                 float eq = 0.0f;
                 if (i_in) {
                     const float a = q[c + 1 + sk], b = q[c - 1], e = q[c + 1], f = q[c - 1 + sk];
-                    eq = (a - b + e - f) / (e + a + b + f + 1e-10f);
+                    eq = fdiv(a - b + e - f, e + a + b + f + 1e-10f);
                 }
-                val = val - cw_u * eq / Gsw;
+                val = val - fdiv(cw_u * eq, Gsw);
             }
             if (j_in) {
                 const float a = q[c + sk + sj], b = q[c - sj], e = q[c + sj], f = q[c + sk - sj];
-                const float eq = (a - b + e - f) / (e + f + a + b + 1e-10f);
-                val = val - cw_v * eq / Gsw;
+                const float eq = fdiv(a - b + e - f, e + f + a + b + 1e-10f);
+                val = val - fdiv(cw_v * eq, Gsw);
             }
             r_w2 = val * 0.5f * dzc;
         }
@@ -284,8 +306,8 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
         fin_i2 = is_w ? (fmaxf(0.f, f0) - fminf(0.f, f0)) : 0.0f;
     }
 #undef SGN
-    const float beta_out_i = (a0 - qmin_i) / (fout_i + 1e-15f);
-    const float beta_in_i2 = (qmax_i2 - a1) / (fin_i2 + 1e-15f);
+    const float beta_out_i = fdiv(a0 - qmin_i, fout_i + 1e-15f);
+    const float beta_in_i2 = fdiv(qmax_i2 - a1, fin_i2 + 1e-15f);
     return fminf(fminf(1.f, beta_in_i2), beta_out_i) * U0;
 }
 __device__ __forceinline__ float limit_face(const float *__restrict__ q1f, const float *__restrict__ lf,
@@ -352,13 +374,13 @@ k_mpdata_final(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i,
         const float f1l = flux1(q[c - 1], q0, Ul);
         const float f3 = flux1(q0, q[c + sj], Vn);
         const float f4 = flux1(q[c - sj], q0, Vs);
-        float qq = q0 - ((f1r - f1l) + (f3 - f4)) / den_h;
+        float qq = q0 - fdiv((f1r - f1l) + (f3 - f4), den_h);
         if (bottom) {
-            qq = qq - flux1(q0, q[c + sk], Wt) / den_v;
+            qq = qq - fdiv(flux1(q0, q[c + sk], Wt), den_v);
         } else if (top) {
-            qq = qq - (q0 * Wt - flux1(q[c - sk], q0, Wb)) / den_v;   // Wt == 0 (adv_mpdata.f90:215,322)
+            qq = qq - fdiv(q0 * Wt - flux1(q[c - sk], q0, Wb), den_v);   // Wt == 0 (adv_mpdata.f90:215,322)
         } else {
-            qq = qq - (flux1(q0, q[c + sk], Wt) - flux1(q[c - sk], q0, Wb)) / den_v;
+            qq = qq - fdiv(flux1(q0, q[c + sk], Wt) - flux1(q[c - sk], q0, Wb), den_v);
         }
         out.p[m][c] = qq;
     }
@@ -455,10 +477,10 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
                 const float f1l = flux1(qxm1, q0, UL);
                 const float f3 = flux1(q0, qp1, VN);
                 const float f4 = flux1(qm1, q0, VS);
-                float qq = q0 - ((f1r - f1l) + (f3 - f4)) / den_h;
-                if (bottom) qq = qq - flux1(q0, qzp1, WT) / den_v;
-                else if (top) qq = qq - (q0 * WT - flux1(qzm1, q0, WB)) / den_v;
-                else qq = qq - (flux1(q0, qzp1, WT) - flux1(qzm1, q0, WB)) / den_v;
+                float qq = q0 - fdiv((f1r - f1l) + (f3 - f4), den_h);
+                if (bottom) qq = qq - fdiv(flux1(q0, qzp1, WT), den_v);
+                else if (top) qq = qq - fdiv(q0 * WT - flux1(qzm1, q0, WB), den_v);
+                else qq = qq - fdiv(flux1(q0, qzp1, WT) - flux1(qzm1, q0, WB), den_v);
                 out.p[m][c] = qq;
             }
             qm2 = qm1; qm1 = q0; q0 = qp1; qp1 = qp2; lm2 = lm1; lm1 = l0; l0 = lp1; lp1 = lp2;
