@@ -310,82 +310,6 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
     const float beta_in_i2 = fdiv(qmax_i2 - a1, fin_i2 + 1e-15f);
     return fminf(fminf(1.f, beta_in_i2), beta_out_i) * U0;
 }
-__device__ __forceinline__ float limit_face(const float *__restrict__ q1f, const float *__restrict__ lf,
-                                            const float *__restrict__ U2, int ca, int cface, int s,
-                                            int pos, int n, bool is_w)
-{
-    // ca = index of left cell a; cface = index where the face (a|b) is stored; face (a-1|a) is at
-    // cface - s and face (b|b+1) at cface + s for all three staggerings used here.
-    const bool first = (pos == 0), last = (pos + 1 == n - 1);
-    const float q0 = q1f[ca], q1 = q1f[ca + s], l0 = lf[ca], l1 = lf[ca + s];
-    float qm1 = 0, lm1 = 0, Um = 0, q2 = 0, l2 = 0, Up = 0;
-    if (!first) { qm1 = q1f[ca - s]; lm1 = lf[ca - s]; Um = U2[cface - s]; }
-    if (!last)  { q2 = q1f[ca + 2 * s]; l2 = lf[ca + 2 * s]; Up = U2[cface + s]; }
-    return fct_limit(qm1, q0, q1, q2, lm1, l0, l1, l2, Um, U2[cface], Up, first, last, is_w);
-}
-
-// ------------------------------------------------------------------------------------------------
-// A4+A2 fused: final donor-cell pass with per-scalar pseudo-velocities, limiting its own faces.
-//   qold = field before pass 1 ("l"), q1 = field after pass 1, out = new field (ping-pong partner)
-// ------------------------------------------------------------------------------------------------
-template <bool RHO, bool FCT>
-__global__ void __launch_bounds__(BX * BY)
-k_mpdata_final(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
-               const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
-{
-    const TileId tb = xcd_tile();
-    const int i = tb.x * BX + threadIdx.x;
-    const int k = tb.y * BY + threadIdx.y;
-    const int j = tb.z;
-    if (i >= d.nx || k >= d.nz) return;
-    const int c = d.idx(i, k, j);
-    const int sk = d.sk, sj = d.sj;
-    const bool interior = (i > 0) && (i < d.nx - 1) && (j > 0) && (j < d.ny - 1);
-    if (!interior) {
-        for (int m = 0; m < nv; ++m) out.p[m][c] = q1in.p[m][c];
-        return;
-    }
-    const float r = RHO ? rho[c] : 1.0f;
-    const float ja = jaco[c];
-    const float den_h = ja * r;
-    const float den_v = dz[c] * ja * r;
-    const bool bottom = (k == 0), top = (k == d.nz - 1);
-    for (int m = 0; m < nv; ++m) {
-        const float *__restrict__ q = q1in.p[m];
-        const float *__restrict__ l = qold.p[m];
-        const float *__restrict__ u2 = u2i.p[m];
-        const float *__restrict__ v2 = v2i.p[m];
-        const float *__restrict__ w2 = w2i.p[m];
-        float Ul, Ur, Vs, Vn, Wb = 0.0f, Wt = 0.0f;
-        if (FCT) {
-            Ul = limit_face(q, l, u2, c - 1, c, 1, i - 1, d.nx, false);
-            Ur = limit_face(q, l, u2, c, c + 1, 1, i, d.nx, false);
-            Vs = limit_face(q, l, v2, c - sj, c, sj, j - 1, d.ny, false);
-            Vn = limit_face(q, l, v2, c, c + sj, sj, j, d.ny, false);
-            if (!bottom) Wb = limit_face(q, l, w2, c - sk, c - sk, sk, k - 1, d.nz, true);
-            if (!top)    Wt = limit_face(q, l, w2, c, c, sk, k, d.nz, true);
-        } else {
-            Ul = u2[c]; Ur = u2[c + 1]; Vs = v2[c]; Vn = v2[c + sj];
-            if (!bottom) Wb = w2[c - sk];
-            if (!top)    Wt = w2[c];
-        }
-        const float q0 = q[c];
-        const float f1r = flux1(q0, q[c + 1], Ur);
-        const float f1l = flux1(q[c - 1], q0, Ul);
-        const float f3 = flux1(q0, q[c + sj], Vn);
-        const float f4 = flux1(q[c - sj], q0, Vs);
-        float qq = q0 - fdiv((f1r - f1l) + (f3 - f4), den_h);
-        if (bottom) {
-            qq = qq - fdiv(flux1(q0, q[c + sk], Wt), den_v);
-        } else if (top) {
-            qq = qq - fdiv(q0 * Wt - flux1(q[c - sk], q0, Wb), den_v);   // Wt == 0 (adv_mpdata.f90:215,322)
-        } else {
-            qq = qq - fdiv(flux1(q0, q[c + sk], Wt) - flux1(q[c - sk], q0, Wb), den_v);
-        }
-        out.p[m][c] = qq;
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // A4+A2 fused, second generation: every limited face is computed ONCE.
@@ -412,7 +336,6 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     const int j1 = min(j0 + FJB - 1, d.ny - 2);
     const int sk = d.sk, sj = d.sj;
     const bool in_i = (i <= d.nx - 1), in_k = (k <= d.nz - 1);
-    const bool valid = in_i && in_k;
     const bool wave_out = in_k && (ty <= FBY - 2 || k == d.nz - 1);          // wave-uniform
     const bool do_out = wave_out && (lane <= 62) && (i <= d.nx - 2);
     const bool bottom = (k == 0), top = (k == d.nz - 1);

@@ -125,7 +125,7 @@ __device__ void th_column(const ThState *__restrict__ T, float *qv1d, float *qc1
 {
     const float *sa = T->sa, *sb = T->sb;
     const float R1 = TH_R1, R2 = TH_R2, eps = TH_eps, T_0 = TH_T_0, PI2 = TH_PI2;
-    const float am_r = TH_am_r, am_i = TH_am_i, bm_r = TH_bm_r, bm_i = TH_bm_i, bm_g = TH_bm_g, mu_i = TH_mu_i, mu_g = TH_mu_g;
+    const float am_r = TH_am_r, am_i = TH_am_i, bm_i = TH_bm_i, bm_g = TH_bm_g, mu_i = TH_mu_i, mu_g = TH_mu_g;
     const float D0r = TH_D0r, D0c = TH_D0c, D0s = TH_D0s, D0g = TH_D0g, fv_r = TH_fv_r, lsub = TH_lsub, lvap0 = TH_lvap0;
     const float oRv = TH_oRv, olfus = TH_olfus, xm0i = TH_xm0i, C_cube = TH_C_cube, HGFR = TH_HGFR, rho_w = TH_rho_w;
     const float mu_r = T->mu_r, mu_c = T->mu_c, Nt_c = T->Nt_c, am_g = T->am_g, av_g = T->av_g, bv_g = T->bv_g;
