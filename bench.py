@@ -239,6 +239,10 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
                          "mp_ms_per_step": mp_ms_step},
+            # informational: the microphysics is VALU-bound, its share of the step and its algorithmic traffic
+            "microphysics": {"kernel": "k_thompson_pack" if args.mp == "thompson" else "k_mp_simple", "bound": "valu",
+                             "ms_per_step": mp_ms_step,
+                             "algorithmic_GBps": (mem_cells * (84 if args.mp == "thompson" else 56) / (mp_ms_step * 1e-3) / 1e9) if mp_ms_step > 0 else 0.0},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nscal)
