@@ -16,7 +16,7 @@ class IcarHipError(RuntimeError):
 SYMBOLS = [
     "icar_hip_ctx_create", "icar_hip_ctx_destroy", "icar_hip_set_stream", "icar_hip_synchronize",
     "icar_hip_field_upload", "icar_hip_field_download", "icar_hip_field_fill", "icar_hip_field_device_ptr",
-    "icar_hip_field_count", "icar_hip_field_elem_size", "icar_hip_setup_winds", "icar_hip_advect",
+    "icar_hip_field_count", "icar_hip_field_elem_size", "icar_hip_setup_winds", "icar_hip_advect", "icar_hip_advect_occupancy",
     "icar_hip_mp_simple", "icar_hip_thompson_init", "icar_hip_thompson", "icar_hip_thompson_tiles", "icar_hip_thompson_table", "icar_hip_mp_tiles",
     "icar_hip_max_courant", "icar_hip_balance_uvw", "icar_hip_diagnostic_update", "icar_hip_dqdt_upload",
     "icar_hip_apply_forcing", "icar_hip_enforce_limits", "icar_hip_halo_count", "icar_hip_halo_pack",

@@ -13,6 +13,8 @@
 // Arithmetic follows the reference's operation order; compiled with -ffp-contract=off and
 // IEEE division so the result is bit-identical to the CPU reference.
 #include "ctx.h"
+#include <vector>
+#include <algorithm>
 
 #define BX 64
 #define BY 4
@@ -53,12 +55,16 @@ __device__ __forceinline__ float flux1(float l, float r, float U)
 // them.  Here XCD x works on the contiguous range [x*n/8, (x+1)*n/8) of the (i fastest, then k, then j) tile order, so
 // the blocks that share planes run on the same XCD close together in time and the overlap hits in L2.
 struct TileId { int x, y, z; };
-__device__ __forceinline__ TileId xcd_tile()
+// rows: how many z-slices (j rows / j slabs) of tiles one XCD takes before the next XCD's turn.  A single contiguous
+// range per XCD (rows = gz/8) would share the most planes but hands each XCD one region of the domain -- clouds are not
+// spread evenly, and the launch then lasts as long as the cloudiest eighth.
+__device__ __forceinline__ TileId xcd_tile(unsigned rows)
 {
     const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
     unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned per = n / 8;
-    if (id < per * 8) id = (id % 8) * per + id / 8;      // the n % 8 tail blocks keep their place
+    const unsigned chunk = gx * gy * rows, super = chunk * 8;
+    const unsigned s = id / super, w = id % super;
+    if ((s + 1) * super <= n) id = s * super + (w % 8) * chunk + w / 8;      // the last partial super-chunk keeps its order
     TileId t;
     t.x = (int)(id % gx); t.y = (int)((id / gx) % gy); t.z = (int)(id / (gx * gy));
     return t;
@@ -71,7 +77,7 @@ k_setup_winds(Dims d, const float *__restrict__ u, const float *__restrict__ v, 
               const float *__restrict__ jw, const float *__restrict__ dz, float dt, float dx,
               float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float *__restrict__ Wdz)
 {
-    const TileId tb = xcd_tile();
+    const TileId tb = xcd_tile(4);
     const int i = tb.x * BX + threadIdx.x;
     const int k = tb.y * BY + threadIdx.y;
     const int j = tb.z;
@@ -105,17 +111,25 @@ template <bool RHO>
 __global__ void __launch_bounds__(BX * BY)
 k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
               const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ W,
-              const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
+              const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
+              unsigned char *__restrict__ occ)
 {
-    const TileId tb = xcd_tile();
+    const TileId tb = xcd_tile(4);
     const int i = tb.x * BX + threadIdx.x;
     const int k = tb.y * BY + threadIdx.y;
     const int j = tb.z;
     if (i >= d.nx || k >= d.nz) return;
     const int c = d.idx(i, k, j);
+    // occ[m][j][k][it] = 1 when the 64-cell row segment (it,k,j) of the OUTPUT of scalar m holds a non-zero (pre-cleared
+    // to 0; only ones are ever stored, so the two branches below cannot race)
+    const size_t oslot = ((size_t)j * d.nz + k) * gridDim.x + tb.x, ostride = (size_t)d.ny * d.nz * gridDim.x;
     const bool interior = (i > 0) && (i < d.nx - 1) && (j > 0) && (j < d.ny - 1);
     if (!interior) {
-        for (int m = 0; m < nv; ++m) out.p[m][c] = in.p[m][c];
+        for (int m = 0; m < nv; ++m) {
+            const float v = in.p[m][c];
+            out.p[m][c] = v;
+            if (occ && v != 0.0f) occ[(size_t)m * ostride + oslot] = 1;
+        }
         return;
     }
     const float Ur = U[c + 1], Ul = U[c], Vn = V[c + d.sj], Vs = V[c], Wt = W[c];
@@ -141,7 +155,38 @@ k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
             qq = qq - fdiv(flux1(q0, q[c + d.sk], Wt) - flux1(q[c - d.sk], q0, Wb), den_v);
         }
         out.p[m][c] = qq;
+        if (occ) {                                               // one store per wave, by its first lane holding a non-zero
+            const unsigned long long nzb = __ballot(qq != 0.0f);
+            if (nzb && (int)threadIdx.x == __ffsll((long long)nzb) - 1) occ[(size_t)m * ostride + oslot] = 1;
+        }
     }
+}
+
+// needf[m][block of k_mpdata_final2] = any non-zero of the pass-1 field within 2 cells of the block's outputs: outside of
+// that, the unlimited velocity of every face the block touches is zero, fct_limit returns it unchanged and the final
+// donor-cell pass reproduces the (zero) pass-1 field.
+__global__ void k_occ_blocks(const unsigned char *__restrict__ occ, unsigned char *__restrict__ needf, int nt, int nx, int nz, int ny, int nv,
+                             int gx, int gy, int gz, int fby, int fjb)
+{
+    // one wave per (scalar, block): the lanes stride over the (j, k, i-segment) entries of the block's neighbourhood
+    const size_t t = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    const size_t nb = (size_t)gx * gy * gz;
+    if (t >= nb * nv) return;
+    const int m = (int)(t / nb); const size_t r = t % nb;
+    const int bx = (int)(r % gx), by = (int)((r / gx) % gy), bz = (int)(r / ((size_t)gx * gy));
+    const int i0 = max(1 + bx * 63 - 2, 0) / 64, i1 = min(1 + bx * 63 + 63 + 2, nx - 1) / 64;
+    const int k0 = max(by * (fby - 1) - 2, 0), k1 = min(by * (fby - 1) + fby - 1 + 2, nz - 1);
+    const int j0 = max(1 + bz * fjb - 2, 0), j1 = min(1 + bz * fjb + fjb - 1 + 2, ny - 1);
+    const unsigned char *o = occ + (size_t)m * nt * nz * ny;
+    const int ni = i1 - i0 + 1, nk = k1 - k0 + 1, tot = ni * nk * (j1 - j0 + 1);
+    unsigned char any = 0;
+    for (int e = lane; e < tot; e += 64) {
+        const int ii = i0 + e % ni, kk = k0 + (e / ni) % nk, jj = j0 + e / (ni * nk);
+        any |= o[((size_t)jj * nz + kk) * nt + ii];
+    }
+    const bool w = __any(any != 0);
+    if (lane == 0) needf[t] = w ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -153,12 +198,31 @@ template <bool RHO>
 __global__ void __launch_bounds__(BX * BY)
 k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int nv,
                 const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ Wz,
-                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
+                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
+                const unsigned char *__restrict__ occ)
 {
-    const TileId tb = xcd_tile();
+    const TileId tb = xcd_tile(4);
     const int i = tb.x * BX + threadIdx.x;
     const int k = tb.y * BY + threadIdx.y;
     const int j = tb.z;
+    // (all 64 lanes take part: this runs before the lanes beyond nx leave)
+    // Which scalars have a non-zero anywhere in this row segment's stencil (the 27 neighbouring segments)?  The lanes
+    // share the 27 x nv flag bytes between them, one ballot per scalar: a handful of loads per wave, no extra pass.
+    unsigned needmask = ~0u;
+    if (occ) {
+        const int nt = (int)gridDim.x;
+        const size_t ostride = (size_t)d.ny * d.nz * nt;
+        needmask = 0;
+        const int lane = threadIdx.x;
+        for (int e = lane; e < 27 * nv; e += 64) {                 // e -> (scalar, neighbour)
+            const int m = e / 27, nb = e - m * 27;
+            const int jj = min(max(j + nb / 9 - 1, 0), d.ny - 1), kk = min(max(k + (nb / 3) % 3 - 1, 0), d.nz - 1);
+            const int ii = min(max(tb.x + nb % 3 - 1, 0), nt - 1);
+            if (occ[(size_t)m * ostride + ((size_t)jj * d.nz + kk) * nt + ii]) needmask |= 1u << m;
+        }
+        for (int dd = 32; dd > 0; dd >>= 1) needmask |= __shfl_xor(needmask, dd);
+        needmask = __builtin_amdgcn_readfirstlane(needmask);
+    }
     if (i >= d.nx || k >= d.nz) return;
     const int c = d.idx(i, k, j);
     const int sk = d.sk, sj = d.sj;
@@ -201,6 +265,10 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
     for (int m = 0; m < nv; ++m) {
         const float *__restrict__ q = qin.p[m];
         float *__restrict__ u2m = u2o.p[m], *__restrict__ v2m = v2o.p[m], *__restrict__ w2m = w2o.p[m];
+        if (!((needmask >> m) & 1u)) {                            // wave-uniform: the whole stencil of this row segment is zero
+            u2m[c] = 0.0f; v2m[c] = 0.0f; w2m[c] = 0.0f;
+            continue;
+        }
         const float q0 = q[c];
         // ---- U face (i-1 | i) : adv_mpdata.f90:134-168
         float r_u2 = 0.0f;
@@ -325,11 +393,12 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
 template <bool RHO, bool FCT>
 __global__ void __launch_bounds__(64 * FBY)
 k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
-                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz)
+                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
+                const unsigned char *__restrict__ needf)
 {
     __shared__ float s_wb[FBY][64];
     const int lane = threadIdx.x, ty = threadIdx.y;
-    const TileId tb = xcd_tile();
+    const TileId tb = xcd_tile(2);
     const int i = 1 + tb.x * 63 + lane;
     const int k = tb.y * (FBY - 1) + ty;
     const int j0 = 1 + tb.z * FJB;
@@ -341,7 +410,18 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     const bool bottom = (k == 0), top = (k == d.nz - 1);
     const int ic = in_i ? i : d.nx - 1, kc = in_k ? k : d.nz - 1;            // clamped => all loads stay in bounds
     const int cb = d.idx(ic, kc, 0);
+    unsigned needmask = ~0u;
+    if (needf) {
+        const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z, blk = tb.x + (size_t)gridDim.x * (tb.y + (size_t)gridDim.y * tb.z);
+        needmask = 0;
+        for (int m = 0; m < nv; ++m) needmask |= (needf[(size_t)m * nblk + blk] ? 1u : 0u) << m;
+        needmask = __builtin_amdgcn_readfirstlane(needmask);
+    }
     for (int m = 0; m < nv; ++m) {
+        if (!((needmask >> m) & 1u)) {                            // block-uniform: pass-1 field is zero within 2 cells
+            if (do_out) for (int j = j0; j <= j1; ++j) out.p[m][cb + j * sj] = 0.0f;
+            continue;
+        }
         const float *__restrict__ q = q1in.p[m];
         const float *__restrict__ l = qold.p[m];
         const float *__restrict__ u2 = u2i.p[m];
@@ -468,6 +548,34 @@ int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int
     return 0;
 }
 
+// fraction of row segments (fluxes) / blocks (final pass) of the last MPDATA call that were NOT skipped, per scalar slot
+int icar_advect_occupancy(icar_hip_ctx *c, int n, float *frac_fluxes, float *frac_final)
+{
+    if (!c->occ) { icar_set_error("advect_occupancy: no MPDATA call with occupancy flags yet"); return 1; }
+    const int nt = (c->d.nx + BX - 1) / BX, nz = c->d.nz, ny = c->d.ny;
+    const size_t per1 = (size_t)nt * nz * ny;
+    const size_t perf = (size_t)((c->d.nx - 1 + 62) / 63) * ((nz - 1 + 8 - 2) / (8 - 1)) * ((ny - 2 + 8 - 1) / 8);
+    std::vector<unsigned char> h1(per1 * n), hf(perf * n);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(h1.data(), c->occ, h1.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hf.data(), c->needf, hf.size(), hipMemcpyDeviceToHost));
+    for (int m = 0; m < n; ++m) {
+        size_t a = 0, b = 0;
+        const unsigned char *o = h1.data() + m * per1;
+        for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) for (int it = 0; it < nt; ++it) {
+            bool any = false;                                   // same 27-neighbour test as k_mpdata_fluxes
+            for (int jj = std::max(j - 1, 0); jj <= std::min(j + 1, ny - 1) && !any; ++jj)
+                for (int kk = std::max(k - 1, 0); kk <= std::min(k + 1, nz - 1) && !any; ++kk)
+                    for (int ii = std::max(it - 1, 0); ii <= std::min(it + 1, nt - 1); ++ii)
+                        if (o[((size_t)jj * nz + kk) * nt + ii]) { any = true; break; }
+            a += any;
+        }
+        for (size_t t = 0; t < perf; ++t) b += hf[m * perf + t] != 0;
+        frac_fluxes[m] = (float)a / per1; frac_final[m] = (float)b / perf;
+    }
+    return 0;
+}
+
 int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_density, const int *fields, int n)
 {
     if (!c->winds_valid) { icar_set_error("advect: call icar_hip_setup_winds first"); return 1; }
@@ -506,26 +614,43 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     };
     if (order == 1) {
         // q -> alt, swap  (upwind; or mpdata_order=1: adv_mpdata.f90:374,404-411)
-        if (advect_density) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz);
-        else                hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz);
+        if (advect_density) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz, (unsigned char *)nullptr);
+        else                hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz, (unsigned char *)nullptr);
         HIPCHK(hipGetLastError());
         swap_fields();
         return 0;
     }
+    // Occupancy of the pass-1 fields: hydrometeor fields are zero over large parts of the domain, and a row segment
+    // (fluxes) / block (final pass) whose whole stencil is zero produces exact zeros -- skipped, wave/block-uniformly.
+    const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + FJB - 1) / FJB), bf(64, FBY);
+    const int nt = (int)g.x;
+    const size_t occ_n = (size_t)ICAR_MAX_ADV * nt * c->d.nz * c->d.ny, nf_n = (size_t)ICAR_MAX_ADV * gf.x * gf.y * gf.z;
+    static const bool no_skip = getenv("ICAR_HIP_MPDATA_NO_SKIP") != nullptr;      // A/B switch for profiling
+    if (!c->occ && !no_skip) {
+        HIPCHK(hipMalloc(&c->occ, occ_n)); HIPCHK(hipMalloc(&c->needf, nf_n));
+    }
+    unsigned char *occ = no_skip ? nullptr : c->occ;
+    if (occ) HIPCHK(hipMemsetAsync(occ, 0, (size_t)n * nt * c->d.nz * c->d.ny, c->stream));
     // iord = 1 : q -> q2
-    if (advect_density) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, q, q2, n, c->U, c->V, c->W, rho, jaco, dz);
-    else                hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, q, q2, n, c->U, c->V, c->W, rho, jaco, dz);
+    if (advect_density) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, q, q2, n, c->U, c->V, c->W, rho, jaco, dz, occ);
+    else                hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, q, q2, n, c->U, c->V, c->W, rho, jaco, dz, occ);
+    if (occ) {
+        const size_t n2 = (size_t)n * gf.x * gf.y * gf.z;
+        hipLaunchKernelGGL(k_occ_blocks, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, c->stream, occ, c->needf, nt, c->d.nx, c->d.nz, c->d.ny, n,
+                           (int)gf.x, (int)gf.y, (int)gf.z, FBY, FJB);
+    }
     for (int iord = 2; iord <= order; ++iord) {
+        // the flags describe the pass-1 field of the first corrective iteration only
+        const unsigned char *need1 = (occ && iord == 2) ? occ : nullptr, *needf = (occ && iord == 2) ? c->needf : nullptr;
         // pseudo-velocities from q2 with the ORIGINAL U_m,V_m,W_m/dz (adv_mpdata.f90:379)
-        if (advect_density) hipLaunchKernelGGL((k_mpdata_fluxes<true>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz);
-        else                hipLaunchKernelGGL((k_mpdata_fluxes<false>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz);
+        if (advect_density) hipLaunchKernelGGL((k_mpdata_fluxes<true>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
+        else                hipLaunchKernelGGL((k_mpdata_fluxes<false>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
         // limiter (l = q, q1 = q2) fused into the donor-cell pass q2 -> alt ; then q := alt
         {
             const int nring = 2 * c->d.nx * c->d.nz + 2 * c->d.nz * (c->d.ny - 2);
             hipLaunchKernelGGL(k_copy_ring, dim3((nring + 255) / 256), dim3(256), 0, c->stream, c->d, q2c, alt, n);
         }
-        const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + FJB - 1) / FJB), bf(64, FBY);
-#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final2<R, F>), gf, bf, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz)
+#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final2<R, F>), gf, bf, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz, needf)
         if (advect_density) { if (fct) FINAL(true, true); else FINAL(true, false); }
         else                { if (fct) FINAL(false, true); else FINAL(false, false); }
 #undef FINAL

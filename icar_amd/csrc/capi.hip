@@ -283,6 +283,8 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     float *scr[] = {c->U, c->V, c->W, c->Wdz, c->q2, c->u2, c->v2, c->w2, c->d_red};
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
+    if (c->occ) hipFree(c->occ);
+    if (c->needf) hipFree(c->needf);
     icar_thompson_free(c);
     icar_linwinds_free(c);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -367,6 +369,13 @@ int icar_hip_advect(icar_hip_ctx *c, int scheme, int mpdata_order, int fct, int 
 {
     if (!c || (!fields && nfields > 0)) { icar_set_error("advect: null argument"); return 1; }
     return icar_advect_run(c, scheme, mpdata_order, fct, advect_density, fields, nfields);
+}
+
+int icar_hip_advect_occupancy(icar_hip_ctx *c, int nfields, float *frac_fluxes, float *frac_final)
+{
+    if (!c || !frac_fluxes || !frac_final || nfields < 1 || nfields > ICAR_MAX_ADV) { icar_set_error("advect_occupancy: bad argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_advect_occupancy(c, nfields, frac_fluxes, frac_final);
 }
 
 int icar_hip_mp_simple(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_count)

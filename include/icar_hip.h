@@ -108,6 +108,12 @@ int icar_hip_setup_winds(icar_hip_ctx *ctx, int scheme, float dt, float dx, int 
 int icar_hip_advect(icar_hip_ctx *ctx, int scheme, int mpdata_order, int fct, int advect_density,
                     const int *fields, int nfields);
 
+/* Diagnostic of the last MPDATA call: hydrometeor fields are zero over large parts of the domain and the kernels skip
+ * row segments / blocks whose whole stencil is zero (the result there is exactly zero).  Returns, per scalar in the
+ * order of the fields[] of that call, the fraction of row segments (pseudo-velocity kernel) and of blocks (final pass)
+ * that had to be computed. */
+int icar_hip_advect_occupancy(icar_hip_ctx *ctx, int nfields, float *frac_fluxes, float *frac_final);
+
 /* ---- M1: mp_simple_driver (src/physics/mp_simple.f90:595-646) on the tile its..kte -----------
  * uses PRESSURE, POTENTIAL_TEMPERATURE, EXNER, DENSITY, WATER_VAPOR, CLOUD_WATER, RAIN, SNOW,
  * DZ_MASS; adds the tile's surface fluxes to PRECIPITATION / SNOWFALL exactly as

@@ -95,3 +95,43 @@ def test_full_size_properties():
     # a blob far from the boundary moves but keeps its mass (sum over a window that contains it)
     s0 = q0[64:-64, :, 64:-64].astype(np.float64).sum(); s1 = q[64:-64, :, 64:-64].astype(np.float64).sum()
     assert abs(s1 - s0) / s0 < 5e-3
+
+
+@pytest.mark.parametrize("fct", [True, False])
+def test_mpdata_sparse_fields_skip_zero_regions(oracle, fct):
+    """Hydrometeor-like fields: zero almost everywhere with small blobs that straddle the 64-cell row segments, the
+    8-level chunks and the 8-row marches of the kernels.  The kernels skip row segments / blocks whose stencil is all
+    zero (icar_hip_advect_occupancy reports how much); the result must stay bit-identical to the oracle, which
+    computes every cell."""
+    import ctypes
+    from icar_amd.capi import lib, check
+    nx, ny, nz = 200, 45, 20
+    c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.01, n_hydro=1)
+    rng = np.random.default_rng(7)
+    names = ["water_vapor", "cloud_water", "rain", "snow", "cloud_ice"]
+    blobs = {"cloud_water": [(62, 5, 7), (129, 16, 8), (190, 30, 0)], "rain": [(1, 1, 1), (198, 43, 18), (64, 24, 9)],
+             "snow": [(100, 20, 10)], "cloud_ice": []}
+    for n, bl in blobs.items():
+        a = np.zeros((ny, nz, nx), np.float32)
+        for (i, j, k) in bl:
+            sl = (slice(max(j - 1, 0), j + 2), slice(max(k - 1, 0), k + 2), slice(max(i - 2, 0), i + 3))
+            a[sl] = np.float32(1e-4) * (1 + rng.random(a[sl].shape)).astype(np.float32)
+        c[n] = a
+    dt = ideal.cfl_dt(c)
+    q = np.stack([c[n] for n in names]).copy()
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.adv_options.flux_corrected_transport = fct
+    opt.advect_vars([KVAR[n] for n in names])
+    for step in range(3):
+        oracle.advect(kADV_MPDATA, q, *adv_args(c), dt, fct=fct, nsteps=1)
+        advect(d, opt, dt)
+        ff = (ctypes.c_float * len(names))(); fb = (ctypes.c_float * len(names))()
+        check(lib().icar_hip_advect_occupancy(d.ctx, len(names), ff, fb), "advect_occupancy")
+        for m, n in enumerate(names):
+            got = d.get(MEMBER[n])
+            assert bits_equal(got, q[m]), f"step {step} {n}: {nbitdiff(got, q[m])} cells differ"
+    # advection order: qv, cloud_water, rain, snow, cloud_ice -> slots 0..4
+    assert ff[0] == 1.0 and fb[0] == 1.0                     # water vapour is dense
+    assert 0 < ff[1] < 0.5 and 0 < fb[2] < 0.7, (list(ff), list(fb))
+    assert ff[4] == 0.0 and fb[4] == 0.0                     # an all-zero field is skipped entirely
+    d.close()
