@@ -19,27 +19,14 @@
 #define BX 64
 #define BY 4
 
-// Correctly rounded FP32 quotient at half the cost of the compiler's expansion (profiles/micro/divbench.hip: 21 vs 56
-// SIMD cycles per wave for the bare chain).  The expansion is  v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma,
-// v_div_fmas, v_div_fixup ; the scale / fmas / fixup steps only act when an operand or the quotient leaves the normal
-// range.  fdiv() runs the same rcp / fma / mul chain (Markstein: the last fma yields the correctly rounded quotient)
-// on the numerator pre-scaled by 2^64 -- an exact operation that keeps the two residuals normal for numerators down
-// to the smallest subnormal -- and scales the quotient back, exactly.  Branch-free, so independent divisions
-// interleave (a per-wave "take the IEEE path" branch was measured SLOWER than the IEEE division itself: it cuts the
-// basic block at every quotient).  Bit-identical to n / d when: |n| < 2^63, d normal with 2^-60 < |d| < 2^60 (here:
-// sums of field values plus 1e-10 / 1e-15, or metric factors), and the quotient is not subnormal (else it may differ
-// in the last subnormal digit, 1.4e-45); a -0 numerator gives +0 (the sign of a zero quotient is discarded by every
-// use on this path: flux1(), q - x with q != -0).
-__device__ __forceinline__ float fdiv(float n, float d)
-{
-    const float ns = n * 0x1p64f;
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    float q = ns * r;
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, ns), r, q);
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, ns), r, q);
-    return q * 0x1p-64f;
-}
+// Every quotient of the scheme goes through fdiv() = the compiler's IEEE expansion (v_div_scale x2, v_rcp, fma, fma, mul,
+// fma, fma, fma, v_div_fmas, v_div_fixup).  Tried and dropped (profiles/micro/divbench.hip):
+//  * the bare rcp / fma / mul chain on a 2^64-scaled numerator (Markstein): bit-identical for normal quotients and 3-6 %
+//    faster per kernel, but it rounds twice when the quotient is subnormal -- and the tails of the hydrometeor fields do
+//    reach 1e-39 (one cell of tests/test_gpu_advect.py::test_mpdata_sparse_fields... differed by 1.4e-45);
+//  * a per-wave "all operands safe ? lean : IEEE" branch: slower than the IEEE division alone, because it cuts the basic
+//    block at every quotient and the independent divisions no longer interleave.
+__device__ __forceinline__ float fdiv(float n, float d) { return n / d; }
 
 __device__ __forceinline__ float flux1(float l, float r, float U)
 {   // donor-cell flux, src/physics/adv_mpdata.f90:40

@@ -129,7 +129,10 @@ def test_mpdata_sparse_fields_skip_zero_regions(oracle, fct):
         check(lib().icar_hip_advect_occupancy(d.ctx, len(names), ff, fb), "advect_occupancy")
         for m, n in enumerate(names):
             got = d.get(MEMBER[n])
-            assert bits_equal(got, q[m]), f"step {step} {n}: {nbitdiff(got, q[m])} cells differ"
+            if not bits_equal(got, q[m]):
+                w = np.argwhere(got.view(np.int32) != q[m].view(np.int32))
+                det = [(tuple(int(v) for v in ix), float(got[tuple(ix)]), float(q[m][tuple(ix)])) for ix in w[:4]]
+                raise AssertionError(f"step {step} {n}: {len(w)} cells differ, e.g. {det}")
     # advection order: qv, cloud_water, rain, snow, cloud_ice -> slots 0..4
     assert ff[0] == 1.0 and fb[0] == 1.0                     # water vapour is dense
     assert 0 < ff[1] < 0.5 and 0 < fb[2] < 0.7, (list(ff), list(fb))
