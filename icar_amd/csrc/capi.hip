@@ -215,12 +215,20 @@ __global__ void k_balance_uvw(Dims d, const float *__restrict__ u, const float *
     }
 }
 
-int icar_balance_uvw_run(icar_hip_ctx *c, float dx)
+int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update)
 {
-    const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V);
+    // update != 0: wind.f90:341-360 balances the forcing tendencies u/v/w%meta_data%dqdt_3d instead of the winds
+    const float *u = update ? c->dqdt[ICAR_F_U] : icar_field_f(c, ICAR_F_U), *v = update ? c->dqdt[ICAR_F_V] : icar_field_f(c, ICAR_F_V);
     const float *ju = icar_field_f(c, ICAR_F_JACOBIAN_U), *jv = icar_field_f(c, ICAR_F_JACOBIAN_V);
     const float *jw = icar_field_f(c, ICAR_F_JACOBIAN_W), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
-    float *w = icar_field_f(c, ICAR_F_W, false);
+    float *w = nullptr;
+    if (update) {
+        if (!c->dqdt[ICAR_F_W]) {
+            if (icar_hip_check(hipMalloc(&c->dqdt[ICAR_F_W], c->n3 * sizeof(float)), "hipMalloc(dqdt w)")) return 1;
+        }
+        w = c->dqdt[ICAR_F_W];
+        if (!u || !v) { icar_set_error("balance_uvw(update): upload the u and v dqdt_3d first (icar_hip_dqdt_upload)"); return 1; }
+    } else w = icar_field_f(c, ICAR_F_W, false);
     if (!u || !v || !ju || !jv || !jw || !dz || !w) return 1;
     dim3 g((c->d.nx + 63) / 64, c->d.ny), b(64);
     hipLaunchKernelGGL(k_balance_uvw, g, b, 0, c->stream, c->d, u, v, w, ju, jv, jw, dz, dx);
@@ -466,7 +474,22 @@ int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
 int icar_hip_balance_uvw(icar_hip_ctx *c, float dx)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
-    return icar_balance_uvw_run(c, dx);
+    return icar_balance_uvw_run(c, dx, 0);
+}
+
+int icar_hip_balance_uvw_update(icar_hip_ctx *c, float dx)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_balance_uvw_run(c, dx, 1);
+}
+
+int icar_hip_dqdt_download(icar_hip_ctx *c, int f, void *host)
+{
+    if (!c || !host) { icar_set_error("dqdt_download: null argument"); return 1; }
+    if (f < 0 || f >= ICAR_N_FIELDS || field_is_2dd(f) || !c->dqdt[f]) { icar_set_error("dqdt_download: no dqdt mirror for this field"); return 1; }
+    HIPCHK(hipMemcpyAsync(host, c->dqdt[f], icar_field_count(c, f) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int icar_hip_linwinds_setup(icar_hip_ctx *c, const icar_hip_lt_options *opt, const float *global_terrain,

@@ -84,6 +84,12 @@ class domain_t:
             raise ValueError(f"dqdt {name}: shape {a.shape} != {self.shape(fid)}")
         check(lib().icar_hip_dqdt_upload(self.ctx, fid, a.ctypes.data_as(ctypes.c_void_p)), f"dqdt_upload {name}")
 
+    def get_dqdt(self, name):
+        fid = self.fid(name)
+        a = np.empty(self.shape(fid), np.float32)
+        check(lib().icar_hip_dqdt_download(self.ctx, fid, a.ctypes.data_as(ctypes.c_void_p)), f"dqdt_download {name}")
+        return a
+
     def apply_forcing(self, dt_seconds, forced):
         """domain%apply_forcing(dt) (domain_obj.f90:2383-2448). forced = [(name, force_boundaries), ...];
         include ("w", False) like the reference's separate w update."""

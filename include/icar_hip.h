@@ -163,12 +163,16 @@ int icar_hip_diagnostic_update(icar_hip_ctx *ctx);
  * rows) get  x += dqdt*dt ; otherwise the whole field does (u, v, w, pressure ...).  dt is REAL(8)
  * like time_delta_t%seconds(). */
 int icar_hip_dqdt_upload(icar_hip_ctx *ctx, int field, const void *host);
+int icar_hip_dqdt_download(icar_hip_ctx *ctx, int field, void *host);
 int icar_hip_apply_forcing(icar_hip_ctx *ctx, double dt_seconds, const int *fields, const int *force_boundaries, int nfields,
                            int west_boundary, int east_boundary, int south_boundary, int north_boundary);
 int icar_hip_enforce_limits(icar_hip_ctx *ctx, const int *fields, int nfields);
 
 /* ---- W1: balance_uvw (src/physics/wind.f90:81-169): w from the horizontal divergence ---------- */
 int icar_hip_balance_uvw(icar_hip_ctx *ctx, float dx);
+/* same on u/v/w%meta_data%dqdt_3d -- the form update_winds uses at every forcing step after the first
+ * (src/physics/wind.f90:341-360); the w tendency mirror is created if needed. */
+int icar_hip_balance_uvw_update(icar_hip_ctx *ctx, float dx);
 
 /* ---- W3: linear-theory wind look-up table (src/physics/linear_winds.f90) ----------------------
  * options%lt_options (src/objects/options_obj.f90:1400-1530; defaults there: buffer 50, stability_window_size 10,
