@@ -1,0 +1,158 @@
+// icar_amd/csrc/column_comm.h -- how the levels of a column talk to each other when every thread owns ONE level.
+//   WaveComm  : one column per wave, level = lane; wave shuffles / ballot.  nz of 64 lanes are busy.
+//   BlockComm : cpb whole columns per block, thread = level*cpb + column (column fastest: a wave spans few levels of
+//               neighbouring columns => coalesced rows and little divergence); the couplings go through LDS.
+// Used by the Thompson column (thompson_lane.inc) and by mp_simple (mp_simple.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct WaveComm {
+    int k; bool active;
+    __device__ __forceinline__ WaveComm(int lane, int nz) : k(lane), active(lane < nz) {}
+    __device__ __forceinline__ bool any(bool p) { return __any(p); }
+    // min over levels >= own (inactive top lanes pass the neutral element)
+    __device__ __forceinline__ double suffix_min(double v)
+    {
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const double o_ = __shfl_down(v, dd);
+            if (k + dd < 64) v = fmin(v, o_);
+        }
+        return v;
+    }
+    // nearest level >= own that "has" the species (inactive top lanes have has=1, value 0 == vtXk(kte+1) = 0)
+    __device__ __forceinline__ void carry_down2(float &a, float &b, int has)
+    {
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const float oa = __shfl_down(a, dd), ob = __shfl_down(b, dd);
+            const int oh = __shfl_down(has, dd);
+            if (!has && k + dd < 64) { a = oa; b = ob; has = oh; }
+        }
+        if (!has) { a = 0.f; b = 0.f; }
+    }
+    // ksed1 = highest level with a sedimenting particle (kts if none; kte -> kte-1), onstep = 1/max(nstep) (:2548-2555)
+    __device__ __forceinline__ void sed_plan(int cond, int ns, int kte, int &ksed1, float &onstep)
+    {
+        const unsigned long long m = __ballot(cond);
+        ksed1 = m ? (63 - __clzll((long long)m)) : 0;
+        for (int dd = 32; dd > 0; dd >>= 1) { const int o = __shfl_xor(ns, dd); ns = ns > o ? ns : o; }
+        if (ksed1 == kte) ksed1 = kte - 1;
+        onstep = (ns > 0) ? 1.f / (float)ns : 1.0f;
+    }
+    __device__ __forceinline__ int loop_max(int n) { return n; }           // one column per wave: already uniform
+    __device__ __forceinline__ void up2(float x, float y, float &ux, float &uy) { ux = __shfl_down(x, 1); uy = __shfl_down(y, 1); }
+    __device__ __forceinline__ float up1(float x) { return __shfl_down(x, 1); }
+};
+
+// cpb whole columns per block of nt >= cpb*nz threads; thread = level*cpb + column.  LDS (dynamic):
+// double d[nt] | float f[2][2][nt] | int has[nt] | int colmax[2][cpb+1] | int blkmax
+struct BlockComm {
+    double *sd; float *sf; int *shas, *scolmax, *sblkmax;
+    int tid, nt, k, col, cpb, nz; bool active; unsigned step;
+    __host__ __device__ static size_t lds_bytes(int nt, int cpb) { return (size_t)nt * (8 + 16 + 4) + (size_t)(2 * (cpb + 1) + 1) * 4; }
+    // col_ok: this thread's column lies inside the tile (blocks are aligned to multiples of cpb columns)
+    __device__ __forceinline__ BlockComm(void *lds, int tid_, int nt_, int cpb_, int nz_, int col_lo, int col_hi)
+        : tid(tid_), nt(nt_), cpb(cpb_), nz(nz_), step(0)
+    {
+        sd = (double *)lds; sf = (float *)(sd + nt); shas = (int *)(sf + 4 * nt); scolmax = shas + nt; sblkmax = scolmax + 2 * (cpb + 1);
+        const bool in = tid < cpb * nz;
+        k = in ? tid / cpb : nz - 1;            // idle threads sit at "kte" of a dummy column: they never read upward
+        col = in ? tid - k * cpb : cpb;
+        active = in && col >= col_lo && col <= col_hi;
+        if (!active) { k = nz - 1; }
+    }
+    __device__ __forceinline__ float &F(int b, int w, int t) { return sf[(b * 2 + w) * nt + t]; }
+    __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p); }
+    __device__ __forceinline__ double suffix_min(double v)
+    {
+        __syncthreads();
+        sd[tid] = v;
+        __syncthreads();
+        if (active) for (int kk = k + 1; kk < nz; ++kk) v = fmin(v, sd[kk * cpb + col]);
+        return v;
+    }
+    __device__ __forceinline__ void carry_down2(float &a, float &b, int has)
+    {
+        __syncthreads();
+        F(0, 0, tid) = a; F(0, 1, tid) = b; shas[tid] = has;
+        __syncthreads();
+        if (!has) {                              // only active threads can have has == 0
+            int kk = k + 1;
+            while (kk < nz && !shas[kk * cpb + col]) ++kk;
+            if (kk < nz) { a = F(0, 0, kk * cpb + col); b = F(0, 1, kk * cpb + col); }
+            else { a = 0.f; b = 0.f; }
+        }
+        step = 0;                                // f[0] was just used: the next up*() starts on f[1]
+    }
+    __device__ __forceinline__ void sed_plan(int cond, int ns, int kte, int &ksed1, float &onstep)
+    {
+        __syncthreads();
+        if (tid <= cpb) { scolmax[tid] = 0; scolmax[cpb + 1 + tid] = 0; }
+        __syncthreads();
+        if (cond) atomicMax(&scolmax[col], k);
+        if (ns > 0) atomicMax(&scolmax[cpb + 1 + col], ns);
+        __syncthreads();
+        ksed1 = scolmax[col]; ns = scolmax[cpb + 1 + col];
+        if (ksed1 == kte) ksed1 = kte - 1;
+        onstep = (ns > 0) ? 1.f / (float)ns : 1.0f;
+    }
+    // per-column OR / maximum of a non-negative float (bit patterns of non-negative floats order like integers)
+    __device__ __forceinline__ bool col_any(bool p)
+    {
+        __syncthreads();
+        if (tid <= cpb) scolmax[tid] = 0;
+        __syncthreads();
+        if (p) scolmax[col] = 1;
+        __syncthreads();
+        return scolmax[col] != 0;
+    }
+    __device__ __forceinline__ float col_max_pos(float v)
+    {
+        __syncthreads();
+        if (tid <= cpb) scolmax[tid] = 0;
+        __syncthreads();
+        if (active) atomicMax(&scolmax[col], __float_as_int(v));
+        __syncthreads();
+        return __int_as_float(scolmax[col]);
+    }
+    __device__ __forceinline__ int loop_max(int n)
+    {
+        __syncthreads();
+        if (tid == 0) *sblkmax = 0;
+        __syncthreads();
+        if (active) atomicMax(sblkmax, n);
+        __syncthreads();
+        return *sblkmax;
+    }
+    // value(s) of the level above in my column; alternating buffers => one barrier per sub-step
+    __device__ __forceinline__ void up2(float x, float y, float &ux, float &uy)
+    {
+        const int b = (int)((++step) & 1u);
+        F(b, 0, tid) = x; F(b, 1, tid) = y;
+        __syncthreads();
+        const bool u = active && k + 1 < nz;
+        ux = u ? F(b, 0, tid + cpb) : 0.f; uy = u ? F(b, 1, tid + cpb) : 0.f;
+    }
+    __device__ __forceinline__ float up1(float x)
+    {
+        const int b = (int)((++step) & 1u);
+        F(b, 0, tid) = x;
+        __syncthreads();
+        return (active && k + 1 < nz) ? F(b, 0, tid + cpb) : 0.f;
+    }
+};
+
+
+// Block geometry for BlockComm: cpb = floor(nt/nz) whole columns per nt-thread block.  nt is a multiple of 256 (4 waves
+// per SIMD step): 320- or 640-thread blocks (5 / 10 waves) load the CU's SIMDs unevenly and measured 1.5x slower than
+// 256.  A bigger block is taken only for a clear (>10 %) gain in busy threads, because its barriers cost more.
+// Returns the fraction of busy threads (0 when nz > 1024).
+static inline float block_comm_geometry(int nz, int &nt, int &cpb)
+{
+    float best = 0.0f; nt = 0; cpb = 0;
+    for (int t = 256; t <= 1024; t *= 2) {
+        if (t < nz) continue;
+        const float u = (float)((t / nz) * nz) / t;
+        if (u > best + (nt ? 0.10f : 0.0f)) { best = u; nt = t; cpb = t / nz; }
+    }
+    return best;
+}

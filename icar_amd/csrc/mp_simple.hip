@@ -2,14 +2,21 @@
 //
 // Reference algorithm: src/physics/mp_simple.f90 (driver :595-646, column :481-566, per-level
 // conversions :381-420, saturation adjustment :198-280, sedimentation :437-459).
-// Design: one column per lane with lanes along i, so every level-k access of a wave is one
-// coalesced 256-B row.  The five mutable column species (T, qv, qc, qr, qs) are staged in LDS as
-// [species][k][lane] (lane-contiguous => bank-conflict free) for the whole column lifetime; the
-// read-only p, rho, dz stream from global (L2-resident).  FP32 throughout like the reference;
+// Design (k_mp_simple_pack): one LEVEL per thread, whole columns packed into a 256-thread block (thread = level*cpb +
+// column, column_comm.h).  The scheme is per-level work -- the saturation iteration (:198-280), the conversions and the
+// evaporation sweep after every fall sub-step -- coupled only by the fall fluxes: flux(k+1) of the level above is read
+// through LDS once per sub-step (mp_simple.f90:437-459 only ever uses the not-yet-modified q(k+1), so all levels of a
+// sub-step are independent), and the column-wide "any rain / snow" and CFL numbers are LDS reductions.  State lives in
+// registers; 16 waves per CU instead of the 3 the first version (k_mp_simple: one column per lane, 51 kB of LDS per
+// 64 columns) could keep resident.  FP32 throughout like the reference;
 // exp() is evaluated in FP64 and rounded once so that it agrees with the host libm's correctly
 // rounded expf in all but ~1e-3 of evaluations (documented tolerance in tests/).
 #include "ctx.h"
+#include "fp64_math.h"
+#include "column_comm.h"
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 #define MPS_LANES 64
 
@@ -18,7 +25,7 @@ constexpr float LH_vapor = 2.26E6f, dLHvdt = 2400.0f, LH_liquid = 3.34E5f, heat_
 constexpr float SMALL_VALUE = 1E-30f, freezing_threshold = 273.15f;
 constexpr float snow_fall_rate = 1.5f, rain_fall_rate = 10.0f, snow_cloud_init = 0.0001f, rain_cloud_init = 0.0001f;
 
-__device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float expf_cr(float x) { return (float)d_exp((double)x); }
 
 __device__ __forceinline__ float sat_mr(float temperature, float pressure)
 {   // mp_simple.f90:146-182
@@ -216,6 +223,89 @@ k_mp_simple(Dims d, const float *__restrict__ pressure, float *__restrict__ th, 
     snow_acc[c2] = snow_acc[c2] + snow;
     if (err) atomicAdd(err_count, 1);
 }
+
+// one level of one column per thread; see the header comment.  All threads of the block run the same sub-step loops.
+__global__ void __launch_bounds__(1024, 4)
+k_mp_simple_pack(Dims d, const float *__restrict__ pressure, float *__restrict__ th, const float *__restrict__ pii,
+                 const float *__restrict__ rho, float *__restrict__ qv_g, float *__restrict__ qc_g,
+                 float *__restrict__ qr_g, float *__restrict__ qs_g, const float *__restrict__ dz,
+                 double *__restrict__ precip_acc, double *__restrict__ snow_acc,
+                 float dt, float cloud2rain, float cloud2snow,
+                 int i0, int i1, int j0, int kts, int kte, int cpb, int ib0, int *__restrict__ err_count)
+{
+    extern __shared__ double lds_pack[];
+    const int nz = d.nz;
+    const int first = (ib0 + blockIdx.x) * cpb;
+    BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nz, i0 - first, i1 - first);
+    const int j = j0 + blockIdx.y;
+    const int i = x.active ? first + x.col : max(i0, min(i1, first));
+    const int k = x.k;
+    const int c = d.idx(i, k, j);
+    const float pi_ = pii[c], p = pressure[c], rh = rho[c], dzk = dz[c];
+    float T = th[c] * pi_, qv = qv_g[c], qc = qc_g[c], qr = qr_g[c], qs = qs_g[c];
+    int err = 0;
+    float rain = 0.0f, snow = 0.0f;
+    const float L_melt = -1 * LH_liquid;
+    const bool in_k = x.active && k >= kts && k <= kte;
+    const int top = (kte < nz - 2) ? kte : nz - 2;
+    if (in_k) mp_conversions(p, T, qv, qc, qr, qs, cloud2rain, cloud2snow, err);
+    // one fall sub-step of species q (:437-459): F = flux leaving this level, upF = flux arriving from the level above
+#define MPS_SEDIMENT(q, vfall, acc)                                                                   \
+    {                                                                                                 \
+        const float F = vfall * q * rh;                                                               \
+        const float upF = x.up1(F);                                                                   \
+        if (on && x.active) {                                                                         \
+            if (k == kts) { q = q - (F / dzk / rh); acc; }                                            \
+            else if (k > kts && k <= top + 1) q = q - F / (rh * dzk);                                 \
+            if (k >= kts && k <= top) q = q + upF / (rh * dzk);                                       \
+        }                                                                                             \
+    }
+    {   // rain :503-530
+        const bool has = x.col_any(x.active && qr > SMALL_VALUE);
+        const float m = x.col_max_pos(x.active ? dt / dzk * rain_fall_rate : 0.0f);
+        const float cfl = ceilf(m);
+        const float vfall = dt * rain_fall_rate / cfl;
+        const int ncfl = has ? (int)lroundf(cfl) : 0;
+        const float rate = cloud2rain / (2 * ncfl);
+        for (int nmax = x.loop_max(ncfl), s = 1; s <= nmax; ++s) {
+            const bool on = s <= ncfl;
+            MPS_SEDIMENT(qr, vfall, rain = rain + F)
+            if (on && in_k) {
+                const float L_evap = -1 * (LH_vapor + (373.15f - T) * dLHvdt);
+                const float qvsat = sat_mr(T, p);
+                if (qv < qvsat && qr > SMALL_VALUE) phase_change(T, qr, qvsat, qv, L_evap, rate, err);
+            }
+        }
+    }
+    {   // snow :531-562
+        const bool has = x.col_any(x.active && qs > SMALL_VALUE);
+        const float m = x.col_max_pos(x.active ? dt / dzk * snow_fall_rate : 0.0f);
+        const float cfl = ceilf(m);
+        const float vfall = dt * snow_fall_rate / cfl;
+        const int ncfl = has ? (int)lroundf(cfl) : 0;
+        const float rate = cloud2snow / (2 * ncfl);
+        for (int nmax = x.loop_max(ncfl), s = 1; s <= nmax; ++s) {
+            const bool on = s <= ncfl;
+            MPS_SEDIMENT(qs, vfall, { snow = snow + F; rain = rain + F; })
+            if (on && in_k) {
+                const float L_evap = -1 * (LH_vapor + (373.15f - T) * dLHvdt);
+                const float L_subl = L_melt + L_evap;
+                const float qvsat = sat_mr(T, p);
+                if (qv < qvsat && qs > SMALL_VALUE) phase_change(T, qs, qvsat, qv, L_subl, rate, err);
+            }
+        }
+    }
+#undef MPS_SEDIMENT
+    if (!x.active) return;
+    th[c] = T / pi_;
+    qv_g[c] = qv; qc_g[c] = qc; qr_g[c] = qr; qs_g[c] = qs;
+    if (k == kts) {   // process_subdomain, mp_driver.f90:587-595: REAL(8) accumulators += REAL(4) tile fluxes
+        const int c2 = i + d.nx * j;
+        precip_acc[c2] = precip_acc[c2] + rain;
+        snow_acc[c2] = snow_acc[c2] + snow;
+    }
+    if (err) atomicAdd(err_count, 1);
+}
 }  // namespace
 
 int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_out)
@@ -234,15 +324,26 @@ int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int
     // mp_simple.f90:619-620, evaluated with the host libm like the reference
     const float cloud2snow = std::exp(-1.0f * (1 / 2000.0f) * dt);
     const float cloud2rain = std::exp(-1.0f * (1 / 500.0f) * dt);
-    const size_t lds_bytes = (size_t)5 * c->d.nz * MPS_LANES * sizeof(float);
-    if (lds_bytes > 160 * 1024) { icar_set_error("mp_simple: nz too large for the LDS column staging"); return 1; }
-    HIPCHK(hipFuncSetAttribute((const void *)k_mp_simple, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIPCHK(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
     ScopedTimer t(c, "mp");
-    const int ncol = ite - its + 1;
-    dim3 g((ncol + MPS_LANES - 1) / MPS_LANES, jte - jts + 1), b(MPS_LANES);
-    hipLaunchKernelGGL(k_mp_simple, g, b, lds_bytes, c->stream, c->d, p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa,
-                       dt, cloud2rain, cloud2snow, its - c->ims, ite - c->ims, jts - c->jms, kts - c->kms, kte - c->kms, c->d_flag);
+    const char *mode = getenv("ICAR_HIP_MP_SIMPLE");              // A/B switch: "lane" = one column per lane (first version)
+    const int nz = c->d.nz;
+    int nt = 0, cpb = 0;
+    if (!(mode && !strcmp(mode, "lane")) && block_comm_geometry(nz, nt, cpb) > 0.0f) {
+        // whole columns packed into blocks of 256 threads (512 / 1024 when nz needs it), thread = level*cpb + column
+        const int i0 = its - c->ims, i1 = ite - c->ims, ib0 = i0 / cpb, nb = i1 / cpb - ib0 + 1;
+        hipLaunchKernelGGL(k_mp_simple_pack, dim3(nb, jte - jts + 1), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d,
+                           p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa, dt, cloud2rain, cloud2snow,
+                           i0, i1, jts - c->jms, kts - c->kms, kte - c->kms, cpb, ib0, c->d_flag);
+    } else {
+        const size_t lds_bytes = (size_t)5 * nz * MPS_LANES * sizeof(float);
+        if (lds_bytes > 160 * 1024) { icar_set_error("mp_simple: nz too large for the LDS column staging"); return 1; }
+        HIPCHK(hipFuncSetAttribute((const void *)k_mp_simple, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        const int ncol = ite - its + 1;
+        dim3 g((ncol + MPS_LANES - 1) / MPS_LANES, jte - jts + 1), b(MPS_LANES);
+        hipLaunchKernelGGL(k_mp_simple, g, b, lds_bytes, c->stream, c->d, p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa,
+                           dt, cloud2rain, cloud2snow, its - c->ims, ite - c->ims, jts - c->jms, kts - c->kms, kte - c->kms, c->d_flag);
+    }
     HIPCHK(hipGetLastError());
     if (err_out) {
         HIPCHK(hipMemcpyAsync(err_out, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));

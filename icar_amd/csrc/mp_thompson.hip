@@ -15,6 +15,7 @@
 #include "ctx.h"
 #include "thompson_state.h"
 #include "fp64_math.h"
+#include "column_comm.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1170,18 +1171,15 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
     // A/B switches for profiling: ICAR_HIP_THOMPSON=lane (column per lane, scratch arrays) | wave (column per wave)
     const char *mode = getenv("ICAR_HIP_THOMPSON");
     const bool want_lane = mode && !strcmp(mode, "lane"), want_wave = mode && !strcmp(mode, "wave");
-    // Packed layout: cpb = floor(nt/nk) whole columns per nt-thread block.  nt is a multiple of 256 (4 waves per SIMD
-    // step): 320- or 640-thread blocks (5 / 10 waves) load the CU's SIMDs unevenly and measured 1.5x slower than 256.
-    // Thread utilisation vs one column per 64-lane wave decides; ties go to the smaller block / the wave kernel.
-    int cpb = 0, nt = 0; float best_u = (nk <= 64) ? nk / 64.0f : 0.0f;
+    // Packed layout (column_comm.h) unless one column per 64-lane wave fills the lanes as well (52 <= nk <= 64).
+    int cpb = 0, nt = 0;
     if (nk >= 2 && !want_wave && !want_lane) {
         const int force = getenv("ICAR_HIP_THOMPSON_CPB") ? atoi(getenv("ICAR_HIP_THOMPSON_CPB")) : 0;   // profiling only
-        if (force) { cpb = force; nt = (force * nk + 63) / 64 * 64; }
-        else for (int t = 256; t <= 1024; t *= 2) {
-            const float u = (float)((t / nk) * nk) / t;
-            if (u > best_u + (nt ? 0.10f : 0.02f)) { best_u = u; nt = t; cpb = t / nk; }   // bigger blocks only for a clear gain (barrier cost)
+        if (force) { cpb = force; nt = (force * nk + 63) / 64 * 64; if (nt > 1024) { cpb = 0; nt = 0; } }
+        else {
+            const float u = block_comm_geometry(nk, nt, cpb);
+            if (nk <= 64 && u <= nk / 64.0f + 0.02f) { cpb = 0; nt = 0; }
         }
-        if (nt > 1024) { cpb = 0; nt = 0; }
     }
     if (cpb) {
         // all tiles in ONE launch: process_halo's four 1-cell strips are latency-bound when launched one after another
