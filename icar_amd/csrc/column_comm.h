@@ -41,26 +41,32 @@ struct WaveComm {
     __device__ __forceinline__ int loop_max(int n) { return n; }           // one column per wave: already uniform
     __device__ __forceinline__ void up2(float x, float y, float &ux, float &uy) { ux = __shfl_down(x, 1); uy = __shfl_down(y, 1); }
     __device__ __forceinline__ float up1(float x) { return __shfl_down(x, 1); }
+    // the same three services for several species at once (BlockComm pays one barrier round for all of them)
+    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1)
+    { carry_down2(a0, b0, has0); carry_down2(a1, b1, has1); }
+    __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4])
+    { for (int s = 0; s < 4; ++s) sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); }
+    __device__ __forceinline__ void up6(const float v[6], float u[6]) { for (int s = 0; s < 6; ++s) u[s] = __shfl_down(v[s], 1); }
 };
 
 // cpb whole columns per block of nt >= cpb*nz threads; thread = level*cpb + column.  LDS (dynamic):
-// double d[nt] | float f[2][2][nt] | int has[nt] | int colmax[2][cpb+1] | int blkmax
+// double d[nt] | float f[2][6][nt] | int has[nt] | int colmax[2][cpb+1] | int blkmax
 struct BlockComm {
     double *sd; float *sf; int *shas, *scolmax, *sblkmax;
     int tid, nt, k, col, cpb, nz; bool active; unsigned step;
-    __host__ __device__ static size_t lds_bytes(int nt, int cpb) { return (size_t)nt * (8 + 16 + 4) + (size_t)(2 * (cpb + 1) + 1) * 4; }
+    __host__ __device__ static size_t lds_bytes(int nt, int cpb) { return (size_t)nt * (8 + 48 + 4) + (size_t)(2 * (cpb + 1) + 1) * 4; }
     // col_ok: this thread's column lies inside the tile (blocks are aligned to multiples of cpb columns)
     __device__ __forceinline__ BlockComm(void *lds, int tid_, int nt_, int cpb_, int nz_, int col_lo, int col_hi)
         : tid(tid_), nt(nt_), cpb(cpb_), nz(nz_), step(0)
     {
-        sd = (double *)lds; sf = (float *)(sd + nt); shas = (int *)(sf + 4 * nt); scolmax = shas + nt; sblkmax = scolmax + 2 * (cpb + 1);
+        sd = (double *)lds; sf = (float *)(sd + nt); shas = (int *)(sf + 12 * nt); scolmax = shas + nt; sblkmax = scolmax + 2 * (cpb + 1);
         const bool in = tid < cpb * nz;
         k = in ? tid / cpb : nz - 1;            // idle threads sit at "kte" of a dummy column: they never read upward
         col = in ? tid - k * cpb : cpb;
         active = in && col >= col_lo && col <= col_hi;
         if (!active) { k = nz - 1; }
     }
-    __device__ __forceinline__ float &F(int b, int w, int t) { return sf[(b * 2 + w) * nt + t]; }
+    __device__ __forceinline__ float &F(int b, int w, int t) { return sf[(b * 6 + w) * nt + t]; }
     __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p); }
     __device__ __forceinline__ double suffix_min(double v)
     {
@@ -73,13 +79,29 @@ struct BlockComm {
     __device__ __forceinline__ void carry_down2(float &a, float &b, int has)
     {
         __syncthreads();
-        F(0, 0, tid) = a; F(0, 1, tid) = b; shas[tid] = has;
-        __syncthreads();
-        if (!has) {                              // only active threads can have has == 0
-            int kk = k + 1;
-            while (kk < nz && !shas[kk * cpb + col]) ++kk;
-            if (kk < nz) { a = F(0, 0, kk * cpb + col); b = F(0, 1, kk * cpb + col); }
-            else { a = 0.f; b = 0.f; }
+        F(0, 0, tid) = a; F(0, 1, tid) = b;
+        if (nz <= 64) {
+            // per-column bit mask of the levels that hold the species: the nearest one above is a shift + count-trailing-
+            // zeros away (a scan loop runs, for the whole wave, as long as its unluckiest lane: up to nz iterations)
+            unsigned long long *mask = (unsigned long long *)scolmax;             // (cpb+1) 64-bit words
+            if (tid <= cpb) mask[tid] = 0ull;
+            __syncthreads();
+            if (has && active) atomicOr(&mask[col], 1ull << k);
+            __syncthreads();
+            if (!has) {                          // only active threads can have has == 0
+                const unsigned long long m = (k + 1 < 64) ? (mask[col] >> (k + 1)) : 0ull;
+                if (m) { const int kk = k + 1 + __builtin_ctzll(m); a = F(0, 0, kk * cpb + col); b = F(0, 1, kk * cpb + col); }
+                else { a = 0.f; b = 0.f; }
+            }
+        } else {
+            shas[tid] = has;
+            __syncthreads();
+            if (!has) {
+                int kk = k + 1;
+                while (kk < nz && !shas[kk * cpb + col]) ++kk;
+                if (kk < nz) { a = F(0, 0, kk * cpb + col); b = F(0, 1, kk * cpb + col); }
+                else { a = 0.f; b = 0.f; }
+            }
         }
         step = 0;                                // f[0] was just used: the next up*() starts on f[1]
     }
@@ -138,6 +160,59 @@ struct BlockComm {
         F(b, 0, tid) = x;
         __syncthreads();
         return (active && k + 1 < nz) ? F(b, 0, tid + cpb) : 0.f;
+    }
+    // two species in one exchange (nz <= 64: per-column bit masks in the sd area; else two plain calls)
+    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1)
+    {
+        if (nz > 64) { carry_down2(a0, b0, has0); carry_down2(a1, b1, has1); return; }
+        __syncthreads();
+        F(0, 0, tid) = a0; F(0, 1, tid) = b0; F(0, 2, tid) = a1; F(0, 3, tid) = b1;
+        unsigned long long *mask = (unsigned long long *)sd;                      // 2 x (cpb+1) words, nt >= 2(cpb+1)
+        if (tid < 2 * (cpb + 1)) mask[tid] = 0ull;
+        __syncthreads();
+        if (active) {
+            if (has0) atomicOr(&mask[col], 1ull << k);
+            if (has1) atomicOr(&mask[cpb + 1 + col], 1ull << k);
+        }
+        __syncthreads();
+        if (!has0) {
+            const unsigned long long m = (k + 1 < 64) ? (mask[col] >> (k + 1)) : 0ull;
+            if (m) { const int kk = k + 1 + __builtin_ctzll(m); a0 = F(0, 0, kk * cpb + col); b0 = F(0, 1, kk * cpb + col); }
+            else { a0 = 0.f; b0 = 0.f; }
+        }
+        if (!has1) {
+            const unsigned long long m = (k + 1 < 64) ? (mask[cpb + 1 + col] >> (k + 1)) : 0ull;
+            if (m) { const int kk = k + 1 + __builtin_ctzll(m); a1 = F(0, 2, kk * cpb + col); b1 = F(0, 3, kk * cpb + col); }
+            else { a1 = 0.f; b1 = 0.f; }
+        }
+        step = 0;
+    }
+    // four sedimentation plans in one exchange: per-column max level with a sedimenting particle and max sub-step count
+    __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4])
+    {
+        int *cm = shas;                                                           // 8 x (cpb+1) ints, nt >= 8(cpb+1) for nz >= 9
+        if (8 * (cpb + 1) > nt) { for (int s = 0; s < 4; ++s) sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); return; }
+        __syncthreads();
+        if (tid < 8 * (cpb + 1)) cm[tid] = 0;
+        __syncthreads();
+        for (int s = 0; s < 4; ++s) {
+            if (cond[s]) atomicMax(&cm[(2 * s) * (cpb + 1) + col], k);
+            if (ns[s] > 0) atomicMax(&cm[(2 * s + 1) * (cpb + 1) + col], ns[s]);
+        }
+        __syncthreads();
+        for (int s = 0; s < 4; ++s) {
+            int ks = cm[(2 * s) * (cpb + 1) + col]; const int n = cm[(2 * s + 1) * (cpb + 1) + col];
+            if (ks == kte) ks = kte - 1;
+            ksed1[s] = ks; onstep[s] = (n > 0) ? 1.f / (float)n : 1.0f;
+        }
+    }
+    __device__ __forceinline__ void up6(const float v[6], float u[6])
+    {
+        const int b = (int)((++step) & 1u);
+        for (int s = 0; s < 6; ++s) F(b, s, tid) = v[s];
+        __syncthreads();
+        const bool up = active && k + 1 < nz;
+        for (int s = 0; s < 6; ++s) u[s] = up ? F(b, s, tid + cpb) : 0.f;
     }
 };
 

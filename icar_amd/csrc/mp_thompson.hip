@@ -1098,7 +1098,7 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     }
 }
 
-struct ThTiles { int n, i0[4], i1[4], j0[4], ib0[4], nbx[4], off[5]; };
+struct ThTiles { int n, i0[4], i1[4], j0[4], ib0[4], nbx[4], off[5], xcd_run; };
 
 // cpb whole columns per block (aligned to multiples of cpb in i), thread = level*cpb + column (thompson_lane.inc: BlockComm)
 __global__ void __launch_bounds__(1024, 4)      // any block size <= 1024; register budget for 4 waves per SIMD (128 VGPRs)
@@ -1110,9 +1110,16 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 {
     extern __shared__ double lds_pack[];
     // several (its..ite, jts..jte) tiles in one launch (process_halo's four strips): block -> tile by prefix offsets
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin; neighbouring column groups share 64-B lines (a group is
+    // 24 B wide at nz = 40), so each XCD takes runs of XCD_RUN consecutive groups and the shared lines hit in its L2.
+    int bid = (int)blockIdx.x;
+    {
+        const int run = tl.xcd_run, super = run * 8, sc = bid / super, w = bid % super;
+        if ((sc + 1) * super <= (int)gridDim.x) bid = sc * super + (w % 8) * run + w / 8;
+    }
     int t = 0;
-    while (t + 1 < tl.n && (int)blockIdx.x >= tl.off[t + 1]) ++t;
-    const int local = (int)blockIdx.x - tl.off[t];
+    while (t + 1 < tl.n && bid >= tl.off[t + 1]) ++t;
+    const int local = bid - tl.off[t];
     const int i0 = tl.i0[t], i1 = tl.i1[t];
     const int first = (tl.ib0[t] + local % tl.nbx[t]) * cpb;  // first column slot of this block (multiple of cpb)
     BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nk, i0 - first, i1 - first);
@@ -1184,6 +1191,7 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
     if (cpb) {
         // all tiles in ONE launch: process_halo's four 1-cell strips are latency-bound when launched one after another
         ThTiles tl; tl.n = nt_; tl.off[0] = 0;
+        tl.xcd_run = 64;                 // consecutive column groups (and a few rows of them) per XCD turn
         for (int t = 0; t < nt_; ++t) {
             tl.i0[t] = T4[t][0] - c->ims; tl.i1[t] = T4[t][1] - c->ims; tl.j0[t] = T4[t][2] - c->jms;
             tl.ib0[t] = tl.i0[t] / cpb; tl.nbx[t] = tl.i1[t] / cpb - tl.ib0[t] + 1;
