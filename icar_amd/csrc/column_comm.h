@@ -70,10 +70,18 @@ struct BlockComm {
     __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p); }
     __device__ __forceinline__ double suffix_min(double v)
     {
+        // two-level: minimum over the rest of my chunk of 8 levels, then over the chunk minima above (<= 7 + nz/8 reads
+        // instead of up to nz-1; a wave pays for its lowest lane).  min is exact, so the grouping does not matter.
+        double *cm = (double *)sf;                                   // chunk minima [chunk][cpb], 6 nt doubles available
         __syncthreads();
         sd[tid] = v;
         __syncthreads();
-        if (active) for (int kk = k + 1; kk < nz; ++kk) v = fmin(v, sd[kk * cpb + col]);
+        const int c8 = k >> 3, kend = min((c8 + 1) << 3, nz);
+        if (active) for (int kk = k + 1; kk < kend; ++kk) v = fmin(v, sd[kk * cpb + col]);
+        if (active && (k & 7) == 0) cm[c8 * cpb + col] = v;          // the lowest level of a chunk now holds its minimum
+        __syncthreads();
+        if (active) for (int cc = c8 + 1; cc * 8 < nz; ++cc) v = fmin(v, cm[cc * cpb + col]);
+        step = 0;                                                    // the f area was used: next up*() starts fresh
         return v;
     }
     __device__ __forceinline__ void carry_down2(float &a, float &b, int has)

@@ -82,6 +82,7 @@ int icar_thompson_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
                       int ids, int ide, int jds, int jde, int kds, int kde);
 int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*tiles)[4], int kts, int kte,
                             int ids, int ide, int jds, int jde, int kds, int kde);
+int icar_thompson_prepare_constants(icar_hip_ctx *c);
 void icar_thompson_free(icar_hip_ctx *c);
 void icar_linwinds_free(icar_hip_ctx *c);
 int icar_linwinds_setup_run(icar_hip_ctx *c, const icar_hip_lt_options *o, const float *terrain, int nxg, int nyg, int ids, int jds, float dx);

@@ -1145,7 +1145,20 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
     th[c] = t1d / pi_;
 }
+// arguments come from the host so that nothing is folded at compile time: the value must be what a level computes at run time
+__global__ void k_thompson_constants(ThState *T, float rg, float xslw1) { T->N0_exp_default = th_graupel_N0_exp(rg, xslw1); }
 }  // namespace
+
+// called by icar_thompson_init_run once the device state exists
+int icar_thompson_prepare_constants(icar_hip_ctx *c)
+{
+    ThState *T = const_cast<ThState *>(icar_thompson_device_state(c));
+    if (!T) { icar_set_error("thompson: no device state"); return 1; }
+    hipLaunchKernelGGL(k_thompson_constants, dim3(1), dim3(1), 0, c->stream, T, TH_R1, 0.01f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
 
 int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*tiles)[4], int kts, int kte,
                             int ids, int ide, int jds, int jde, int kds, int kde)

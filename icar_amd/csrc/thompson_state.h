@@ -88,4 +88,7 @@ struct ThState {
     double *tps_iaus, *tni_iaus, *tpi_ide;                                                    /* (64,55) */
     double *t_Efrw, *t_Efsw;                                                                  /* (100,100) */
     float sa[10], sb[10], Tc[NTB_T];
+    /* graupel intercept of a level without graupel above 5e-5 and without supercooled rain (mp_thompson.f90:1456-1466 with
+     * rg <= 5e-5, xslw1 = 0.01): a constant, evaluated once on the device by the very function the levels use */
+    double N0_exp_default;
 };

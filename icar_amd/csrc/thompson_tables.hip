@@ -578,7 +578,7 @@ int icar_thompson_init_run(icar_hip_ctx *c, const float *params, const int *flag
     T->d_state = to_device(c, A, &D, 1);
     if (!T->d_state) { icar_set_error("thompson_init: hipMalloc failed"); return 1; }
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return icar_thompson_prepare_constants(c);
 }
 
 // Download one lookup table by its reference name (tests / cross-checks with ICAR's own *.dat caches).
