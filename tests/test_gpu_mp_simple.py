@@ -138,3 +138,39 @@ def test_mp_simple_layouts_bit_identical(nz):
     assert outs[None]["rain_mass"].max() > 1e-6 and outs[None]["accumulated_precipitation"].max() > 0
     for k in outs[None]:
         assert np.array_equal(outs[None][k], outs["lane"][k]), f"{k}: {(outs[None][k] != outs['lane'][k]).sum()} cells differ"
+
+
+def test_mp_simple_full_size_column_subset_vs_oracle(oracle):
+    """BASELINE size (512x512x40): 4000 random columns, re-run by the CPU oracle as a small domain of their own (the scheme
+    is column-local), must be BIT-identical to the device (oracle math-mode 1); all fields stay finite and non-negative."""
+    nx = ny = 512; nz = 40; dt = 45.0; steps = 3
+    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.7)).astype(np.float32)
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_SB04
+    mp_init(opt, d)
+    rng = np.random.default_rng(5)
+    jj = rng.integers(1, ny - 1, 4000); ii = rng.integers(1, nx - 1, 4000)
+    names = ["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water", "rain", "snow", "dz_mass"]
+    sub = {k: np.ascontiguousarray(np.pad(np.stack([c[k][jj, :, ii].T] * 3, axis=0), ((0, 0), (0, 0), (1, 1)), mode="edge")) for k in names}
+    n = sub["pressure"].shape[2]
+    oracle.set_math_mode(1)
+    try:
+        for _ in range(steps):
+            mp(d, opt, dt); d.model_time_seconds += dt
+            rain = np.zeros((3, n), np.float32); snow = np.zeros((3, n), np.float32)
+            assert oracle.mp_simple(sub["pressure"], sub["potential_temperature"], sub["exner"], sub["density"], sub["water_vapor"],
+                                    sub["cloud_water"], sub["rain"], sub["snow"], rain, snow, dt, sub["dz_mass"], 2, n - 1, 2, 2, 1, nz) == 0
+            th = d.get("potential_temperature") - np.float32(0.8); d.set("potential_temperature", th)
+            sub["potential_temperature"] -= np.float32(0.8)
+    finally:
+        oracle.set_math_mode(0)
+    member = {"potential_temperature": "potential_temperature", "water_vapor": "water_vapor", "cloud_water": "cloud_water_mass",
+              "rain": "rain_mass", "snow": "snow_mass"}
+    for k, m in member.items():
+        a = d.get(m)
+        assert np.isfinite(a).all() and (k == "potential_temperature" or a.min() >= 0), k
+        got = a[jj, :, ii].T; ref = sub[k][1, :, 1:-1]
+        assert np.array_equal(got, ref), f"{k}: {(got != ref).sum()} of {got.size} subset cells differ"
+    assert d.get("rain_mass").max() > 1e-5
+    d.close()
