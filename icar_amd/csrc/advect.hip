@@ -383,7 +383,7 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
                 const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
                 const unsigned char *__restrict__ needf)
 {
-    __shared__ float s_wb[FBY][64];
+    __shared__ float s_wb[2][FBY][64];       // double-buffered by row parity: one barrier per row instead of two
     const int lane = threadIdx.x, ty = threadIdx.y;
     const TileId tb = xcd_tile(2);
     const int i = 1 + tb.x * 63 + lane;
@@ -397,6 +397,7 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     const bool bottom = (k == 0), top = (k == d.nz - 1);
     const int ic = in_i ? i : d.nx - 1, kc = in_k ? k : d.nz - 1;            // clamped => all loads stay in bounds
     const int cb = d.idx(ic, kc, 0);
+    unsigned rowctr = 0;                                          // rows processed by this block (block-uniform)
     unsigned needmask = ~0u;
     if (needf) {
         const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z, blk = tb.x + (size_t)gridDim.x * (tb.y + (size_t)gridDim.y * tb.z);
@@ -454,10 +455,10 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
                 if (!bottom) WB = wz0;
             }
             const float UR = __shfl_down(UL, 1);
-            s_wb[ty][lane] = WB;
+            const int pb = (int)((rowctr++) & 1u);     // the buffer written two rows ago is free: everyone passed a barrier since
+            s_wb[pb][ty][lane] = WB;
             __syncthreads();
-            const float WT = (top || ty == FBY - 1) ? 0.0f : s_wb[ty + 1][lane];
-            __syncthreads();
+            const float WT = (top || ty == FBY - 1) ? 0.0f : s_wb[pb][ty + 1][lane];
             if (do_out) {
                 const float r = RHO ? rho[c] : 1.0f;
                 const float ja = jaco[c];
