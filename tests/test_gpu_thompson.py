@@ -271,3 +271,24 @@ def test_thompson_full_size_budget_and_column_subset_vs_oracle(th_oracle):
         scale = max(np.abs(b).max(), 1e-300)
         bad = np.abs(a - b) > 1e-5 * np.maximum(np.abs(b), 1e-3 * scale)
         assert bad.mean() <= 1e-4, f"{k}: {bad.mean():.2e} of the subset beyond rtol 1e-5 (bit-different: {(got[k] != ref[k]).mean():.2e})"
+
+
+def test_table_cache_files_byte_identical_to_the_reference(tmp_path):
+    """icar_amd.thompson_cache writes qr_acr_qg_mpt.dat / qr_acr_qs_mpt.dat / freezeH2O_mpt.dat from the DEVICE tables in the
+    reference's Fortran unformatted-sequential layout; their SHA-256 must equal the digests of the files the compiled
+    reference wrote (tests/golden/thompson_cache_sha256.json) -- i.e. a reference run can consume them as its own."""
+    import hashlib, json, os
+    from icar_amd import thompson_cache as tc
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "thompson_cache_sha256.json")))["files"]
+    c = ideal.make_case(8, 8, 4)
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    mp_init(opt, d)
+    tc.write_caches(d, str(tmp_path))
+    d.close()
+    for f, g in gold.items():
+        p = os.path.join(str(tmp_path), f)
+        assert os.path.getsize(p) == g["bytes"], f
+        assert hashlib.sha256(open(p, "rb").read()).hexdigest() == g["sha256"], f"{f} differs from the reference's file"
+    back = tc.read_caches(str(tmp_path))
+    assert len(back) == 24 and back["tcg_racg"].size == 28 * 28 * 37 * 37
