@@ -111,3 +111,22 @@ def test_update_winds_first_and_later_calls(oracle):
     assert bits_equal(d.get_dqdt("w"), want2) and np.abs(want2).max() > 0
     assert bits_equal(d.get("w"), want)                          # the winds themselves are untouched by the later call
     d.close()
+
+
+def test_output_file_from_device_fields(tmp_path):
+    """output_t.save_file on a real domain_t: the file holds what domain%...%data_3d holds after the step (NetCDF classic,
+    the reference's names / dimension order; icar_amd/output.py)."""
+    from icar_amd.output import output_t, read_file
+    c = case(40, 22, 9, seed=2)
+    d = single_image_domain(c)
+    d.diagnostic_update()
+    o = output_t(image=1)
+    o.add_variables(["water_vapor", "temperature", "u", "precipitation", "surface_pressure"])
+    fn = str(tmp_path / "icar_out_000001_2000-01-01_00-00-00.nc")
+    o.save_file(d, fn, 1, 51544.0)
+    r = read_file(fn)
+    assert np.array_equal(r["qv"][0], d.get("water_vapor").transpose(1, 0, 2))
+    assert np.array_equal(r["temperature"][0], d.get("temperature").transpose(1, 0, 2))
+    assert np.array_equal(r["u"][0], d.get("u").transpose(1, 0, 2)) and r["_dims_u"][-1] == "lon_u"
+    assert np.array_equal(r["psfc"][0], d.get("surface_pressure"))
+    d.close()
