@@ -121,7 +121,7 @@ def test_output_file_from_device_fields(tmp_path):
     d = single_image_domain(c)
     d.diagnostic_update()
     o = output_t(image=1)
-    o.add_variables(["water_vapor", "temperature", "u", "precipitation", "surface_pressure"])
+    o.add_variables(["water_vapor", "temperature", "u", "surface_pressure"])
     fn = str(tmp_path / "icar_out_000001_2000-01-01_00-00-00.nc")
     o.save_file(d, fn, 1, 51544.0)
     r = read_file(fn)
