@@ -119,3 +119,71 @@ def perturbation_download(domain, comp):
 def perturbation_upload(domain, comp, arr):
     a = np.ascontiguousarray(arr, np.float32)
     check(lib().icar_hip_linwinds_perturbation_upload(domain.ctx, comp, a.ctypes.data_as(ctypes.c_void_p)), "pert_upload")
+
+
+# ---- LUT disk cache (src/io/lt_lut_io.f90: write_LUT :58-108, read_LUT :118-190) ---------------------------------------
+LT_LUT_VERSION = "1.1"                      # lt_lut_io.f90:30
+_LUT_ATTRS = ("dirmax", "spdmax", "spdmin", "dirmin", "nsqmax", "nsqmin", "n_dir_values", "n_nsq_values", "n_spd_values",
+              "minimum_layer_size")
+
+
+def _lut_attr_values(lt):
+    lo, hi = lt.resolved()
+    return dict(dirmax=np.float32(lt.dirmax), spdmax=np.float32(lt.spdmax), spdmin=np.float32(lt.spdmin), dirmin=np.float32(lt.dirmin),
+                nsqmax=np.float32(hi), nsqmin=np.float32(lo), n_dir_values=np.int32(lt.n_dir_values),
+                n_nsq_values=np.int32(lt.n_nsq_values), n_spd_values=np.int32(lt.n_spd_values),
+                minimum_layer_size=np.float32(lt.minimum_layer_size))
+
+
+def lut_filename(options, nimages, image):
+    """linear_winds.f90:616: <u_LUT_Filename>_<num_images>_<this_image>.nc"""
+    base = getattr(options.lt_options, "u_LUT_Filename", "Linear_Theory_LUT.nc")
+    return f"{base}_{nimages}_{image}.nc"
+
+
+def write_LUT(filename, domain, options):
+    """write_LUT: variables uLUT (nspd,ndir,nnsq,nxu,nz,ny), vLUT (nspd,ndir,nnsq,nx,nz,nyv), dz (nz) and the lt_options as
+    global attributes, names as in the reference.  The reference creates NetCDF-4/HDF5 (nf90_create(NF90_NETCDF4)), for
+    which this image has no library; this writes 64-bit-offset classic NetCDF, which nf90_open reads just the same, but
+    whose fixed-size variables are limited to 4 GiB each -- enough for test-size LUTs, not for a production one (30 GB)."""
+    from scipy.io import netcdf_file
+    u = lut_download(domain, options, 0); v = lut_download(domain, options, 1)
+    if u.nbytes >= (1 << 32) or v.nbytes >= (1 << 32):
+        raise IcarHipError("write_LUT: LUT component >= 4 GiB does not fit a classic NetCDF variable (NetCDF-4 not available here)")
+    dz = np.asarray(options.parameters.dz_levels, np.float32)[:domain.nz]
+    with netcdf_file(filename, "w", version=2) as f:
+        # Fortran (nspd,ndir,nnsq,nxu,nz,ny) == C (ny,nz,nxu,nnsq,ndir,nspd): the shape lut_download returns
+        for name, n in zip(("ny", "nz", "nxu", "nnsq", "ndir", "nspd"), u.shape):
+            f.createDimension(name, int(n))
+        f.createDimension("nyv", int(v.shape[0])); f.createDimension("nx", int(v.shape[2]))
+        f.createVariable("uLUT", "f", ("ny", "nz", "nxu", "nnsq", "ndir", "nspd"))[:] = u
+        f.createVariable("vLUT", "f", ("nyv", "nz", "nx", "nnsq", "ndir", "nspd"))[:] = v
+        f.createVariable("dz", "f", ("nz",))[:] = dz
+        for k, val in _lut_attr_values(options.lt_options).items():
+            setattr(f, k, val)
+        f.lt_LUT_version = LT_LUT_VERSION
+
+
+def read_LUT(filename, domain, options):
+    """read_LUT: returns 0 and uploads the LUTs if the file matches the namelist (version, every lt_options attribute, the
+    LUT dimensions and dz), otherwise the number of mismatches (the reference then regenerates the LUT)."""
+    import os
+    from scipy.io import netcdf_file
+    if not os.path.exists(filename):
+        return 1
+    error = 0
+    with netcdf_file(filename, "r", mmap=False) as f:
+        ver = getattr(f, "lt_LUT_version", b"")
+        error += (ver.decode() if isinstance(ver, bytes) else str(ver)) != LT_LUT_VERSION
+        for k, val in _lut_attr_values(options.lt_options).items():
+            have = getattr(f, k, None)
+            error += have is None or np.asarray(have).ravel()[0] != val
+        if error:
+            return int(error)
+        u = np.array(f.variables["uLUT"][:]); v = np.array(f.variables["vLUT"][:]); dz = np.array(f.variables["dz"][:])
+    want_dz = np.asarray(options.parameters.dz_levels, np.float32)[:domain.nz]
+    if u.shape != _lut_shape(domain, options, 0) or v.shape != _lut_shape(domain, options, 1) or dz.shape != want_dz.shape \
+            or not np.array_equal(dz.astype(np.float32), want_dz):
+        return 1
+    lut_upload(domain, options, 0, u.astype(np.float32)); lut_upload(domain, options, 1, v.astype(np.float32))
+    return 0

@@ -108,6 +108,33 @@ def test_lut_build_space_varying_dz_vs_oracle():
     d.close()
 
 
+def test_lut_disk_cache_round_trip(tmp_path):
+    """write_LUT / read_LUT (src/io/lt_lut_io.f90): same variable / dimension / attribute names; a file that does not match
+    the namelist is refused like the reference refuses it."""
+    nxg, nyg, nz, dx = 24, 20, 3, 1500.0
+    opt = options_t()
+    opt.lt_options = lt_options_type(buffer=4, n_dir_values=4, n_spd_values=3, n_nsq_values=2)
+    opt.parameters.dz_levels = np.array([80.0, 150.0, 320.0], np.float32)
+    d = make_domain(nxg, nyg, nz, dx)
+    LW.setup_linwinds(d, opt, terrain(nxg, nyg, seed=2))
+    fn = str(tmp_path / LW.lut_filename(opt, 1, 1))
+    LW.write_LUT(fn, d, opt)
+    u0 = LW.lut_download(d, opt, 0); v0 = LW.lut_download(d, opt, 1)
+    from icar_amd.output import read_file
+    r = read_file(fn)
+    assert r["_dims_uLUT"] == ("ny", "nz", "nxu", "nnsq", "ndir", "nspd") and r["_dims_vLUT"] == ("nyv", "nz", "nx", "nnsq", "ndir", "nspd")
+    assert r["_attributes"]["lt_LUT_version"] == b"1.1" and int(r["_attributes"]["n_dir_values"]) == 4
+    d2 = make_domain(nxg, nyg, nz, dx)
+    LW.setup_linwinds(d2, opt, terrain(nxg, nyg, seed=2), build=False)
+    assert LW.read_LUT(fn, d2, opt) == 0
+    assert bits_equal(LW.lut_download(d2, opt, 0), u0) and bits_equal(LW.lut_download(d2, opt, 1), v0)
+    opt2 = options_t(); opt2.lt_options = lt_options_type(buffer=4, n_dir_values=4, n_spd_values=3, n_nsq_values=2, spdmax=25.0)
+    opt2.parameters.dz_levels = opt.parameters.dz_levels
+    assert LW.read_LUT(fn, d2, opt2) > 0                                   # spdmax differs -> regenerate
+    assert LW.read_LUT(str(tmp_path / "missing.nc"), d2, opt) == 1
+    d.close(); d2.close()
+
+
 def _run_spatial(oracle, moist, variable_N, update, smooth=True, passes=2):
     nx, ny, nz = 70, 37, 12
     a = atmosphere(nx, ny, nz, seed=5, moist=moist)
