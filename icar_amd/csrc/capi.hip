@@ -293,6 +293,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     if (c->d_flag) hipFree(c->d_flag);
     if (c->occ) hipFree(c->occ);
     if (c->needf) hipFree(c->needf);
+    if (c->iw_adj) hipFree(c->iw_adj);
     icar_thompson_free(c);
     icar_linwinds_free(c);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -481,6 +482,31 @@ int icar_hip_balance_uvw_update(icar_hip_ctx *c, float dx)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
     return icar_balance_uvw_run(c, dx, 1);
+}
+
+int icar_hip_iterative_winds_correct_w(icar_hip_ctx *c, int update)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_iterative_winds_correct_w(c, update);
+}
+
+int icar_hip_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int update)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (nsweeps < 0 || !(dx > 0)) { icar_set_error("iterative_winds_sweep: bad argument"); return 1; }
+    return icar_iterative_winds_sweep(c, dx, nsweeps, update);
+}
+
+int icar_hip_box_pack(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, void *dbuf)
+{
+    if (!c || !dbuf) { icar_set_error("box_pack: null argument"); return 1; }
+    return icar_box_copy(c, field, which, i0, ni, j0, nj, (float *)dbuf, false);
+}
+
+int icar_hip_box_unpack(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, const void *dbuf)
+{
+    if (!c || !dbuf) { icar_set_error("box_unpack: null argument"); return 1; }
+    return icar_box_copy(c, field, which, i0, ni, j0, nj, (float *)dbuf, true);
 }
 
 int icar_hip_dqdt_download(icar_hip_ctx *c, int f, void *host)

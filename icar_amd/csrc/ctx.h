@@ -40,6 +40,7 @@ struct icar_hip_ctx {
     int batch_cap = 0;
     unsigned char *occ = nullptr, *needf = nullptr;   // MPDATA occupancy flags (advect.hip)
     bool winds_valid = false;
+    float *iw_adj = nullptr;             // iterative_winds ADJ scratch (iterative_winds.hip)
     // reductions / flags
     float *d_red = nullptr;              // small device scratch for reductions
     int *d_flag = nullptr;
@@ -74,6 +75,9 @@ int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int
 int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out);
 int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update);
+int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update);
+int icar_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int update);
+int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, float *buf, bool unpack);
 int icar_diagnostic_update_run(icar_hip_ctx *c);
 int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);
 int icar_enforce_limits_run(icar_hip_ctx *c, const int *fields, int n);

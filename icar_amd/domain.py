@@ -193,6 +193,18 @@ def _halo_unpack(self, direction, halo, field_ids, buf):
                                      ctypes.c_void_p(buf.data_ptr())), "icar_hip_halo_unpack")
 
 
+def _box_pack(self, field, which, i0, ni, j0, nj, buf):
+    check(lib().icar_hip_box_pack(self.ctx, int(field), int(which), int(i0), int(ni), int(j0), int(nj),
+                                  ctypes.c_void_p(buf.data_ptr())), "icar_hip_box_pack")
+
+
+def _box_unpack(self, field, which, i0, ni, j0, nj, buf):
+    check(lib().icar_hip_box_unpack(self.ctx, int(field), int(which), int(i0), int(ni), int(j0), int(nj),
+                                    ctypes.c_void_p(buf.data_ptr())), "icar_hip_box_unpack")
+
+
+domain_t.box_pack = _box_pack
+domain_t.box_unpack = _box_unpack
 domain_t.halo_count = _halo_count
 domain_t.new_buffer = _new_buffer
 domain_t.halo_pack = _halo_pack

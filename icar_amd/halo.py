@@ -93,6 +93,81 @@ class HaloComm:
             tile.halo_unpack(d, self.halo, field_ids, self._recv[d])
 
 
+    # ---- exchange_u / exchange_v (exchangeable_obj.f90:158-229) -----------------------------------------------
+    def exchange_uv(self, tile, u_field, v_field, which=0):
+        """`call domain%u%exchange_u(); call domain%v%exchange_v()` (wind.f90:404-405, :482-483) as ONE message per
+        neighbour.  The two fields are independent, so batching them is equivalent; all boxes are packed before any
+        is unpacked (PUTs before `sync images`), and N/S are unpacked before E/W like the reference's retrieve order.
+        The tile provides box_pack / box_unpack (field, which, i0, ni, j0, nj, buffer) and dims via tile.nx/nz/ny."""
+        if not self.peers:
+            return
+        plan = staggered_boxes(tile.nx, tile.ny, self.halo)
+        nz = tile.nz
+        flds = {"u": u_field, "v": v_field}
+        key = ("uv", tile.nx, tile.ny, nz)
+        if getattr(self, "_uvkey", None) != key:
+            size = lambda boxes: sum(b[2] * b[4] * nz for b in boxes)
+            self._uvsend = {d: tile.new_buffer(size(plan[d][0])) for d in self.peers}
+            self._uvrecv = {d: tile.new_buffer(size(plan[d][1])) for d in self.peers}
+            self._uvkey = key
+        def walk(d, boxes, buf, fn):
+            off = 0
+            for kind, i0, ni, j0, nj in boxes:
+                n = ni * nj * nz
+                fn(flds[kind], which, i0, ni, j0, nj, buf[off:off + n])
+                off += n
+        for d in self.peers:
+            walk(d, plan[d][0], self._uvsend[d], tile.box_pack)
+        self._transfer(tile, self._uvsend, self._uvrecv)
+        for d in sorted(self.peers):                       # 0,1 = north, south first; then east, west
+            walk(d, plan[d][1], self._uvrecv[d], tile.box_unpack)
+
+    def _transfer(self, tile, send, recv):
+        """Blocking neighbour exchange of already packed buffers (same transport rules as send()/retrieve())."""
+        any_buf = next(iter(send.values()))
+        stage = any_buf.is_cuda and dist.get_backend(self.group) == "gloo"
+        host_sync = any_buf.is_cuda and (stage or bool(getattr(tile, "needs_host_sync", lambda: False)()))
+        if host_sync:
+            tile.synchronize()
+        sbuf, rbuf = send, recv
+        if stage:
+            sbuf = {d: b.cpu() for d, b in send.items()}
+            rbuf = {d: torch.empty(b.shape, dtype=b.dtype) for d, b in recv.items()}
+        ops = []
+        for d in sorted(self.peers):
+            ops.append(dist.P2POp(dist.isend, sbuf[d], self.peers[d], group=self.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf[d], self.peers[d], group=self.group))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        if stage:
+            for d in self.peers:
+                recv[d].copy_(rbuf[d])
+        if host_sync:
+            torch.cuda.synchronize()
+
+
+def staggered_boxes(nx, ny, h):
+    """Index table of exchange_u + exchange_v for a tile of nx x ny mass cells (memory extents, halos included).
+    Returns {dir: (send_boxes, recv_boxes)}; a box is (kind, i0, ni, j0, nj), 0-based, kind "u" (nx+1 columns) or "v"
+    (ny+1 rows).  recv_boxes[dir] is where the message FROM the neighbour in direction dir lands.
+      u: N/S like exchange (put_north/put_south over the full staggered width, :160-161);
+         east PUT is halo+1 columns n-2h..n-h (:166), landing in the neighbour's columns start..start+h (:188);
+         west PUT is columns start+h+1..start+2h (:172), landing in the neighbour's last h columns (retrieve_east_halo)
+      v: E/W like exchange; north PUT rows n-2h..n-h (:202) -> rows start..start+h (:221); south PUT rows
+         start+h+1..start+2h (:207) -> the neighbour's last h rows (retrieve_north_halo)."""
+    X, Y = nx + 1, ny + 1
+    return {
+        DIR_NORTH: ([("u", 0, X, ny - 2 * h, h), ("v", 0, nx, Y - 1 - 2 * h, h + 1)],
+                    [("u", 0, X, ny - h, h), ("v", 0, nx, Y - h, h)]),
+        DIR_SOUTH: ([("u", 0, X, h, h), ("v", 0, nx, h + 1, h)],
+                    [("u", 0, X, 0, h), ("v", 0, nx, 0, h + 1)]),
+        DIR_EAST: ([("u", X - 1 - 2 * h, h + 1, 0, ny), ("v", nx - 2 * h, h, 0, Y)],
+                   [("u", X - h, h, 0, ny), ("v", nx - h, h, 0, Y)]),
+        DIR_WEST: ([("u", h + 1, h, 0, ny), ("v", h, h, 0, Y)],
+                   [("u", 0, h + 1, 0, ny), ("v", 0, h, 0, Y)]),
+    }
+
+
 def co_min(value, group=None, device=None):
     """time_step.f90:413 `call co_min(seconds)`: all-reduce(min) of one REAL(8)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

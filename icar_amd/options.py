@@ -80,6 +80,7 @@ class parameter_options_type:            # opt_types.f90:188-326 (subset on the 
     debug: bool = False
     ideal: bool = False
     space_varying_dz: bool = False       # options_obj.f90:1936
+    wind_iterations: int = 100           # options_obj.f90:1029
 
 
 @dataclass

@@ -3,7 +3,11 @@ import ctypes
 from .capi import lib, check, IcarHipError
 from .linear_winds import linear_perturb
 
-kWIND_LINEAR = 1                 # icar_constants.f90:368 (windtype)
+from . import _fields as F
+
+kWIND_LINEAR = 1                 # icar_constants.f90:368-377 (windtype)
+kITERATIVE_WINDS = 3
+kLINEAR_ITERATIVE_WINDS = 5
 
 
 def balance_uvw(domain, update=False):
@@ -12,16 +16,40 @@ def balance_uvw(domain, update=False):
     check(fn(domain.ctx, ctypes.c_float(domain.dx)), "balance_uvw")
 
 
+def exchange_uv(domain, update=False):
+    """domain%u%exchange_u(); domain%v%exchange_v() (on the dqdt_3d arrays when iterative_winds swapped them in)."""
+    if getattr(domain, "comm", None) is not None:
+        domain.comm.exchange_uv(domain, F.U, F.V, which=1 if update else 0)
+
+
+def iterative_winds(domain, options, update=False):
+    """wind.f90:371-498: Jacobi-like removal of the 3-D divergence from u, v with w pinned to zero at the model top.
+    Same control flow as the reference; on one image the loop is a single device call."""
+    n = int(options.parameters.wind_iterations) + 1          # do it = 0, wind_iterations
+    dx = ctypes.c_float(domain.dx)
+    exchange_uv(domain, update)
+    balance_uvw(domain, update)
+    check(lib().icar_hip_iterative_winds_correct_w(domain.ctx, int(update)), "iterative_winds")
+    if getattr(domain, "comm", None) is None or not domain.comm.peers:
+        check(lib().icar_hip_iterative_winds_sweep(domain.ctx, dx, n, int(update)), "iterative_winds")
+        return
+    for _ in range(n):
+        check(lib().icar_hip_iterative_winds_sweep(domain.ctx, dx, 1, int(update)), "iterative_winds")
+        exchange_uv(domain, update)
+
+
 def update_winds(domain, options):
-    """wind.f90:289-360 for windtype 0 and kWIND_LINEAR.  First call: linear_perturb on u, v then balance_uvw on the
+    """wind.f90:289-360 for windtype 0, kWIND_LINEAR, kITERATIVE_WINDS and kLINEAR_ITERATIVE_WINDS.  First call: linear_perturb on u, v then balance_uvw on the
     winds; every later call (a new forcing step has put the next winds into dqdt_3d) the same on the tendencies.
     make_winds_grid_relative (rotation by sintheta / costheta) belongs to the forcing reader and is not on this path;
     setup_linwinds(domain, options, global_terrain) must have been called when windtype == kWIND_LINEAR."""
     wt = options.physics.windtype
-    if wt not in (0, kWIND_LINEAR):
-        raise IcarHipError("update_winds: only windtype 0 and kWIND_LINEAR are on the device path")
+    if wt not in (0, kWIND_LINEAR, kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS):
+        raise IcarHipError("update_winds: windtype kCONSERVE_MASS is not on the device path")
     first = not getattr(domain, "_winds_initialised", False)
-    if wt == kWIND_LINEAR:
+    if wt in (kWIND_LINEAR, kLINEAR_ITERATIVE_WINDS):
         linear_perturb(domain, options, options.lt_options.vert_smooth, False, options.parameters.advect_density, update=not first)
+    if wt in (kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS):
+        iterative_winds(domain, options, update=not first)
     balance_uvw(domain, update=not first)
     domain._winds_initialised = True

@@ -174,6 +174,15 @@ int icar_hip_balance_uvw(icar_hip_ctx *ctx, float dx);
  * (src/physics/wind.f90:341-360); the w tendency mirror is created if needed. */
 int icar_hip_balance_uvw_update(icar_hip_ctx *ctx, float dx);
 
+/* ---- iterative_winds (src/physics/wind.f90:371-498), SURVEY 8(f) rank 4 -----------------------
+ * The host keeps the reference's control flow: [exchange_u, exchange_v], balance_uvw, correct_w, then
+ * wind_iterations+1 times { sweep(1); exchange_u; exchange_v }.  On one image the exchanges are no-ops and
+ * sweep(wind_iterations+1) runs the whole loop.  update != 0 works on u/v/w%meta_data%dqdt_3d (wind.f90:392-401).
+ *   correct_w  :430-441  w(i,k,j) -= min(sum(dz(1:k))/sum(dz), 1) * w(i,kme,j)
+ *   sweep      :455-481  div = calc_divergence(u,v,w) (:172-228); ADJ = div/(-2/dx); u, v faces +-ADJ*0.5 */
+int icar_hip_iterative_winds_correct_w(icar_hip_ctx *ctx, int update);
+int icar_hip_iterative_winds_sweep(icar_hip_ctx *ctx, float dx, int nsweeps, int update);
+
 /* ---- W3: linear-theory wind look-up table (src/physics/linear_winds.f90) ----------------------
  * options%lt_options (src/objects/options_obj.f90:1400-1530; defaults there: buffer 50, stability_window_size 10,
  * vert_smooth 10, max/min_stability 6e-4/1e-7, N_squared 3e-5, linear_contribution 1, linear_update_fraction 0.2,
@@ -230,6 +239,12 @@ int icar_hip_spatial_winds(icar_hip_ctx *ctx, int update);
  * buffer into my halo planes like retrieve_<dir>_halo.  Buffers are device pointers; the element
  * count per field is icar_hip_halo_count(). */
 size_t icar_hip_halo_count(const icar_hip_ctx *ctx, int dir, int halo);
+/* Staggered faces: exchange_u / exchange_v (exchangeable_obj.f90:158-229) move halo+1 planes in the staggered
+ * direction, which the cell-grid packers above cannot express.  box_pack gathers the 0-based box
+ * [i0, i0+ni) x all levels x [j0, j0+nj) of one REAL(4) 3-D field (which = 0: data_3d, 1: meta_data%dqdt_3d) into a
+ * device buffer laid out [nj][nz][ni]; box_unpack scatters it back.  icar_amd/halo.py holds the index table. */
+int icar_hip_box_pack(icar_hip_ctx *ctx, int field, int which, int i0, int ni, int j0, int nj, void *dbuf);
+int icar_hip_box_unpack(icar_hip_ctx *ctx, int field, int which, int i0, int ni, int j0, int nj, const void *dbuf);
 int icar_hip_halo_pack(icar_hip_ctx *ctx, int dir, int halo, const int *fields, int nfields, void *dbuf);
 int icar_hip_halo_unpack(icar_hip_ctx *ctx, int dir, int halo, const int *fields, int nfields, const void *dbuf);
 

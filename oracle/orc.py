@@ -131,6 +131,34 @@ def balance_uvw(u, v, ju, jv, jw, dz, dx):
     return w
 
 
+def calc_divergence(u, v, w, ju, jv, jw, dz, jaco, dx):
+    ny, nz, nx = jw.shape
+    div = np.zeros((ny, nz, nx), np.float32)
+    lib().orc_calc_divergence(_i(nx), _i(nz), _i(ny), _p(u), _p(v), _p(w), _p(ju), _p(jv), _p(jw), _p(dz), _p(jaco), _f(dx), _p(div))
+    return div
+
+
+def iterative_winds_correct_w(w, dz):
+    ny, nz, nx = w.shape
+    lib().orc_iterative_winds_correct_w(_i(nx), _i(nz), _i(ny), _p(w), _p(dz))
+
+
+def iterative_winds_sweep(u, v, w, ju, jv, jw, dz, jaco, dx):
+    ny, nz, nx = w.shape
+    adj = np.zeros((ny, nz, nx), np.float32)
+    lib().orc_iterative_winds_sweep(_i(nx), _i(nz), _i(ny), _p(u), _p(v), _p(w), _p(ju), _p(jv), _p(jw), _p(dz), _p(jaco), _f(dx), _p(adj))
+
+
+def iterative_winds(u, v, ju, jv, jw, dz, jaco, dx, iterations):
+    """wind.f90:371-498 on one image (exchange_u/v are no-ops): returns (u, v, w)."""
+    u = u.copy(); v = v.copy()
+    w = balance_uvw(u, v, ju, jv, jw, dz, dx)
+    iterative_winds_correct_w(w, dz)
+    for _ in range(iterations + 1):
+        iterative_winds_sweep(u, v, w, ju, jv, jw, dz, jaco, dx)
+    return u, v, w
+
+
 def max_courant(u, v, w, dz_levels, dx):
     ny, nz, nx = w.shape
     fn = lib().orc_max_courant

@@ -4,6 +4,7 @@
  *   apply_forcing       src/objects/domain_obj.f90:2383-2448
  *   enforce_limits      src/objects/domain_obj.f90:2228-2243
  *   balance_uvw         src/physics/wind.f90:81-169 (+ calc_divergence :172-228)
+ *   iterative_winds     src/physics/wind.f90:371-498 (stages split so a tiled run can exchange_u/v between them)
  *   compute_dt (3)      src/main/time_step.f90:264-289
  * PARITY UNPINNED by execution: these procedures live in NetCDF/coarray-dependent units
  * (domain_obj.f90, time_step.f90, wind.f90) that cannot be compiled in this image; the code below is
@@ -85,6 +86,61 @@ void orc_balance_uvw(int nx, int nz, int ny, const float *u, const float *v, flo
             else wk = (wprev * jwprev - div * dz[c]) / jw[c];
             w[c] = wk; wprev = wk; jwprev = jw[c];
         }
+    }
+}
+
+/* calc_divergence, full form (wind.f90:203-226): horizontal + vertical metric divergence, then / jaco */
+void orc_calc_divergence(int nx, int nz, int ny, const float *u, const float *v, const float *w, const float *ju, const float *jv,
+                         const float *jw, const float *dz, const float *jaco, float dx, float *div)
+{
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) for (int i = 0; i < nx; ++i) {
+        const size_t c = IDX(i, k, j);
+        const float du = u[IDXU(i + 1, k, j)] * ju[IDXU(i + 1, k, j)] - u[IDXU(i, k, j)] * ju[IDXU(i, k, j)];
+        const float dv = v[IDX(i, k, j + 1)] * jv[IDX(i, k, j + 1)] - v[c] * jv[c];
+        float d = (du + dv) / dx;
+        const float wm = w[c] * jw[c];
+        if (k == 0) d = d + wm / dz[c];
+        else d = d + (wm - w[IDX(i, k - 1, j)] * jw[IDX(i, k - 1, j)]) / dz[c];
+        div[c] = d / jaco[c];
+    }
+}
+
+/* wind.f90:430-441: remove the model-top w linearly with the fractional height of each level (k ascending, so the
+ * top level itself is zeroed last and every lower level sees the uncorrected top value) */
+void orc_iterative_winds_correct_w(int nx, int nz, int ny, float *w, const float *dz)
+{
+    for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+        float height = 0;
+        for (int k = 0; k < nz; ++k) height += dz[IDX(i, k, j)];
+        float part = 0;
+        for (int k = 0; k < nz; ++k) {
+            part += dz[IDX(i, k, j)];
+            float corr = part / height;
+            if (corr > 1.0f) corr = 1.0f;
+            w[IDX(i, k, j)] = w[IDX(i, k, j)] - corr * w[IDX(i, nz - 1, j)];
+        }
+    }
+}
+
+/* one pass of the loop body wind.f90:455-481 (without the exchanges): ADJ = div / (-2/dx), then the four array
+ * statements on u and v with U_cor = V_cor = 0.5.  adj is nx*nz*ny scratch. */
+void orc_iterative_winds_sweep(int nx, int nz, int ny, float *u, float *v, const float *w, const float *ju, const float *jv,
+                               const float *jw, const float *dz, const float *jaco, float dx, float *adj)
+{
+    const float coef = -2 / dx;
+    orc_calc_divergence(nx, nz, ny, u, v, w, ju, jv, jw, dz, jaco, dx, adj);
+    for (size_t c = 0; c < (size_t)nx * nz * ny; ++c) adj[c] = adj[c] / coef;
+    for (int j = 1; j <= ny - 2; ++j) for (int k = 0; k < nz; ++k) for (int i = 2; i <= nx - 1; ++i) {
+        float x = u[IDXU(i, k, j)];
+        x = x + (adj[IDX(i - 1, k, j)] * 0.5f);
+        x = x - (adj[IDX(i, k, j)] * 0.5f);
+        u[IDXU(i, k, j)] = x;
+    }
+    for (int j = 2; j <= ny - 1; ++j) for (int k = 0; k < nz; ++k) for (int i = 1; i <= nx - 2; ++i) {
+        float x = v[IDX(i, k, j)];
+        x = x + (adj[IDX(i, k, j - 1)] * 0.5f);
+        x = x - (adj[IDX(i, k, j)] * 0.5f);
+        v[IDX(i, k, j)] = x;
     }
 }
 

@@ -6,11 +6,11 @@ import torch
 
 
 class HostTile:
-    def __init__(self, grid, fields):
+    def __init__(self, grid, fields, dqdt=None):
         self.grid = grid
         self.f = fields                 # {field_id: float32 array (ny, nz, nx)} with halos
-        any_f = next(iter(fields.values()))
-        self.ny, self.nz, self.nx = any_f.shape
+        self.dq = dqdt or {}            # {field_id: dqdt_3d mirror}
+        self.nx, self.nz, self.ny = grid.ime - grid.ims + 1, grid.kme - grid.kms + 1, grid.jme - grid.jms + 1
 
     def halo_count(self, d, h):
         return self.nx * self.nz * h if d in (0, 1) else h * self.nz * self.ny
@@ -37,3 +37,12 @@ class HostTile:
         for m, fid in enumerate(field_ids):
             tgt = self.f[fid][sj, :, si]
             tgt[...] = b[m * per:(m + 1) * per].reshape(tgt.shape)
+
+    # staggered boxes (exchange_u / exchange_v): same [nj][nz][ni] layout as icar_hip_box_pack
+    def box_pack(self, field, which, i0, ni, j0, nj, buf):
+        a = (self.dq if which else self.f)[field]
+        buf.copy_(torch.from_numpy(np.ascontiguousarray(a[j0:j0 + nj, :, i0:i0 + ni]).ravel()))
+
+    def box_unpack(self, field, which, i0, ni, j0, nj, buf):
+        a = (self.dq if which else self.f)[field]
+        a[j0:j0 + nj, :, i0:i0 + ni] = buf.numpy().reshape(nj, self.nz, ni)

@@ -65,3 +65,35 @@ def test_two_tiles_one_process_exchange():
     for g, d in tiles:
         assert np.array_equal(d.get("water_vapor"), G[g.jms - 1:g.jme, :, g.ims - 1:g.ime])
         d.close()
+
+
+@pytest.mark.parametrize("halo", [1, 2])
+def test_staggered_boxes_match_host_double(halo):
+    """exchange_u / exchange_v faces (exchangeable_obj.f90:158-229): every send and receive box of
+    icar_amd.halo.staggered_boxes through icar_hip_box_pack/unpack vs plain numpy slicing, on data_3d and dqdt_3d."""
+    from icar_amd.halo import staggered_boxes
+    g = grid_t().set_grid_dimensions(70, 50, 6, 4, 1, halo_width=halo)
+    ny, nz, nx = g.jme - g.jms + 1, 6, g.ime - g.ims + 1
+    rng = np.random.default_rng(9)
+    mk = lambda s: rng.standard_normal(s).astype(np.float32)
+    u, v, du, dv = mk((ny, nz, nx + 1)), mk((ny + 1, nz, nx)), mk((ny, nz, nx + 1)), mk((ny + 1, nz, nx))
+    d = mk_domain(g, {"u": u, "v": v}); d.set_dqdt("u", du); d.set_dqdt("v", dv)
+    ht = HostTile(g, {11: u.copy(), 12: v.copy()}, {11: du.copy(), 12: dv.copy()})
+    fid = {"u": 11, "v": 12}
+    for direction, (send, recv) in staggered_boxes(nx, ny, halo).items():
+        for which in (0, 1):
+            for kind, i0, ni, j0, nj in send:
+                gb = d.new_buffer(ni * nj * nz); hb = ht.new_buffer(ni * nj * nz)
+                d.box_pack(fid[kind], which, i0, ni, j0, nj, gb); d.synchronize()
+                ht.box_pack(fid[kind], which, i0, ni, j0, nj, hb)
+                assert torch.equal(gb.cpu(), hb), (direction, kind, which)
+            for kind, i0, ni, j0, nj in recv:
+                inbox = torch.from_numpy(mk(ni * nj * nz))
+                d.box_unpack(fid[kind], which, i0, ni, j0, nj, inbox.cuda()); d.synchronize()
+                ht.box_unpack(fid[kind], which, i0, ni, j0, nj, inbox)
+    assert np.array_equal(d.get("u"), ht.f[11]) and np.array_equal(d.get("v"), ht.f[12])
+    assert np.array_equal(d.get_dqdt("u"), ht.dq[11]) and np.array_equal(d.get_dqdt("v"), ht.dq[12])
+    assert not np.array_equal(ht.f[11], u) and not np.array_equal(ht.dq[12], dv)
+    with pytest.raises(Exception):
+        d.box_pack(11, 0, 0, nx + 2, 0, 1, d.new_buffer((nx + 2) * nz))      # outside the field
+    d.close()

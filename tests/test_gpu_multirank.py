@@ -171,6 +171,63 @@ def _worker_oracle(rank, world, port, adv, q):
         dist.destroy_process_group()
 
 
+def _worker_iw(rank, world, port, adv, q):
+    """Tiled iterative_winds on device tiles (exchange_u/v through HaloComm) == the CPU oracle run on host tiles with
+    the same exchange, whole tile, bit-for-bit; both the winds form and the dqdt_3d (update) form."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        torch.cuda.set_device(0)
+        from icar_amd import ideal
+        from icar_amd.grid import grid_t
+        from icar_amd.halo import HaloComm
+        from icar_amd.wind import update_winds, kITERATIVE_WINDS
+        from host_tile import HostTile
+        from oracle import orc
+        case = ideal.make_case(NXG, NYG, NZ, hill_height=700.0, noise=0.02, n_hydro=1, exact=True)
+        rng = np.random.default_rng(2)
+        case["u"] = (case["u"] + rng.normal(0, 1, case["u"].shape)).astype(np.float32)
+        case["v"] = (case["v"] + rng.normal(0, 1, case["v"].shape)).astype(np.float32)
+        opt = _options("upwind", case)
+        opt.physics.windtype = kITERATIVE_WINDS; opt.parameters.wind_iterations = 5
+        g = grid_t().set_grid_dimensions(NXG, NYG, NZ, world, rank + 1)
+        d = _setup(case, g, opt, HaloComm(g, rank + 1))
+        def cut(a):
+            if a.shape[2] == NXG + 1: return np.ascontiguousarray(a[g.jms - 1:g.jme, :, g.ims - 1:g.ime + 1])
+            if a.shape[0] == NYG + 1: return np.ascontiguousarray(a[g.jms - 1:g.jme + 1, :, g.ims - 1:g.ime])
+            return np.ascontiguousarray(a[g.jms - 1:g.jme, :, g.ims - 1:g.ime])
+        geo = [cut(case[n]) for n in ("jacobian_u", "jacobian_v", "jacobian_w", "advection_dz", "jacobian")]
+        dxf = float(case["dx"])
+        dug = (0.01 * rng.standard_normal(case["u"].shape)).astype(np.float32); dvg = (0.01 * rng.standard_normal(case["v"].shape)).astype(np.float32)
+        for which, (ug, vg) in enumerate(((case["u"], case["v"]), (dug, dvg))):
+            if which:
+                d.set_dqdt("u", cut(ug)); d.set_dqdt("v", cut(vg))
+            update_winds(d, opt)
+            got = (d.get_dqdt("u"), d.get_dqdt("v"), d.get_dqdt("w")) if which else (d.get("u"), d.get("v"), d.get("w"))
+            u_l, v_l = cut(ug), cut(vg)
+            store = {11: u_l, 12: v_l}
+            tile = HostTile(g, {} if which else store, store if which else None); hc = HaloComm(g, rank + 1)
+            hc.exchange_uv(tile, 11, 12, which=which)
+            w_l = orc.balance_uvw(u_l, v_l, *geo[:4], dxf)
+            orc.iterative_winds_correct_w(w_l, geo[3])
+            for _ in range(opt.parameters.wind_iterations + 1):
+                orc.iterative_winds_sweep(u_l, v_l, w_l, *geo, dxf)
+                hc.exchange_uv(tile, 11, 12, which=which)
+            w_l = orc.balance_uvw(u_l, v_l, *geo[:4], dxf)
+            for name, a, b in zip("uvw", got, (u_l, v_l, w_l)):
+                assert np.array_equal(a, b), f"rank {rank} which={which} {name}: {(a != b).sum()} cells differ from the tiled oracle"
+            assert not np.array_equal(u_l, cut(ug))
+        d.close()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(target, world, adv):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -187,6 +244,12 @@ def test_tiled_mpdata_equals_tiled_oracle():
     from oracle import orc
     orc.build()
     _run(_worker_oracle, 4, "mpdata")
+
+
+def test_tiled_iterative_winds_equals_tiled_oracle():
+    from oracle import orc
+    orc.build()
+    _run(_worker_iw, 4, "upwind")
 
 
 @pytest.mark.parametrize("world,adv", [(2, "upwind"), (4, "upwind"), (4, "mpdata")])

@@ -113,6 +113,39 @@ def test_update_winds_first_and_later_calls(oracle):
     d.close()
 
 
+@pytest.mark.parametrize("iters", [0, 7])
+def test_iterative_winds_single_image(oracle, iters):
+    """update_winds with windtype kITERATIVE_WINDS (wind.f90:311-313, :341-343 -> iterative_winds
+    :371-498 -> balance_uvw).  FP32 streaming arithmetic in the reference's statement order => bit-exact, for the first
+    call (winds) and for a later call (the dqdt_3d form)."""
+    from icar_amd.wind import update_winds, kITERATIVE_WINDS
+    c = case(52, 31, 11, seed=11)
+    geo = (c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], c["jacobian"], float(c["dx"]))
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.windtype = kITERATIVE_WINDS; opt.parameters.wind_iterations = iters
+    update_winds(d, opt)
+    u, v, _ = oracle.iterative_winds(c["u"], c["v"], *geo, iters)
+    w = oracle.balance_uvw(u, v, *geo[:4], geo[5])
+    assert bits_equal(d.get("u"), u) and bits_equal(d.get("v"), v) and bits_equal(d.get("w"), w)
+    assert not np.array_equal(u, c["u"]) and not np.array_equal(v, c["v"])
+    # the sweeps must actually remove divergence: compare the residual of the adjusted winds with the balanced-only ones
+    if iters:
+        u0, v0, w0 = oracle.iterative_winds(c["u"], c["v"], *geo, -1)          # balance + top correction, no sweep
+        r0 = np.abs(oracle.calc_divergence(u0, v0, w0, *geo)[2:-2, :, 2:-2]).mean()
+        _, _, wi = oracle.iterative_winds(c["u"], c["v"], *geo, iters)
+        r1 = np.abs(oracle.calc_divergence(u, v, wi, *geo)[2:-2, :, 2:-2]).mean()
+        assert r1 < 0.5 * r0, (r0, r1)
+    rng = np.random.default_rng(4)
+    du = (0.01 * rng.standard_normal(c["u"].shape)).astype(np.float32); dv = (0.01 * rng.standard_normal(c["v"].shape)).astype(np.float32)
+    d.set_dqdt("u", du); d.set_dqdt("v", dv)
+    update_winds(d, opt)
+    u2, v2, _ = oracle.iterative_winds(du, dv, *geo, iters)
+    w2 = oracle.balance_uvw(u2, v2, *geo[:4], geo[5])
+    assert bits_equal(d.get_dqdt("u"), u2) and bits_equal(d.get_dqdt("v"), v2) and bits_equal(d.get_dqdt("w"), w2)
+    assert bits_equal(d.get("u"), u) and bits_equal(d.get("w"), w)             # the winds themselves stay
+    d.close()
+
+
 def test_output_file_from_device_fields(tmp_path):
     """output_t.save_file on a real domain_t: the file holds what domain%...%data_3d holds after the step (NetCDF classic,
     the reference's names / dimension order; icar_amd/output.py)."""
