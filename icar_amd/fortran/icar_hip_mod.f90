@@ -13,7 +13,7 @@ module icar_hip
   private
   public :: hip_ctx_t, hip_create, hip_destroy, hip_upload, hip_download, hip_upload_2dd, hip_download_2dd, &
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
-            hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds
+            hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
@@ -78,6 +78,15 @@ module icar_hip
        import; type(c_ptr), value :: ctx; real(c_float), value :: dx; real(c_float), intent(in) :: dz_levels(*); real(c_float), intent(out) :: res
      end function
      integer(c_int) function icar_hip_balance_uvw(ctx, dx) bind(C, name="icar_hip_balance_uvw")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dx
+     end function
+     integer(c_int) function icar_hip_iterative_winds_correct_w(ctx, update) bind(C, name="icar_hip_iterative_winds_correct_w")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: update
+     end function
+     integer(c_int) function icar_hip_iterative_winds_sweep(ctx, dx, nsweeps, update) bind(C, name="icar_hip_iterative_winds_sweep")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dx; integer(c_int), value :: nsweeps, update
+     end function
+     integer(c_int) function icar_hip_balance_uvw_update(ctx, dx) bind(C, name="icar_hip_balance_uvw_update")
        import; type(c_ptr), value :: ctx; real(c_float), value :: dx
      end function
      integer(c_int) function icar_hip_linwinds_setup(ctx, opt, terrain, nxg, nyg, ids, jds, dx) bind(C, name="icar_hip_linwinds_setup")
@@ -216,6 +225,26 @@ contains
     type(hip_ctx_t), intent(in) :: ctx
     real, intent(in) :: dx
     call check(icar_hip_balance_uvw(ctx%p, real(dx,c_float)), "balance_uvw")
+  end subroutine
+
+  !> iterative_winds (wind.f90:371-498) on ONE image (exchange_u / exchange_v are no-ops there): balance_uvw, the model-top
+  !> correction of w, then wind_iterations+1 Jacobi sweeps.  A multi-image host calls the two entry points itself and
+  !> keeps its `call domain%u%exchange_u(); call domain%v%exchange_v()` between single sweeps.
+  subroutine hip_iterative_winds(ctx, dx, wind_iterations, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dx
+    integer, intent(in) :: wind_iterations
+    logical, intent(in), optional :: update
+    integer(c_int) :: upd
+    upd = 0
+    if (present(update)) upd = merge(1, 0, update)
+    if (upd == 1) then
+       call check(icar_hip_balance_uvw_update(ctx%p, real(dx,c_float)), "balance_uvw_update")
+    else
+       call check(icar_hip_balance_uvw(ctx%p, real(dx,c_float)), "balance_uvw")
+    end if
+    call check(icar_hip_iterative_winds_correct_w(ctx%p, upd), "iterative_winds_correct_w")
+    call check(icar_hip_iterative_winds_sweep(ctx%p, real(dx,c_float), int(wind_iterations+1,c_int), upd), "iterative_winds_sweep")
   end subroutine
 
   !> setup_linwinds (linear_winds.f90:1180): terrain spectrum, wavenumber axes, zeroed perturbation state
