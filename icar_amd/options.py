@@ -81,6 +81,8 @@ class parameter_options_type:            # opt_types.f90:188-326 (subset on the 
     ideal: bool = False
     space_varying_dz: bool = False       # options_obj.f90:1936
     wind_iterations: int = 100           # options_obj.f90:1029
+    restart_file: str = ""               # options_obj.f90 restart_info namelist
+    restart_step_in_file: int = 1
 
 
 @dataclass

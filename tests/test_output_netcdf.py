@@ -43,3 +43,43 @@ def test_output_file_layout_and_append(tmp_path):
     assert r["_attrs_time"]["units"] == b"days since 1858-11-17 00:00:00"
     assert r["_attrs_qv"]["standard_name"] == b"mass_fraction_of_water_vapor_in_air" and r["_attrs_qv"]["units"] == b"kg kg-1"
     assert r["_attributes"]["Conventions"] == b"CF-1.6" and int(r["_attributes"]["image"]) == 3 and r["_attributes"]["dx"] == b"2000.0"
+
+
+def test_restart_reads_back_what_output_wrote(tmp_path):
+    """restart.f90:22-81 + :83-100: every dataset variable of record `restart_step_in_file` goes back into the domain in
+    data_3d(i,k,j) order; a file from another decomposition is refused; the image filename has its hour field zeroed."""
+    import pytest
+    from icar_amd.restart import read_restart_data, restart_model, get_image_filename
+    from icar_amd.options import options_t
+
+    class Dom(FakeDomain):
+        def shape(self, fid): return self.f[fid].shape
+        @staticmethod
+        def fid(name): return name
+        def set(self, name, a):
+            assert a.dtype == self.f[name].dtype or name != "accumulated_precipitation"
+            self.f[name] = np.array(a)
+
+    d = Dom(9, 6, 4, seed=1)
+    o = output_t(image=1)
+    o.add_variables(["water_vapor", "potential_temperature", "u", "v", "precipitation", "z"])
+    fn = str(tmp_path / "r.nc")
+    rec1 = {k: v.copy() for k, v in d.f.items()}
+    o.save_file(d, fn, 1, 51545.0)
+    for k in d.f: d.f[k] = d.f[k] * 2
+    rec2 = {k: v.copy() for k, v in d.f.items()}
+    o.save_file(d, fn, 2, 51545.25)
+    fresh = Dom(9, 6, 4, seed=7)
+    read_restart_data(fresh, o, fn, 1)
+    for k in rec1:
+        want = rec1["z"] if k == "z" else rec1[k]
+        assert np.array_equal(fresh.f[k], want), k
+    opt = options_t(); opt.parameters.restart_file = fn; opt.parameters.restart_step_in_file = 2
+    restart_model(fresh, o, opt)
+    for k in rec2:
+        want = rec1["z"] if k == "z" else rec2[k]            # z has no time dimension: written once, at creation
+        assert np.array_equal(fresh.f[k], want), k
+    with pytest.raises(Exception, match="does not match"):
+        read_restart_data(Dom(8, 6, 4), o, fn, 1)
+    when = datetime.datetime(2010, 10, 3, 14, 30, 0)
+    assert get_image_filename(12, "restart/icar_rst_", when) == "restart/icar_rst_000012_2010-10-03_00-30-00.nc"
