@@ -25,7 +25,7 @@ size_t icar_field_count(const icar_hip_ctx *c, int f)
     const size_t nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
     if (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U || f == ICAR_F_DZDX) return (nx + 1) * nz * ny;
     if (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V || f == ICAR_F_DZDY) return nx * nz * (ny + 1);
-    if (field_is_2dd(f) || f == ICAR_F_SURFACE_PRESSURE) return nx * ny;
+    if (field_is_2dd(f) || f == ICAR_F_SURFACE_PRESSURE || (f >= ICAR_F_IVT && f <= ICAR_F_IWI)) return nx * ny;
     return nx * nz * ny;
 }
 

@@ -71,6 +71,51 @@ k_diag_wreal(Dims d, const float *__restrict__ u, const float *__restrict__ v, c
     }
 }
 
+// optional column integrals (:126-144 -> compute_ivt / compute_iq, atm_utilities.f90:35-102): one thread per column,
+// levels kms..kme-1 bottom-up in the reference's accumulation order; the layer is cut at 500 hPa
+struct ColumnArgs { const float *qv, *um, *vm, *p_i, *liq[2], *ice[3]; float *ivt, *iwv, *iwl, *iwi; };
+
+__global__ void __launch_bounds__(64)
+k_diag_columns(Dims d, ColumnArgs a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
+    if (i >= d.nx) return;
+    const float gravity = 9.81f;                                    // icar_constants.f90
+    float ivt = 0.0f, iwv = 0.0f, iwl = 0.0f, iwi = 0.0f;
+    float pk = a.p_i[d.idx(i, 0, j)];
+    for (int k = 0; k < d.nz - 1; ++k) {
+        const int c = d.idx(i, k, j);
+        const float pk1 = a.p_i[c + d.sk];
+        float dp; bool use = true;
+        if (pk1 > 50000.0f) dp = pk - pk1;
+        else if (pk > 50000.0f) dp = pk - 50000.0f;
+        else { dp = 0.0f; use = false; }
+        if (use) {
+            if (a.ivt) { const float u = a.um[c], v = a.vm[c]; ivt = ivt + (a.qv[c] * sqrtf(u * u + v * v) * dp) / gravity; }
+            if (a.iwv) iwv = iwv + (a.qv[c] * dp) / gravity;
+            if (a.iwl) {
+                float t = 0.0f;
+                if (a.liq[0]) t = t + a.liq[0][c];
+                if (a.liq[1]) t = t + a.liq[1][c];
+                iwl = iwl + (t * dp) / gravity;
+            }
+            if (a.iwi) {
+                float t = 0.0f;
+                if (a.ice[0]) t = t + a.ice[0][c];
+                if (a.ice[1]) t = t + a.ice[1][c];
+                if (a.ice[2]) t = t + a.ice[2][c];
+                iwi = iwi + (t * dp) / gravity;
+            }
+        }
+        pk = pk1;
+    }
+    const int o = i + d.nx * j;
+    if (a.ivt) a.ivt[o] = ivt;
+    if (a.iwv) a.iwv[o] = iwv;
+    if (a.iwl) a.iwl[o] = iwl;
+    if (a.iwi) a.iwi[o] = iwi;
+}
+
 struct ForceArgs { float *x[16]; const float *dq[16]; int stag[16]; int fb[16]; };
 
 __global__ void __launch_bounds__(256)
@@ -113,6 +158,18 @@ int icar_diagnostic_update_run(icar_hip_ctx *c)
     ScopedTimer t(c, "diag");
     dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
     hipLaunchKernelGGL(k_diag_thermo, g, b, 0, c->stream, c->d, p, th, ex, pi, ps, T, Ti, rho, u, v, um, vm);
+    ColumnArgs ca;
+    ca.ivt = (float *)c->field[ICAR_F_IVT]; ca.iwv = (float *)c->field[ICAR_F_IWV];
+    ca.iwl = (float *)c->field[ICAR_F_IWL]; ca.iwi = (float *)c->field[ICAR_F_IWI];
+    if (ca.ivt || ca.iwv || ca.iwl || ca.iwi) {
+        ca.qv = (const float *)c->field[ICAR_F_WATER_VAPOR]; ca.um = um; ca.vm = vm; ca.p_i = pi;
+        ca.liq[0] = (const float *)c->field[ICAR_F_CLOUD_WATER]; ca.liq[1] = (const float *)c->field[ICAR_F_RAIN];
+        ca.ice[0] = (const float *)c->field[ICAR_F_CLOUD_ICE]; ca.ice[1] = (const float *)c->field[ICAR_F_SNOW];
+        ca.ice[2] = (const float *)c->field[ICAR_F_GRAUPEL];
+        if ((ca.ivt || ca.iwv) && !ca.qv) { icar_set_error("diagnostic_update: ivt / iwv need water_vapor on the device"); return 1; }
+        if (ca.ivt && (!um || !vm)) { icar_set_error("diagnostic_update: ivt needs u and v on the device"); return 1; }
+        hipLaunchKernelGGL(k_diag_columns, dim3((c->d.nx + 63) / 64, c->d.ny), dim3(64), 0, c->stream, c->d, ca);
+    }
     const float *w = (const float *)c->field[ICAR_F_W], *dzdx = (const float *)c->field[ICAR_F_DZDX];
     const float *dzdy = (const float *)c->field[ICAR_F_DZDY], *jaco = (const float *)c->field[ICAR_F_JACOBIAN];
     if (u && v && w && dzdx && dzdy && jaco) {

@@ -71,7 +71,12 @@ enum icar_hip_field {
     /* linear-theory winds (src/physics/linear_winds.f90:840-1127) */
     ICAR_F_Z = 35,                 /* domain%z%data_3d (mass-level height)  */
     ICAR_F_NSQUARED = 36,          /* domain%nsquared%data_3d               */
-    ICAR_N_FIELDS = 37
+    /* optional column integrals of diagnostic_update (src/main/time_step.f90:126-144), REAL(4) (nx,ny) */
+    ICAR_F_IVT = 37,               /* domain%ivt%data_2d  integrated vapour transport            */
+    ICAR_F_IWV = 38,               /* domain%iwv%data_2d  integrated water vapour                */
+    ICAR_F_IWL = 39,               /* domain%iwl%data_2d  integrated liquid (cloud + rain)       */
+    ICAR_F_IWI = 40,               /* domain%iwi%data_2d  integrated ice (ice + snow + graupel)  */
+    ICAR_N_FIELDS = 41
 };
 
 enum { ICAR_ADV_UPWIND = 1, ICAR_ADV_MPDATA = 2 };   /* kADV_UPWIND / kADV_MPDATA, icar_constants.f90:341 */
@@ -153,8 +158,10 @@ int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, fl
 
 /* ---- T3: diagnostic_update (src/main/time_step.f90:49-198) ------------------------------------
  * exner=(p/1e5)^(Rd/cp), interface pressure/temperature, surface pressure, T=theta*exner,
- * rho=p/(Rd T), u_mass, v_mass, w_real (uses DZDX, DZDY, JACOBIAN).  The optional column integrals
- * (ivt/iwv/iwl/iwi) and 10 m winds are "not associated" here. */
+ * rho=p/(Rd T), u_mass, v_mass, w_real (uses DZDX, DZDY, JACOBIAN).  The optional column integrals ivt / iwv / iwl / iwi
+ * (compute_ivt, compute_iq: src/utilities/atm_utilities.f90:35-102) are computed for every one of ICAR_F_IVT..IWI the
+ * host has uploaded once (= `associated(domain%ivt%data_2d)`); iwl / iwi sum the hydrometeor fields that are on the
+ * device, like the reference's `associated` tests.  The 10 m winds need roughness_z0 (LSM) and stay host-side. */
 int icar_hip_diagnostic_update(icar_hip_ctx *ctx);
 
 /* ---- F1: apply_forcing / enforce_limits (src/objects/domain_obj.f90:2383-2448, 2228-2243) ----

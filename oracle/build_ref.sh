@@ -2,8 +2,9 @@
 # oracle/build_ref.sh -- TEST INFRASTRUCTURE. Builds oracle/_ref/libicar_ref.so from the
 # reference sources WHERE THEY LIE under /root/reference (nothing is copied into the repo).
 #
-# What is compiled (unmodified, flang -O2): the reference's hot-path modules and the interface
-# modules they `use` (recipe: SURVEY.md Appendix B).  The NetCDF/FFTW-dependent *_obj.f90
+# What is compiled (unmodified, flang -O2): the reference's hot-path modules, the interface
+# modules they `use` (recipe: SURVEY.md Appendix B) and the two helper modules rows T3 / W2 call
+# (utilities/atm_utilities.f90, utilities/array_utilities.f90).  The NetCDF/FFTW-dependent *_obj.f90
 # submodule bodies are not on the path and are not compiled; their never-called type-bound
 # procedures stay unresolved (-Wl,--unresolved-symbols=ignore-all).
 #
@@ -31,7 +32,7 @@ for f in constants/icar_constants constants/wrf_constants utilities/time_delta_o
          main/data_structures objects/opt_types objects/options_h utilities/assertions objects/grid_h \
          objects/meta_data_h objects/variable_h objects/variable_dict_h objects/exchangeable_h \
          objects/boundary_h objects/domain_h objects/grid_obj physics/adv_mpdata physics/advect \
-         physics/mp_simple physics/mp_thompson ; do
+         physics/mp_simple physics/mp_thompson utilities/atm_utilities utilities/array_utilities ; do
   o=$(basename $f).o
   if [ ! -f "$o" ] || [ "$R/$f.f90" -nt "$o" ]; then
     $FC $FLAGS "$R/$f.f90" -o "$o" 2>&1 | grep -v "multi image Fortran features" || true
@@ -41,7 +42,7 @@ $FC $FLAGS "$HERE/ref_shim.f90" -o ref_shim.o 2>&1 | grep -v "multi image Fortra
 OBJS="ref_shim.o ref_link_stubs.o ref_link_stubs_c.o \
     adv_mpdata.o advect.o mp_simple.o mp_thompson.o icar_constants.o wrf_constants.o data_structures.o \
     opt_types.o options_h.o domain_h.o grid_h.o variable_h.o variable_dict_h.o meta_data_h.o \
-    exchangeable_h.o boundary_h.o time_h.o time_delta_obj.o assertions.o grid_obj.o"
+    exchangeable_h.o boundary_h.o time_h.o time_delta_obj.o assertions.o grid_obj.o atm_utilities.o array_utilities.o"
 # The interface modules carry type-bound-procedure tables that point at bodies living in the
 # (uncompiled, NetCDF-dependent) *_obj.f90 submodules.  They are never called on this path; bind
 # each such dangling Fortran module symbol (_QM*) to address 0, which is what a static link with

@@ -114,6 +114,36 @@ def diagnostic_update(p, th, u, v, w, dzdx, dzdy, jaco):
     return out
 
 
+def compute_ivt(qv, u_mass, v_mass, p_i):
+    ny, nz, nx = qv.shape
+    out = np.zeros((ny, nx), np.float32)
+    lib().orc_compute_ivt(_i(nx), _i(nz), _i(ny), _p(qv), _p(u_mass), _p(v_mass), _p(p_i), _p(out))
+    return out
+
+
+def compute_iq(q, p_i):
+    ny, nz, nx = q.shape
+    out = np.zeros((ny, nx), np.float32)
+    lib().orc_compute_iq(_i(nx), _i(nz), _i(ny), _p(q), _p(p_i), _p(out))
+    return out
+
+
+def calc_stability(th_top, th_bot, pii_top, pii_bot, z_top, z_bot, qv_top, qv_bot, qc, variable_N=True, N_squared=1e-5):
+    a = [np.ascontiguousarray(x, np.float32) for x in (th_top, th_bot, pii_top, pii_bot, z_top, z_bot, qv_top, qv_bot, qc)]
+    out = np.zeros(a[0].size, np.float32)
+    lib().orc_calc_stability_n(_i(a[0].size), _i(int(variable_N)), _f(N_squared), *[_p(x) for x in a], _p(out))
+    return out
+
+
+def calc_weight(axis, bestpos, match):
+    axis = np.ascontiguousarray(axis, np.float32); bestpos = np.ascontiguousarray(bestpos, np.int32)
+    match = np.ascontiguousarray(match, np.float32)
+    nextpos = np.zeros(bestpos.size, np.int32); w = np.zeros(bestpos.size, np.float32)
+    lib().orc_calc_weight_n(_i(axis.size), _p(axis), _i(bestpos.size), bestpos.ctypes.data_as(ctypes.c_void_p), _p(match),
+                            nextpos.ctypes.data_as(ctypes.c_void_p), _p(w))
+    return nextpos, w
+
+
 def apply_forcing(x, dqdt, dt, force_boundaries, west, east, south, north):
     nym, nz, nxm = x.shape
     lib().orc_apply_forcing(_i(nxm), _i(nz), _i(nym), _p(x), _p(dqdt), ctypes.c_double(dt), _i(force_boundaries),

@@ -124,3 +124,65 @@ def grid(nx, ny, nz, nimages, image, nx_extra=0, ny_extra=0):
     lib().ref_grid(ctypes.c_int(nx), ctypes.c_int(ny), ctypes.c_int(nz), ctypes.c_int(nimages), ctypes.c_int(image),
                    ctypes.c_int(nx_extra), ctypes.c_int(ny_extra), out)
     return dict(zip(GRID_MEMBERS, list(out)))
+
+
+# ---- helper modules compiled unmodified: utilities/atm_utilities.f90, utilities/array_utilities.f90 -------------------
+def _i(x):
+    return ctypes.c_int(int(x))
+
+
+def exner(p):
+    p = np.ascontiguousarray(p, np.float32); out = np.empty_like(p)
+    lib().ref_exner(_i(p.size), _p(p), _p(out))
+    return out
+
+
+def wind_polar(u, v):
+    """calc_direction, calc_speed and calc_u / calc_v of those: (direction, speed, u_back, v_back)."""
+    u = np.ascontiguousarray(u, np.float32); v = np.ascontiguousarray(v, np.float32)
+    o = [np.empty_like(u) for _ in range(4)]
+    lib().ref_wind_polar(_i(u.size), _p(u), _p(v), *[_p(x) for x in o])
+    return o
+
+
+def calc_stability(th_top, th_bot, pii_top, pii_bot, z_top, z_bot, qv_top, qv_bot, qc):
+    a = [np.ascontiguousarray(x, np.float32) for x in (th_top, th_bot, pii_top, pii_bot, z_top, z_bot, qv_top, qv_bot, qc)]
+    out = np.empty_like(a[0])
+    lib().ref_calc_stability(_i(a[0].size), *[_p(x) for x in a], _p(out))
+    return out
+
+
+def compute_ivt(qv, u, v, p_i):
+    ny, nz, nx = qv.shape
+    out = np.zeros((ny, nx), np.float32)
+    lib().ref_compute_ivt(_i(nx), _i(nz), _i(ny), _p(qv), _p(u), _p(v), _p(p_i), _p(out))
+    return out
+
+
+def compute_iq(q, p_i):
+    ny, nz, nx = q.shape
+    out = np.zeros((ny, nx), np.float32)
+    lib().ref_compute_iq(_i(nx), _i(nz), _i(ny), _p(q), _p(p_i), _p(out))
+    return out
+
+
+def linear_space(vmin, vmax, n):
+    out = np.zeros(n, np.float32)
+    lib().ref_linear_space(_i(n), _f(vmin), _f(vmax), _p(out))
+    return out
+
+
+def calc_weight(axis, bestpos, match):
+    axis = np.ascontiguousarray(axis, np.float32); bestpos = np.ascontiguousarray(bestpos, np.int32)
+    match = np.ascontiguousarray(match, np.float32)
+    nextpos = np.zeros(bestpos.size, np.int32); w = np.zeros(bestpos.size, np.float32)
+    lib().ref_calc_weight(_i(axis.size), _p(axis), _i(bestpos.size), bestpos.ctypes.data_as(ctypes.c_void_p), _p(match),
+                          nextpos.ctypes.data_as(ctypes.c_void_p), _p(w))
+    return nextpos, w
+
+
+def smooth_array_3d(a, windowsize, ydim=3):
+    """a: numpy (ny, nz, nx) == Fortran (nx, nz, ny); smoothed in place."""
+    ny, nz, nx = a.shape
+    lib().ref_smooth_array_3d(_i(nx), _i(nz), _i(ny), _p(a), _i(windowsize), _i(ydim))
+    return a

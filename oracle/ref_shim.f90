@@ -20,6 +20,9 @@ module icar_ref_shim
   use options_types,     only: mp_options_type
   use domain_interface,  only: domain_t
   use grid_interface,    only: grid_t
+  use mod_atm_utilities, only: exner_function, calc_direction, calc_speed, calc_u, calc_v, calc_stability, &
+                               compute_ivt, compute_iq, sat_mr
+  use array_utilities,   only: smooth_array, linear_space, calc_weight
   use prif,              only: stub_num_images
   use adv_mpdata,        only: mpdata
   use adv_upwind,        only: upwind
@@ -194,5 +197,81 @@ contains
            g%ns_halo_nx, g%ew_halo_ny, g%halo_nz, g%halo_size, g%nx_global, g%ny_global, g%nx, g%ny, g%nz, &
            g%ids, g%ide, g%jds, g%jde, g%kds, g%kde, g%its, g%ite, g%jts, g%jte, g%kts, g%kte, &
            merge(1, 0, g%is2d), merge(1, 0, g%is3d)]
+  end subroutine
+
+  !> helpers of src/utilities/atm_utilities.f90 (exner_function :682, calc_direction :334, calc_speed :361, calc_u :373,
+  !! calc_v :385, calc_stability :448, compute_ivt :35, compute_iq :73) and src/utilities/array_utilities.f90
+  !! (linear_space :215, calc_weight :263, smooth_array_3d :308) that rows T3 and W2 call -- element-wise over n values
+  subroutine ref_exner(n, p, out) bind(C, name="ref_exner")
+    integer(c_int), value :: n
+    real(c_float), intent(in) :: p(n)
+    real(c_float), intent(out) :: out(n)
+    out = exner_function(p)
+  end subroutine
+
+  subroutine ref_wind_polar(n, u, v, direction, speed, u_back, v_back) bind(C, name="ref_wind_polar")
+    integer(c_int), value :: n
+    real(c_float), intent(in) :: u(n), v(n)
+    real(c_float), intent(out) :: direction(n), speed(n), u_back(n), v_back(n)
+    integer :: i
+    do i = 1, n
+       direction(i) = calc_direction(u(i), v(i))
+    end do
+    speed = calc_speed(u, v)
+    u_back = calc_u(direction, speed)
+    v_back = calc_v(direction, speed)
+  end subroutine
+
+  subroutine ref_calc_stability(n, th_top, th_bot, pii_top, pii_bot, z_top, z_bot, qv_top, qv_bot, qc, out) bind(C, name="ref_calc_stability")
+    integer(c_int), value :: n
+    real(c_float), intent(in), dimension(n) :: th_top, th_bot, pii_top, pii_bot, z_top, z_bot, qv_top, qv_bot, qc
+    real(c_float), intent(out) :: out(n)
+    integer :: i
+    do i = 1, n
+       out(i) = calc_stability(th_top(i), th_bot(i), pii_top(i), pii_bot(i), z_top(i), z_bot(i), qv_top(i), qv_bot(i), qc(i))
+    end do
+  end subroutine
+
+  subroutine ref_compute_ivt(nx, nz, ny, qv, u, v, p_i, out) bind(C, name="ref_compute_ivt")
+    integer(c_int), value :: nx, nz, ny
+    real(c_float), intent(in), dimension(nx,nz,ny) :: qv, u, v, p_i
+    real(c_float), intent(out) :: out(nx,ny)
+    call compute_ivt(out, qv, u, v, p_i)
+  end subroutine
+
+  subroutine ref_compute_iq(nx, nz, ny, q, p_i, out) bind(C, name="ref_compute_iq")
+    integer(c_int), value :: nx, nz, ny
+    real(c_float), intent(in), dimension(nx,nz,ny) :: q, p_i
+    real(c_float), intent(out) :: out(nx,ny)
+    call compute_iq(out, q, p_i)
+  end subroutine
+
+  subroutine ref_linear_space(n, vmin, vmax, out) bind(C, name="ref_linear_space")
+    integer(c_int), value :: n
+    real(c_float), value :: vmin, vmax
+    real(c_float), intent(out) :: out(n)
+    real, allocatable :: a(:)
+    call linear_space(a, vmin, vmax, n)
+    out = a
+  end subroutine
+
+  !> calc_weight for m (bestpos, match) pairs on one axis; nextpos comes back 1-based like the reference's
+  subroutine ref_calc_weight(n, axis, m, bestpos, match, nextpos, weight) bind(C, name="ref_calc_weight")
+    integer(c_int), value :: n, m
+    real(c_float), intent(in) :: axis(n), match(m)
+    integer(c_int), intent(in) :: bestpos(m)
+    integer(c_int), intent(out) :: nextpos(m)
+    real(c_float), intent(out) :: weight(m)
+    integer :: i
+    do i = 1, m
+       nextpos(i) = -1
+       weight(i) = calc_weight(axis, bestpos(i), nextpos(i), match(i))
+    end do
+  end subroutine
+
+  subroutine ref_smooth_array_3d(nx, nz, ny, wind, windowsize, ydim) bind(C, name="ref_smooth_array_3d")
+    integer(c_int), value :: nx, nz, ny, windowsize, ydim
+    real(c_float), intent(inout) :: wind(nx,nz,ny)
+    call smooth_array(wind, windowsize, ydim)
   end subroutine
 end module icar_ref_shim

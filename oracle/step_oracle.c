@@ -6,7 +6,9 @@
  *   balance_uvw         src/physics/wind.f90:81-169 (+ calc_divergence :172-228)
  *   iterative_winds     src/physics/wind.f90:371-498 (stages split so a tiled run can exchange_u/v between them)
  *   compute_dt (3)      src/main/time_step.f90:264-289
- * PARITY UNPINNED by execution: these procedures live in NetCDF/coarray-dependent units
+ * PINNED by execution (tests/test_oracle_helpers_vs_ref.py, vs utilities/atm_utilities.f90 compiled unmodified into
+ * oracle/_ref): exner_function, compute_ivt, compute_iq.
+ * PARITY UNPINNED by execution for the rest: these procedures live in NetCDF/coarray-dependent units
  * (domain_obj.f90, time_step.f90, wind.f90) that cannot be compiled in this image; the code below is
  * restated from the source statement by statement.
  */
@@ -56,6 +58,30 @@ void orc_diagnostic_update(int nx, int nz, int ny, const float *p, const float *
 }
 
 /* x has extents (nxm, nz, nym) (staggered fields pass their own extents) */
+/* compute_ivt / compute_iq, src/utilities/atm_utilities.f90:35-64 / :73-102 (q2d accumulates over k = kms..kme-1) */
+void orc_compute_ivt(int nx, int nz, int ny, const float *qv, const float *u, const float *v, const float *p_i, float *ivt)
+{
+    const float gravity = 9.81f;
+    for (size_t t = 0; t < (size_t)nx * ny; ++t) ivt[t] = 0;
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz - 1; ++k) for (int i = 0; i < nx; ++i) {
+        const size_t c = IDX(i, k, j), o = (size_t)i + (size_t)nx * j;
+        const float sp = sqrtf(u[c] * u[c] + v[c] * v[c]);
+        if (p_i[IDX(i, k + 1, j)] > 50000) ivt[o] = ivt[o] + (qv[c] * sp * (p_i[c] - p_i[IDX(i, k + 1, j)])) / gravity;
+        else if (p_i[c] > 50000) ivt[o] = ivt[o] + (qv[c] * sp * (p_i[c] - 50000)) / gravity;
+    }
+}
+
+void orc_compute_iq(int nx, int nz, int ny, const float *q, const float *p_i, float *iq)
+{
+    const float gravity = 9.81f;
+    for (size_t t = 0; t < (size_t)nx * ny; ++t) iq[t] = 0;
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz - 1; ++k) for (int i = 0; i < nx; ++i) {
+        const size_t c = IDX(i, k, j), o = (size_t)i + (size_t)nx * j;
+        if (p_i[IDX(i, k + 1, j)] > 50000) iq[o] = iq[o] + (q[c] * (p_i[c] - p_i[IDX(i, k + 1, j)])) / gravity;
+        else if (p_i[c] > 50000) iq[o] = iq[o] + (q[c] * (p_i[c] - 50000)) / gravity;
+    }
+}
+
 void orc_apply_forcing(int nxm, int nz, int nym, float *x, const float *dqdt, double dt, int force_boundaries,
                        int west, int east, int south, int north)
 {

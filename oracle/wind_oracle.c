@@ -5,9 +5,11 @@
  *   calc_direction/speed src/utilities/atm_utilities.f90:334-367
  *   smooth_array (ydim=3) src/utilities/array_utilities.f90:308-417
  *   calc_weight          src/utilities/array_utilities.f90:263-288
- * PARITY UNPINNED by execution: linear_winds.f90 needs FFTW3 + the NetCDF/coarray domain object and cannot be
- * compiled in this image; no reference test holds expected values for it (test_caf_linear_winds_setup.f90 is a
- * smoke test).  The LUT-build half (row W3, FFT) is restated in oracle/wind_oracle.py.
+ * PINNED by execution (tests/test_oracle_helpers_vs_ref.py, bit-exact vs atm_utilities.f90 / array_utilities.f90
+ * compiled unmodified into oracle/_ref): calc_stability, calc_direction, calc_speed, calc_weight, smooth_array_3d.
+ * PARITY UNPINNED by execution: the body of spatial_winds itself -- linear_winds.f90 needs FFTW3 + the NetCDF/coarray
+ * domain object and cannot be compiled in this image; no reference test holds expected values for it
+ * (test_caf_linear_winds_setup.f90 is a smoke test).  The LUT-build half (row W3, FFT) is restated in oracle/wind_oracle.py.
  *
  * Index convention: arrays are Fortran order, 0-based here.  X(i,k,j) -> i + nx*(k + nz*j).
  * Math mode (icar_oracle.c: orc_set_math_mode): 0 = libm logf/expf/atanf as the compiled Fortran calls them,
@@ -71,6 +73,21 @@ static float calc_weight(const float *d, int n, int bestpos, int *nextpos, float
     if (bestpos == n) { *nextpos = n; return 1; }
     *nextpos = bestpos + 1;
     return (d[*nextpos - 1] - match) / (d[*nextpos - 1] - d[bestpos - 1]);
+}
+
+/* element-wise entry points for pinning the helpers against the compiled reference (oracle/ref.py) */
+void orc_calc_stability_n(int n, int variable_N, float N_squared, const float *th_top, const float *th_bot, const float *pii_top,
+                          const float *pii_bot, const float *z_top, const float *z_bot, const float *qv_top, const float *qv_bot,
+                          const float *qc, float *out)
+{
+    orc_lt_opts o = {0}; o.variable_N = variable_N; o.N_squared = N_squared;
+    for (int t = 0; t < n; ++t)
+        out[t] = calc_stability(&o, th_top[t], th_bot[t], pii_top[t], pii_bot[t], z_top[t], z_bot[t], qv_top[t], qv_bot[t], qc[t]);
+}
+
+void orc_calc_weight_n(int n, const float *axis, int m, const int *bestpos, const float *match, int *nextpos, float *weight)
+{
+    for (int t = 0; t < m; ++t) weight[t] = calc_weight(axis, n, bestpos[t], &nextpos[t], match[t]);
 }
 
 /* smooth_array_3d(wind, windowsize, ydim=3): wind is (nx, nlev, nrow) */

@@ -13,7 +13,9 @@ linear-theory wind LUT build, SURVEY.md section 8 row W3:
     initialize_spatial_winds        src/physics/linear_winds.f90:596-830   (LUT loop, destagger :766-772)
     linear_space / calc_u / calc_v  src/utilities/array_utilities.f90:215-237, atm_utilities.f90:373-391
 
-PARITY UNPINNED: linear_winds.f90 cannot be built in this image (it needs FFTW3's fftw3.f03 and the
+Pinned by execution (tests/test_oracle_helpers_vs_ref.py, vs the unmodified utility modules in oracle/_ref):
+linear_space, calc_u, calc_v.
+PARITY UNPINNED for everything else: linear_winds.f90 cannot be built in this image (it needs FFTW3's fftw3.f03 and the
 NetCDF/coarray-dependent domain object) and the reference's own test for it
 (tests/test_caf_linear_winds_setup.f90) is a smoke test without expected values.  Third-party
 arithmetic: FFTW3 (system package, unpinned; CI image Ubuntu 20.04 libfftw3 3.3.8); its documented

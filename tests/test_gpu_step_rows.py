@@ -44,6 +44,36 @@ def test_diagnostic_update(oracle):
     d.close()
 
 
+def test_diagnostic_update_column_integrals(oracle):
+    """The optional ivt / iwv / iwl / iwi of diagnostic_update (time_step.f90:126-144; compute_ivt / compute_iq pinned
+    against the compiled reference in test_oracle_helpers_vs_ref.py): computed only for the "associated" ones, from the
+    u_mass / v_mass / pressure_interface of the same call, hydrometeor sums over the fields that are on the device."""
+    c = case(45, 23, 30, seed=6)
+    c["pressure"] = (c["pressure"] * np.float32(1.0)).astype(np.float32)
+    d = single_image_domain(c)
+    zero2 = np.zeros((c["ny"], c["nx"]), np.float32)
+    for n in ("ivt", "iwv", "iwl"):
+        d.set(n, zero2)                                    # iwi stays "not associated"
+    d.diagnostic_update()
+    oracle.set_math_mode(1)
+    try:
+        r = oracle.diagnostic_update(c["pressure"], c["potential_temperature"], c["u"], c["v"], c["w"], c["dzdx"], c["dzdy"], c["jacobian"])
+    finally:
+        oracle.set_math_mode(0)
+    p_i = r["pressure_interface"]
+    assert bits_equal(d.get("pressure_interface"), p_i)
+    assert (p_i < 50000).any() and (p_i > 50000).any(), "the 500 hPa cut must be inside the column"
+    assert bits_equal(d.get("ivt"), oracle.compute_ivt(c["water_vapor"], r["u_mass"], r["v_mass"], p_i))
+    assert bits_equal(d.get("iwv"), oracle.compute_iq(c["water_vapor"], p_i))
+    liquid = (np.float32(0) + c["cloud_water"]) + c["rain"]
+    assert bits_equal(d.get("iwl"), oracle.compute_iq(liquid, p_i)) and float(d.get("iwv").max()) > 1.0
+    d.set("iwi", zero2)
+    d.diagnostic_update()
+    ice = ((np.float32(0) + c["cloud_ice"]) + c["snow"]) + c["graupel"]
+    assert bits_equal(d.get("iwi"), oracle.compute_iq(ice, p_i))
+    d.close()
+
+
 def test_apply_forcing_and_enforce_limits(oracle):
     c = case(40, 22, 9)
     rng = np.random.default_rng(11)
