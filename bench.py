@@ -86,6 +86,24 @@ def one_step(d, opt, group=None, device=None, cool=0.0):
     return dt
 
 
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask, capped by the cgroup CPU quota (v2 cpu.max or v1
+    cfs_quota).  omp_get_max_threads() reports the host's logical CPUs even inside a quota'd container."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(args, nscalars):
     """The CPU restatement (oracle/, bit-identical to the compiled reference kernels) timed on this
     box's host cores on a bounded sample of the same workload."""
@@ -93,6 +111,8 @@ def cpu_baseline(args, nscalars):
         from oracle import orc
         from icar_amd import ideal
         orc.build()
+        if "OMP_NUM_THREADS" not in os.environ:
+            orc.set_num_threads(usable_cpus())
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "grid-cell updates/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
     nx, ny, nz = 256, 256, args.nz
