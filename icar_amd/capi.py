@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libicar_hip.so")
+LIB_PATH = os.environ.get("ICAR_HIP_LIB") or os.path.join(_HERE, "lib", "libicar_hip.so")     # override: A/B builds of profiles/micro
 _lib = None
 
 

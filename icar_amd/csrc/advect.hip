@@ -15,6 +15,7 @@
 #include "ctx.h"
 #include <vector>
 #include <algorithm>
+#include <cstring>
 
 #define BX 64
 #define BY 4
@@ -26,7 +27,11 @@
 //    reach 1e-39 (one cell of tests/test_gpu_advect.py::test_mpdata_sparse_fields... differed by 1.4e-45);
 //  * a per-wave "all operands safe ? lean : IEEE" branch: slower than the IEEE division alone, because it cuts the basic
 //    block at every quotient and the independent divisions no longer interleave.
+#ifdef ICAR_EXPERIMENT_RCP
+__device__ __forceinline__ float fdiv(float n, float d) { return n * __builtin_amdgcn_rcpf(d); }
+#else
 __device__ __forceinline__ float fdiv(float n, float d) { return n / d; }
+#endif
 
 __device__ __forceinline__ float flux1(float l, float r, float U)
 {   // donor-cell flux, src/physics/adv_mpdata.f90:40
@@ -321,6 +326,170 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// A3, software-pipelined over the scalars.  The version above issues the 16 stencil loads of ONE scalar, waits, computes,
+// stores, and only then touches the next scalar: per wave one 256-B row segment of new HBM data is in flight at a time,
+// and with 8 waves per SIMD that caps the kernel at ~2 TB/s of traffic, far below what the arithmetic needs
+// (profiles/micro: replacing every IEEE division by v_rcp*mul removed half the VALU instructions and bought 8 %).
+// Here the stencil of the NEXT active scalar is loaded (unconditionally, offsets clamped at the domain edges) before the
+// current one is evaluated, so two scalars' worth of loads overlap the ~270 VALU instructions of one evaluation.
+// Arithmetic: identical expressions in identical order -- results are bit-identical to k_mpdata_fluxes.
+// ------------------------------------------------------------------------------------------------
+struct Stencil16 {
+    float c0, xm, xp, yp, ym, xm_yp, xm_ym, xp_ym, zp, zm, xm_zp, xm_zm, xp_zp, zp_ym, zm_ym, zp_yp;
+};
+struct StencilOff { int xm, xp, yp, ym, zp, zm; };
+
+__device__ __forceinline__ Stencil16 load_stencil(const float *__restrict__ q, int c, const StencilOff &o)
+{
+    Stencil16 s;
+    s.c0 = q[c]; s.xm = q[c + o.xm]; s.xp = q[c + o.xp]; s.yp = q[c + o.yp]; s.ym = q[c + o.ym];
+    s.xm_yp = q[c + o.xm + o.yp]; s.xm_ym = q[c + o.xm + o.ym]; s.xp_ym = q[c + o.xp + o.ym];
+    s.zp = q[c + o.zp]; s.zm = q[c + o.zm]; s.xm_zp = q[c + o.xm + o.zp]; s.xm_zm = q[c + o.xm + o.zm];
+    s.xp_zp = q[c + o.xp + o.zp]; s.zp_ym = q[c + o.zp + o.ym]; s.zm_ym = q[c + o.zm + o.ym]; s.zp_yp = q[c + o.zp + o.yp];
+    return s;
+}
+
+template <bool RHO>
+__global__ void __launch_bounds__(BX * BY)
+k_mpdata_fluxes_pipe(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int nv,
+                     const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ Wz,
+                     const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
+                     const unsigned char *__restrict__ occ)
+{
+    const TileId tb = xcd_tile(4);
+    const int i = tb.x * BX + threadIdx.x;
+    const int k = tb.y * BY + threadIdx.y;
+    const int j = tb.z;
+    unsigned needmask = (nv >= 32) ? ~0u : ((1u << nv) - 1u);
+    if (occ) {                                                      // see k_mpdata_fluxes
+        const int nt = (int)gridDim.x;
+        const size_t ostride = (size_t)d.ny * d.nz * nt;
+        needmask = 0;
+        const int lane = threadIdx.x;
+        for (int e = lane; e < 27 * nv; e += 64) {
+            const int m = e / 27, nb = e - m * 27;
+            const int jj = min(max(j + nb / 9 - 1, 0), d.ny - 1), kk = min(max(k + (nb / 3) % 3 - 1, 0), d.nz - 1);
+            const int ii = min(max(tb.x + nb % 3 - 1, 0), nt - 1);
+            if (occ[(size_t)m * ostride + ((size_t)jj * d.nz + kk) * nt + ii]) needmask |= 1u << m;
+        }
+        for (int dd = 32; dd > 0; dd >>= 1) needmask |= __shfl_xor(needmask, dd);
+        needmask = __builtin_amdgcn_readfirstlane(needmask);
+    }
+    if (i >= d.nx || k >= d.nz) return;
+    const int c = d.idx(i, k, j);
+    const int sk = d.sk, sj = d.sj;
+    const bool has_u = (i >= 1), has_v = (j >= 1), has_w = (k < d.nz - 1);
+    const bool j_in = (j > 0) && (j < d.ny - 1);
+    const bool k_in = (k > 0) && (k < d.nz - 1);
+    const bool i_in = (i > 0) && (i < d.nx - 1);
+    StencilOff o;
+    o.xm = has_u ? -1 : 0; o.xp = (i < d.nx - 1) ? 1 : 0;
+    o.ym = has_v ? -sj : 0; o.yp = (j < d.ny - 1) ? sj : 0;
+    o.zm = (k > 0) ? -sk : 0; o.zp = has_w ? sk : 0;
+
+    const float G0 = RHO ? jaco[c] * rho[c] : jaco[c];
+    float u = 0, Gsu = 1, au = 0, cu_v = 0, cu_w = 0;
+    if (has_u) {
+        u = U[c];
+        Gsu = G0 + (RHO ? jaco[c - 1] * rho[c - 1] : jaco[c - 1]);
+        au = fabsf(u) * (1 - fabsf(u) / (0.5f * Gsu));
+        if (j_in) cu_v = 0.5f * u * ((1 / 4.0f) * (V[c] + V[c + sj] + V[c - 1] + V[c - 1 + sj]));
+        if (k_in) cu_w = 0.5f * u * ((1 / 4.0f) * (Wz[c] + Wz[c - sk] + Wz[c - 1] + Wz[c - 1 - sk]));
+    }
+    float v = 0, Gsv = 1, av = 0, cv_u = 0, cv_w = 0;
+    if (has_v) {
+        v = V[c];
+        Gsv = G0 + (RHO ? jaco[c - sj] * rho[c - sj] : jaco[c - sj]);
+        av = fabsf(v) * (1 - fabsf(v) / (0.5f * Gsv));
+        const float ev = i_in ? (1 / 4.0f) * (U[c + 1] + U[c + 1 - sj] + U[c] + U[c - sj]) : 0.0f;
+        cv_u = 0.5f * v * ev;
+        if (k_in) cv_w = 0.5f * v * ((1 / 4.0f) * (Wz[c] + Wz[c - sk] + Wz[c - sj] + Wz[c - sk - sj]));
+    }
+    float w = 0, Gsw = 1, aw = 0, cw_u = 0, cw_v = 0, dzc = 0;
+    if (has_w) {
+        w = Wz[c];
+        Gsw = (RHO ? jaco[c + sk] * rho[c + sk] : jaco[c + sk]) + G0;
+        aw = fabsf(w) * (1 - fabsf(w) / (0.5f * Gsw));
+        const float ev = i_in ? (1 / 4.0f) * (U[c + 1] + U[c + 1 + sk] + U[c] + U[c + sk]) : 0.0f;
+        cw_u = 0.5f * w * ev;
+        if (j_in) cw_v = 0.5f * w * ((1 / 4.0f) * (V[c] + V[c + sk] + V[c + sj] + V[c + sk + sj]));
+        dzc = dz[c];
+    }
+
+    const unsigned all = (nv >= 32) ? ~0u : ((1u << nv) - 1u);
+    for (unsigned z = all & ~needmask; z; z &= z - 1) {             // wave-uniform: the whole stencil of this row segment is zero
+        const int m = __builtin_ctz(z);
+        u2o.p[m][c] = 0.0f; v2o.p[m][c] = 0.0f; w2o.p[m][c] = 0.0f;
+    }
+    unsigned active = needmask & all;
+    if (!active) return;
+    int m = __builtin_ctz(active); active &= active - 1;
+    Stencil16 s = load_stencil(qin.p[m], c, o);
+    for (;;) {
+        const int mn = active ? __builtin_ctz(active) : -1;
+        Stencil16 nx_ = s;
+        if (mn >= 0) nx_ = load_stencil(qin.p[mn], c, o);            // in flight while scalar m is evaluated
+        // ---- U face (i-1 | i) : adv_mpdata.f90:134-168
+        float r_u2 = 0.0f;
+        if (has_u) {
+            float val = fdiv(au * (s.c0 - s.xm), s.c0 + s.xm + 1e-10f);
+            if (j_in) {
+                const float a = s.yp, b = s.ym, e = s.xm_yp, f = s.xm_ym;
+                const float eq = fdiv(a - b + e - f, a + b + e + f + 1e-10f);
+                val = val - fdiv(cu_v * eq, Gsu);
+            }
+            if (k_in) {
+                const float a = s.zp, b = s.zm, e = s.xm_zp, f = s.xm_zm;
+                const float eq = fdiv(a - b + e - f, a + b + e + f + 1e-10f);
+                val = val - fdiv(cu_w * eq, Gsu);
+            }
+            r_u2 = val * 0.5f;
+        }
+        // ---- V face (j-1 | j) : :172-208
+        float r_v2 = 0.0f;
+        if (has_v) {
+            float val = fdiv(av * (s.c0 - s.ym), s.c0 + s.ym + 1e-10f);
+            {
+                float eq = 0.0f;
+                if (i_in) {
+                    const float a = s.xp_ym, b = s.xm, e = s.xp, f = s.xm_ym;
+                    eq = fdiv(a - b + e - f, e + a + b + f + 1e-10f);
+                }
+                val = val - fdiv(cv_u * eq, Gsv);
+            }
+            if (k_in) {
+                const float a = s.zp_ym, b = s.zm, e = s.zp, f = s.zm_ym;
+                const float eq = fdiv(a - b + e - f, a + b + e + f + 1e-10f);
+                val = val - fdiv(cv_w * eq, Gsv);
+            }
+            r_v2 = val * 0.5f;
+        }
+        // ---- W face (k | k+1) : :214-249
+        float r_w2 = 0.0f;
+        if (has_w) {
+            float val = fdiv(aw * (s.zp - s.c0), s.zp + s.c0 + 1e-10f);
+            {
+                float eq = 0.0f;
+                if (i_in) {
+                    const float a = s.xp_zp, b = s.xm, e = s.xp, f = s.xm_zp;
+                    eq = fdiv(a - b + e - f, e + a + b + f + 1e-10f);
+                }
+                val = val - fdiv(cw_u * eq, Gsw);
+            }
+            if (j_in) {
+                const float a = s.zp_yp, b = s.ym, e = s.yp, f = s.zp_ym;
+                const float eq = fdiv(a - b + e - f, e + f + a + b + 1e-10f);
+                val = val - fdiv(cw_v * eq, Gsw);
+            }
+            r_w2 = val * 0.5f * dzc;
+        }
+        u2o.p[m][c] = r_u2; v2o.p[m][c] = r_v2; w2o.p[m][c] = r_w2;
+        if (mn < 0) break;
+        s = nx_; m = mn; active &= active - 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // A4 core: limited pseudo-velocity of ONE face between cells a and b=a+1 of a 1-D line
 // (adv_mpdata_FCT_core.f90:47-116 with the loop-carried values recomputed from their definition).
 //   qm1,q0,q1,q2 : field after pass 1 at cells a-1,a,b,b+1     lm1,l0,l1,l2 : field before pass 1
@@ -381,15 +550,15 @@ template <bool RHO, bool FCT>
 __global__ void __launch_bounds__(64 * FBY)
 k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
                 const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
-                const unsigned char *__restrict__ needf)
+                const unsigned char *__restrict__ needf, int fjb)
 {
     __shared__ float s_wb[2][FBY][64];       // double-buffered by row parity: one barrier per row instead of two
     const int lane = threadIdx.x, ty = threadIdx.y;
     const TileId tb = xcd_tile(2);
     const int i = 1 + tb.x * 63 + lane;
     const int k = tb.y * (FBY - 1) + ty;
-    const int j0 = 1 + tb.z * FJB;
-    const int j1 = min(j0 + FJB - 1, d.ny - 2);
+    const int j0 = 1 + tb.z * fjb;
+    const int j1 = min(j0 + fjb - 1, d.ny - 2);
     const int sk = d.sk, sj = d.sj;
     const bool in_i = (i <= d.nx - 1), in_k = (k <= d.nz - 1);
     const bool wave_out = in_k && (ty <= FBY - 2 || k == d.nz - 1);          // wave-uniform
@@ -610,7 +779,8 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     }
     // Occupancy of the pass-1 fields: hydrometeor fields are zero over large parts of the domain, and a row segment
     // (fluxes) / block (final pass) whose whole stencil is zero produces exact zeros -- skipped, wave/block-uniformly.
-    const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + FJB - 1) / FJB), bf(64, FBY);
+    static const int fjb = getenv("ICAR_HIP_MPDATA_FJB") ? max(1, atoi(getenv("ICAR_HIP_MPDATA_FJB"))) : FJB;   // rows marched per block
+    const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + fjb - 1) / fjb), bf(64, FBY);
     const int nt = (int)g.x;
     const size_t occ_n = (size_t)ICAR_MAX_ADV * nt * c->d.nz * c->d.ny, nf_n = (size_t)ICAR_MAX_ADV * gf.x * gf.y * gf.z;
     static const bool no_skip = getenv("ICAR_HIP_MPDATA_NO_SKIP") != nullptr;      // A/B switch for profiling
@@ -625,20 +795,26 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     if (occ) {
         const size_t n2 = (size_t)n * gf.x * gf.y * gf.z;
         hipLaunchKernelGGL(k_occ_blocks, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, c->stream, occ, c->needf, nt, c->d.nx, c->d.nz, c->d.ny, n,
-                           (int)gf.x, (int)gf.y, (int)gf.z, FBY, FJB);
+                           (int)gf.x, (int)gf.y, (int)gf.z, FBY, fjb);
     }
     for (int iord = 2; iord <= order; ++iord) {
         // the flags describe the pass-1 field of the first corrective iteration only
         const unsigned char *need1 = (occ && iord == 2) ? occ : nullptr, *needf = (occ && iord == 2) ? c->needf : nullptr;
         // pseudo-velocities from q2 with the ORIGINAL U_m,V_m,W_m/dz (adv_mpdata.f90:379)
-        if (advect_density) hipLaunchKernelGGL((k_mpdata_fluxes<true>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
-        else                hipLaunchKernelGGL((k_mpdata_fluxes<false>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
+        static const bool pipe = getenv("ICAR_HIP_MPDATA_FLUXES") ? strcmp(getenv("ICAR_HIP_MPDATA_FLUXES"), "plain") != 0 : true;   // A/B switch
+        if (pipe) {
+            if (advect_density) hipLaunchKernelGGL((k_mpdata_fluxes_pipe<true>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
+            else                hipLaunchKernelGGL((k_mpdata_fluxes_pipe<false>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
+        } else {
+            if (advect_density) hipLaunchKernelGGL((k_mpdata_fluxes<true>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
+            else                hipLaunchKernelGGL((k_mpdata_fluxes<false>), g, b, 0, c->stream, c->d, q2c, u2, v2, w2, n, c->U, c->V, c->Wdz, rho, jaco, dz, need1);
+        }
         // limiter (l = q, q1 = q2) fused into the donor-cell pass q2 -> alt ; then q := alt
         {
             const int nring = 2 * c->d.nx * c->d.nz + 2 * c->d.nz * (c->d.ny - 2);
             hipLaunchKernelGGL(k_copy_ring, dim3((nring + 255) / 256), dim3(256), 0, c->stream, c->d, q2c, alt, n);
         }
-#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final2<R, F>), gf, bf, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz, needf)
+#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final2<R, F>), gf, bf, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz, needf, fjb)
         if (advect_density) { if (fct) FINAL(true, true); else FINAL(true, false); }
         else                { if (fct) FINAL(false, true); else FINAL(false, false); }
 #undef FINAL
