@@ -550,11 +550,11 @@ template <bool RHO, bool FCT>
 __global__ void __launch_bounds__(64 * FBY)
 k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
                 const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
-                const unsigned char *__restrict__ needf, int fjb)
+                const unsigned char *__restrict__ needf, int fjb, int xrows)
 {
     __shared__ float s_wb[2][FBY][64];       // double-buffered by row parity: one barrier per row instead of two
     const int lane = threadIdx.x, ty = threadIdx.y;
-    const TileId tb = xcd_tile(2);
+    const TileId tb = xcd_tile(xrows);
     const int i = 1 + tb.x * 63 + lane;
     const int k = tb.y * (FBY - 1) + ty;
     const int j0 = 1 + tb.z * fjb;
@@ -780,6 +780,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     // Occupancy of the pass-1 fields: hydrometeor fields are zero over large parts of the domain, and a row segment
     // (fluxes) / block (final pass) whose whole stencil is zero produces exact zeros -- skipped, wave/block-uniformly.
     static const int fjb = getenv("ICAR_HIP_MPDATA_FJB") ? max(1, atoi(getenv("ICAR_HIP_MPDATA_FJB"))) : FJB;   // rows marched per block
+    static const int xrows = getenv("ICAR_HIP_MPDATA_XROWS") ? max(1, atoi(getenv("ICAR_HIP_MPDATA_XROWS"))) : 2;   // j slabs per XCD turn
     const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + fjb - 1) / fjb), bf(64, FBY);
     const int nt = (int)g.x;
     const size_t occ_n = (size_t)ICAR_MAX_ADV * nt * c->d.nz * c->d.ny, nf_n = (size_t)ICAR_MAX_ADV * gf.x * gf.y * gf.z;
@@ -814,7 +815,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
             const int nring = 2 * c->d.nx * c->d.nz + 2 * c->d.nz * (c->d.ny - 2);
             hipLaunchKernelGGL(k_copy_ring, dim3((nring + 255) / 256), dim3(256), 0, c->stream, c->d, q2c, alt, n);
         }
-#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final2<R, F>), gf, bf, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz, needf, fjb)
+#define FINAL(R, F) hipLaunchKernelGGL((k_mpdata_final2<R, F>), gf, bf, 0, c->stream, c->d, q, q2c, u2c, v2c, w2c, alt, n, rho, jaco, dz, needf, fjb, xrows)
         if (advect_density) { if (fct) FINAL(true, true); else FINAL(true, false); }
         else                { if (fct) FINAL(false, true); else FINAL(false, false); }
 #undef FINAL
