@@ -76,10 +76,13 @@ def one_step(d, opt, group=None, device=None, cool=0.0):
     from icar_amd.advection import advect
     dt = update_dt(d, opt, group=group, device=device)
     d.diagnostic_update()
-    mp(d, opt, dt, halo=1)
-    d.halo_send()
-    mp(d, opt, dt, subset=1)
-    d.halo_retrieve()
+    if d.comm is None or not d.comm.peers:
+        mp(d, opt, dt)                   # no neighbours: strips + interior in one launch (icar_amd/time_step.py)
+    else:
+        mp(d, opt, dt, halo=1)
+        d.halo_send()
+        mp(d, opt, dt, subset=1)
+        d.halo_retrieve()
     advect(d, opt, dt)
     d.apply_forcing(dt, FORCED)
     d.model_time_seconds += dt

@@ -41,10 +41,16 @@ def step(domain, end_time, options, group=None, device=None, forced=None, diagno
         if diagnostics:
             domain.diagnostic_update()                         # :474
         if dt > 1e-3:                                          # :483
-            mp(domain, options, dt, halo=1)                    # :512
-            domain.halo_send()                                 # :515
-            mp(domain, options, dt, subset=1)                  # :523
-            domain.halo_retrieve()                             # :526
+            if getattr(domain, "comm", None) is None or not domain.comm.peers:
+                # an image without neighbours has nothing to send between the strips and the interior: mp()'s own
+                # whole-tile form (mp_driver.f90:755-768) does the same columns in ONE launch -- a 1-cell-wide strip
+                # launch cannot fill 256 CUs.  Columns are independent, so the result is identical.
+                mp(domain, options, dt)
+            else:
+                mp(domain, options, dt, halo=1)                # :512
+                domain.halo_send()                             # :515
+                mp(domain, options, dt, subset=1)              # :523
+                domain.halo_retrieve()                         # :526
             advect(domain, options, dt)                        # :529
             if forced:
                 domain.apply_forcing(dt, forced)               # :534
