@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 tag=$1; shift
 O=gpurun_out/fs_$tag; rm -rf $O; mkdir -p $O
 P="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-env "$@" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o p -- $P > $O/f.log 2>&1
-env "$@" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o p -- $P > $O/w.log 2>&1
+timeout 240 env "$@" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o p -- $P > $O/f.log 2>&1
+timeout 240 env "$@" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o p -- $P > $O/w.log 2>&1
 echo "== $tag $@"
 python - "$O" <<'PY'
 import csv, sys, collections
