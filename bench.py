@@ -258,7 +258,7 @@ def main():
                                    f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
                        "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",
                        "dt_s": dt, "mp_active_column_fraction": active},
-            "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpdata_fluxes + k_mpdata_final)",
+            "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpdata_fluxes_pipe + k_mpdata_final2)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
                          "mp_ms_per_step": mp_ms_step},
