@@ -261,7 +261,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpdata_fluxes_pipe + k_mpdata_final2)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
-                         "mp_ms_per_step": mp_ms_step},
+                         "mp_ms_per_step": mp_ms_step,
+                         # informational: the instruction-issue floor of the same launch.  700 VALU
+                         # instructions per scalar-cell is the PMC count of profiles/r01_pmc.md for MPDATA order 2 + FCT;
+                         # 1024 SIMDs x 16 lanes x 2.4 GHz lane-instructions per second.
+                         "valu_floor_ms": (mem_cells * nscal * 700 / (1024 * 16 * 2.4e9) * 1e3) if args.adv == "mpdata" else None},
             # informational: the microphysics is VALU-bound, its share of the step and its algorithmic traffic
             "microphysics": {"kernel": "k_thompson_pack" if args.mp == "thompson" else "k_mp_simple", "bound": "valu",
                              "ms_per_step": mp_ms_step,
