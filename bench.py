@@ -89,6 +89,69 @@ def one_step(d, opt, group=None, device=None, cool=0.0):
     return dt
 
 
+def cpu_reference(args, domain, nscalars):
+    """The UNMODIFIED reference kernels (oracle/_ref: adv_mpdata.f90 + mp_thompson.f90 / mp_simple.f90 compiled by
+    oracle/build_ref.sh, no OpenMP -> one core) timed on one step of the same 256x256x40 sample.  Informational, next
+    to cpu_baseline (the OpenMP port that is bit-identical to them).  Thompson's tables are read from the .dat caches
+    the device tables were written to (byte-identical to the reference's own, tests/test_gpu_thompson.py), which skips
+    the reference's 56 s single-core table build.  Runs in a child process: the Fortran runtime writes to stdout."""
+    try:
+        from oracle import ref
+        if not ref.available():
+            return None
+        import subprocess, tempfile
+        tmp = tempfile.mkdtemp(prefix="icar_ref_tables_")
+        if args.mp == "thompson":
+            from icar_amd.thompson_cache import write_caches
+            write_caches(domain, tmp)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--ref-child", tmp, "--adv", args.adv, "--mp", args.mp,
+                            "--nz", str(args.nz), "--hill", str(args.hill), "--ref-nscal", str(nscalars)],
+                           capture_output=True, text=True, timeout=600, preexec_fn=_unlimited_stack)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "grid-cell updates/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
+
+
+def _unlimited_stack():
+    # adv_mpdata.f90:365-368 keeps four full-grid temporaries on the stack (42 MB at 256x256x40): the reference needs
+    # `ulimit -s unlimited` like any ICAR run
+    import resource
+    hard = resource.getrlimit(resource.RLIMIT_STACK)[1]
+    resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+
+
+def ref_child(args):
+    from oracle import ref
+    from icar_amd import ideal
+    nscalars = args.ref_nscal
+    nx, ny, nz = 256, 256, args.nz
+    c = ideal.make_case(nx, ny, nz, hill_height=args.hill, noise=0.01, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.4)).astype(np.float32)
+    dt = min(ideal.cfl_dt(c), 120.0)
+    names = ["water_vapor", "cloud_water", "rain", "snow", "potential_temperature", "cloud_ice", "graupel",
+             "ice_number", "rain_number"][:nscalars]
+    q = np.stack([c[n] for n in names]).copy()
+    z2 = lambda: np.zeros((ny, nx), np.float32)
+    if args.mp == "thompson":
+        ref.thompson_init(workdir=args.ref_child)
+    acc = [z2() for _ in range(5)]
+    t0 = time.perf_counter()
+    if args.mp == "thompson":
+        ref.thompson(c["water_vapor"], c["cloud_water"], c["rain"], c["cloud_ice"], c["snow"], c["graupel"], c["ice_number"],
+                     c["rain_number"], c["potential_temperature"], c["exner"], c["pressure"], c["dz_mass"], dt, *acc,
+                     1, nx, 1, ny, 1, nz, 2, nx - 1, 2, ny - 1, 1, nz)
+    elif args.mp == "simple":
+        ref.mp_simple(c["pressure"], c["potential_temperature"], c["exner"], c["density"], c["water_vapor"], c["cloud_water"],
+                      c["rain"], c["snow"], acc[0], acc[1], dt, c["dz_mass"], 2, nx - 1, 2, ny - 1, 1, nz)
+    ref.advect(1 if args.adv == "upwind" else 2, q, c["u"], c["v"], c["w"], c["density"], c["jacobian"], c["jacobian_u"],
+               c["jacobian_v"], c["jacobian_w"], c["advection_dz"], c["dz_levels"], float(c["dx"]), dt)
+    el = time.perf_counter() - t0
+    print("\n" + json.dumps({"value": (nx - 2) * (ny - 2) * nz / el, "unit": "grid-cell updates/s", "cores": 1, "kind": "reference",
+                             "sample": f"1 step of 256x256x{nz}, the reference's own {args.adv} + {args.mp} kernels compiled unmodified "
+                                       f"(flang -O2, no OpenMP), {el:.1f} s"}), flush=True)
+
+
 def usable_cpus():
     """CPUs this process may actually run on: the affinity mask, capped by the cgroup CPU quota (v2 cpu.max or v1
     cfs_quota).  omp_get_max_threads() reports the host's logical CPUs even inside a quota'd container."""
@@ -173,7 +236,11 @@ def main():
     ap.add_argument("--adv", default="mpdata", choices=["mpdata", "upwind"])
     ap.add_argument("--mp", default=os.environ.get("ICAR_BENCH_MP", "thompson"), choices=["thompson", "simple", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ref-child", default=None, help=argparse.SUPPRESS)      # internal: cpu_reference()'s child process
+    ap.add_argument("--ref-nscal", type=int, default=9, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.ref_child is not None:
+        return ref_child(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -273,6 +340,9 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nscal)
+            r = cpu_reference(args, d, nscal)
+            if r is not None:
+                out["cpu_reference"] = r
         print(json.dumps(out), flush=True)
     d.close()
     if world > 1:
