@@ -23,8 +23,8 @@ static bool field_is_2dd(int f) { return f == ICAR_F_PRECIPITATION || f == ICAR_
 size_t icar_field_count(const icar_hip_ctx *c, int f)
 {
     const size_t nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
-    if (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U || f == ICAR_F_DZDX) return (nx + 1) * nz * ny;
-    if (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V || f == ICAR_F_DZDY) return nx * nz * (ny + 1);
+    if (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U || f == ICAR_F_DZDX || f == ICAR_F_ZR_U) return (nx + 1) * nz * ny;
+    if (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V || f == ICAR_F_DZDY || f == ICAR_F_ZR_V) return nx * nz * (ny + 1);
     if (field_is_2dd(f) || f == ICAR_F_SURFACE_PRESSURE || (f >= ICAR_F_IVT && f <= ICAR_F_IWI)) return nx * ny;
     return nx * nz * ny;
 }
@@ -482,6 +482,12 @@ int icar_hip_balance_uvw_update(icar_hip_ctx *c, float dx)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
     return icar_balance_uvw_run(c, dx, 1);
+}
+
+int icar_hip_mass_conservative_acceleration(icar_hip_ctx *c, int update)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_mass_conservative_acceleration(c, update);
 }
 
 int icar_hip_iterative_winds_correct_w(icar_hip_ctx *c, int update)

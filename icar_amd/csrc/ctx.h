@@ -76,6 +76,7 @@ int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n,
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out);
 int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update);
 int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update);
+int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update);
 int icar_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int update);
 int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, float *buf, bool unpack);
 int icar_diagnostic_update_run(icar_hip_ctx *c);

@@ -84,6 +84,11 @@ __global__ void k_box(int X, int nz, int i0, int ni, int j0, int nj, float *__re
     if (UNPACK) f[a] = buf[b]; else buf[b] = f[a];
 }
 
+__global__ void k_divide(size_t n, float *__restrict__ x, const float *__restrict__ a)
+{
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) x[t] = x[t] / a[t];
+}
+
 struct Winds { float *u, *v, *w; };
 
 int pick_winds(icar_hip_ctx *c, int update, Winds *o)
@@ -99,6 +104,20 @@ int pick_winds(icar_hip_ctx *c, int update, Winds *o)
 }
 
 }  // namespace
+
+// mass_conservative_acceleration (wind.f90:500-511): u = u / u_accel, v = v / v_accel
+int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update)
+{
+    float *u = update ? c->dqdt[ICAR_F_U] : icar_field_f(c, ICAR_F_U), *v = update ? c->dqdt[ICAR_F_V] : icar_field_f(c, ICAR_F_V);
+    if (!u || !v) { if (update) icar_set_error("mass_conservative_acceleration(update): upload the u and v dqdt_3d first"); return 1; }
+    const float *au = icar_field_f(c, ICAR_F_ZR_U), *av = icar_field_f(c, ICAR_F_ZR_V);
+    if (!au || !av) return 1;
+    hipLaunchKernelGGL(k_divide, dim3(2048), dim3(256), 0, c->stream, icar_field_count(c, ICAR_F_U), u, au);
+    hipLaunchKernelGGL(k_divide, dim3(2048), dim3(256), 0, c->stream, icar_field_count(c, ICAR_F_V), v, av);
+    HIPCHK(hipGetLastError());
+    c->winds_valid = false;
+    return 0;
+}
 
 int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update)
 {
@@ -137,8 +156,8 @@ int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0,
     if (field < 0 || field >= ICAR_N_FIELDS || icar_hip_field_elem_size(field) != 4) { icar_set_error("box: REAL(4) fields only"); return 1; }
     const int nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
     if (icar_field_count(c, field) < (size_t)nx * nz * ny) { icar_set_error("box: 3-D fields only"); return 1; }
-    const int X = (field == ICAR_F_U || field == ICAR_F_JACOBIAN_U || field == ICAR_F_DZDX) ? nx + 1 : nx;
-    const int Y = (field == ICAR_F_V || field == ICAR_F_JACOBIAN_V || field == ICAR_F_DZDY) ? ny + 1 : ny;
+    const int X = (field == ICAR_F_U || field == ICAR_F_JACOBIAN_U || field == ICAR_F_DZDX || field == ICAR_F_ZR_U) ? nx + 1 : nx;
+    const int Y = (field == ICAR_F_V || field == ICAR_F_JACOBIAN_V || field == ICAR_F_DZDY || field == ICAR_F_ZR_V) ? ny + 1 : ny;
     if (i0 < 0 || ni < 1 || i0 + ni > X || j0 < 0 || nj < 1 || j0 + nj > Y) { icar_set_error("box: range outside the field"); return 1; }
     float *f = which ? c->dqdt[field] : icar_field_f(c, field);
     if (!f) { if (which) icar_set_error("box: dqdt_3d of this field is not on the device"); return 1; }

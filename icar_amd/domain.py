@@ -49,8 +49,8 @@ class domain_t:
             pass
 
     def shape(self, fid):
-        if fid in (F.U, F.JACOBIAN_U, F.DZDX): return (self.ny, self.nz, self.nx + 1)
-        if fid in (F.V, F.JACOBIAN_V, F.DZDY): return (self.ny + 1, self.nz, self.nx)
+        if fid in (F.U, F.JACOBIAN_U, F.DZDX, F.ZR_U): return (self.ny, self.nz, self.nx + 1)
+        if fid in (F.V, F.JACOBIAN_V, F.DZDY, F.ZR_V): return (self.ny + 1, self.nz, self.nx)
         if fid in F.IS_2DD or fid in (F.SURFACE_PRESSURE, F.IVT, F.IWV, F.IWL, F.IWI): return (self.ny, self.nx)
         return (self.ny, self.nz, self.nx)
 

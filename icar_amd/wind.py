@@ -6,6 +6,7 @@ from .linear_winds import linear_perturb
 from . import _fields as F
 
 kWIND_LINEAR = 1                 # icar_constants.f90:368-377 (windtype)
+kCONSERVE_MASS = 2
 kITERATIVE_WINDS = 3
 kLINEAR_ITERATIVE_WINDS = 5
 
@@ -39,16 +40,19 @@ def iterative_winds(domain, options, update=False):
 
 
 def update_winds(domain, options):
-    """wind.f90:289-360 for windtype 0, kWIND_LINEAR, kITERATIVE_WINDS and kLINEAR_ITERATIVE_WINDS.  First call: linear_perturb on u, v then balance_uvw on the
+    """wind.f90:289-360 for every windtype: 0, kWIND_LINEAR, kCONSERVE_MASS, kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS.  First call: linear_perturb on u, v then balance_uvw on the
     winds; every later call (a new forcing step has put the next winds into dqdt_3d) the same on the tendencies.
     make_winds_grid_relative (rotation by sintheta / costheta) belongs to the forcing reader and is not on this path;
     setup_linwinds(domain, options, global_terrain) must have been called when windtype == kWIND_LINEAR."""
     wt = options.physics.windtype
-    if wt not in (0, kWIND_LINEAR, kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS):
-        raise IcarHipError("update_winds: windtype kCONSERVE_MASS is not on the device path")
+    if wt not in (0, kWIND_LINEAR, kCONSERVE_MASS, kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS):
+        raise IcarHipError(f"update_winds: unknown windtype {wt}")
     first = not getattr(domain, "_winds_initialised", False)
     if wt in (kWIND_LINEAR, kLINEAR_ITERATIVE_WINDS):
         linear_perturb(domain, options, options.lt_options.vert_smooth, False, options.parameters.advect_density, update=not first)
+    if wt == kCONSERVE_MASS:
+        # wind.f90:301-306 / :333-338: the host has uploaded zr_u / zr_v (zfr_* with use_terrain_difference) as "zr_u" / "zr_v"
+        check(lib().icar_hip_mass_conservative_acceleration(domain.ctx, int(not first)), "mass_conservative_acceleration")
     if wt in (kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS):
         iterative_winds(domain, options, update=not first)
     balance_uvw(domain, update=not first)

@@ -76,7 +76,11 @@ enum icar_hip_field {
     ICAR_F_IWV = 38,               /* domain%iwv%data_2d  integrated water vapour                */
     ICAR_F_IWL = 39,               /* domain%iwl%data_2d  integrated liquid (cloud + rain)       */
     ICAR_F_IWI = 40,               /* domain%iwi%data_2d  integrated ice (ice + snow + graupel)  */
-    ICAR_N_FIELDS = 41
+    /* update_winds, windtype kCONSERVE_MASS (src/physics/wind.f90:301-306): the host uploads domain%zr_u / zr_v, or
+     * zfr_u / zfr_v when options%parameters%use_terrain_difference */
+    ICAR_F_ZR_U = 41,              /* (nx+1, nz, ny)                        */
+    ICAR_F_ZR_V = 42,              /* (nx, nz, ny+1)                        */
+    ICAR_N_FIELDS = 43
 };
 
 enum { ICAR_ADV_UPWIND = 1, ICAR_ADV_MPDATA = 2 };   /* kADV_UPWIND / kADV_MPDATA, icar_constants.f90:341 */
@@ -189,6 +193,10 @@ int icar_hip_balance_uvw_update(icar_hip_ctx *ctx, float dx);
  *   sweep      :455-481  div = calc_divergence(u,v,w) (:172-228); ADJ = div/(-2/dx); u, v faces +-ADJ*0.5 */
 int icar_hip_iterative_winds_correct_w(icar_hip_ctx *ctx, int update);
 int icar_hip_iterative_winds_sweep(icar_hip_ctx *ctx, float dx, int nsweeps, int update);
+
+/* mass_conservative_acceleration (src/physics/wind.f90:500-511): u = u / ICAR_F_ZR_U, v = v / ICAR_F_ZR_V on the winds
+ * (update == 0) or on their meta_data%dqdt_3d (update != 0), as update_winds does for windtype kCONSERVE_MASS */
+int icar_hip_mass_conservative_acceleration(icar_hip_ctx *ctx, int update);
 
 /* ---- W3: linear-theory wind look-up table (src/physics/linear_winds.f90) ----------------------
  * options%lt_options (src/objects/options_obj.f90:1400-1530; defaults there: buffer 50, stability_window_size 10,

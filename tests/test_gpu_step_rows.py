@@ -176,6 +176,28 @@ def test_iterative_winds_single_image(oracle, iters):
     d.close()
 
 
+def test_update_winds_conserve_mass(oracle):
+    """windtype kCONSERVE_MASS (wind.f90:301-306, :333-338): u / zr_u, v / zr_v (mass_conservative_acceleration :500-511,
+    one IEEE division per face) followed by balance_uvw -- first call on the winds, later calls on dqdt_3d."""
+    from icar_amd.wind import update_winds, kCONSERVE_MASS
+    c = case(44, 27, 9, seed=13)
+    rng = np.random.default_rng(7)
+    zr_u = rng.uniform(0.6, 1.4, c["u"].shape).astype(np.float32); zr_v = rng.uniform(0.6, 1.4, c["v"].shape).astype(np.float32)
+    d = single_image_domain(c)
+    d.set("zr_u", zr_u); d.set("zr_v", zr_v)
+    opt = options_t(); opt.physics.windtype = kCONSERVE_MASS
+    update_winds(d, opt)
+    u, v = c["u"] / zr_u, c["v"] / zr_v
+    geo = (c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], float(c["dx"]))
+    assert bits_equal(d.get("u"), u) and bits_equal(d.get("v"), v) and bits_equal(d.get("w"), oracle.balance_uvw(u, v, *geo))
+    du = (0.01 * rng.standard_normal(c["u"].shape)).astype(np.float32); dv = (0.01 * rng.standard_normal(c["v"].shape)).astype(np.float32)
+    d.set_dqdt("u", du); d.set_dqdt("v", dv)
+    update_winds(d, opt)
+    assert bits_equal(d.get_dqdt("u"), du / zr_u) and bits_equal(d.get_dqdt("v"), dv / zr_v)
+    assert bits_equal(d.get_dqdt("w"), oracle.balance_uvw(du / zr_u, dv / zr_v, *geo)) and bits_equal(d.get("u"), u)
+    d.close()
+
+
 def test_output_file_from_device_fields(tmp_path):
     """output_t.save_file on a real domain_t: the file holds what domain%...%data_3d holds after the step (NetCDF classic,
     the reference's names / dimension order; icar_amd/output.py)."""
