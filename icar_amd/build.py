@@ -52,6 +52,7 @@ def build(force=False, verbose=False):
 FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
 FDIR = os.path.join(HERE, "fortran")
 DEMO = os.path.join(LIBDIR, "icar_hip_demo")
+STEP_DEMO = os.path.join(LIBDIR, "icar_hip_step_demo")
 
 
 def build_fortran_host(force=False, verbose=False):
@@ -59,11 +60,13 @@ def build_fortran_host(force=False, verbose=False):
     if not os.path.exists(FLANG):
         return None
     mod = os.path.join(FDIR, "icar_hip_mod.f90"); demo = os.path.join(FDIR, "icar_hip_demo.f90")
-    if not (force or _stale(DEMO, [mod, demo, LIB])):
+    sdemo = os.path.join(FDIR, "icar_hip_step_demo.f90")
+    if not (force or _stale(DEMO, [mod, demo, LIB]) or _stale(STEP_DEMO, [mod, sdemo, LIB])):
         return DEMO
     obj = os.path.join(LIBDIR, "icar_hip_mod.o")
     cmds = [[FLANG, "-O2", "-c", mod, "-o", obj, "-module-dir", LIBDIR],
-            [FLANG, "-O2", "-I" + LIBDIR, demo, obj, "-L" + LIBDIR, "-licar_hip", "-Wl,-rpath,$ORIGIN", "-o", DEMO]]
+            [FLANG, "-O2", "-I" + LIBDIR, demo, obj, "-L" + LIBDIR, "-licar_hip", "-Wl,-rpath,$ORIGIN", "-o", DEMO],
+            [FLANG, "-O2", "-I" + LIBDIR, sdemo, obj, "-L" + LIBDIR, "-licar_hip", "-Wl,-rpath,$ORIGIN", "-o", STEP_DEMO]]
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd))

@@ -13,19 +13,26 @@ module icar_hip
   private
   public :: hip_ctx_t, hip_create, hip_destroy, hip_upload, hip_download, hip_upload_2dd, hip_download_2dd, &
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
-            hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds
+            hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
+            hip_diagnostic_update, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
+            hip_halo_unpack, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
             ICAR_F_JACOBIAN_V, ICAR_F_JACOBIAN_W, ICAR_F_ADVECTION_DZ, ICAR_F_PRECIPITATION, ICAR_F_SNOWFALL, ICAR_F_GRAUPEL_ACC, &
-            ICAR_F_Z, ICAR_F_NSQUARED
+            ICAR_F_Z, ICAR_F_NSQUARED, ICAR_F_PRESSURE_INTERFACE, ICAR_F_TEMPERATURE, ICAR_F_TEMPERATURE_INTERFACE, &
+            ICAR_F_U_MASS, ICAR_F_V_MASS, ICAR_F_W_REAL, ICAR_F_DZDX, ICAR_F_DZDY, ICAR_F_SURFACE_PRESSURE, &
+            ICAR_F_IVT, ICAR_F_IWV, ICAR_F_IWL, ICAR_F_IWI, ICAR_F_ZR_U, ICAR_F_ZR_V
 
   ! enum icar_hip_field (include/icar_hip.h)
   integer(c_int), parameter :: ICAR_F_WATER_VAPOR=0, ICAR_F_CLOUD_WATER=1, ICAR_F_RAIN=2, ICAR_F_SNOW=3, &
        ICAR_F_POTENTIAL_TEMPERATURE=4, ICAR_F_CLOUD_ICE=5, ICAR_F_GRAUPEL=6, ICAR_F_ICE_NUMBER=7, ICAR_F_RAIN_NUMBER=8, &
        ICAR_F_U=11, ICAR_F_V=12, ICAR_F_W=13, ICAR_F_PRESSURE=14, ICAR_F_EXNER=15, ICAR_F_DENSITY=16, ICAR_F_DZ_MASS=17, &
        ICAR_F_JACOBIAN=18, ICAR_F_JACOBIAN_U=19, ICAR_F_JACOBIAN_V=20, ICAR_F_JACOBIAN_W=21, ICAR_F_ADVECTION_DZ=22, &
-       ICAR_F_PRECIPITATION=23, ICAR_F_SNOWFALL=24, ICAR_F_GRAUPEL_ACC=25, ICAR_F_Z=35, ICAR_F_NSQUARED=36
+       ICAR_F_PRECIPITATION=23, ICAR_F_SNOWFALL=24, ICAR_F_GRAUPEL_ACC=25, ICAR_F_PRESSURE_INTERFACE=26, ICAR_F_TEMPERATURE=27, &
+       ICAR_F_TEMPERATURE_INTERFACE=28, ICAR_F_U_MASS=29, ICAR_F_V_MASS=30, ICAR_F_W_REAL=31, ICAR_F_DZDX=32, ICAR_F_DZDY=33, &
+       ICAR_F_SURFACE_PRESSURE=34, ICAR_F_Z=35, ICAR_F_NSQUARED=36, ICAR_F_IVT=37, ICAR_F_IWV=38, ICAR_F_IWL=39, ICAR_F_IWI=40, &
+       ICAR_F_ZR_U=41, ICAR_F_ZR_V=42
 
   !> struct icar_hip_lt_options == the members of options%lt_options the linear-wind path reads
   type, bind(C) :: hip_lt_options_t
@@ -79,6 +86,36 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_balance_uvw(ctx, dx) bind(C, name="icar_hip_balance_uvw")
        import; type(c_ptr), value :: ctx; real(c_float), value :: dx
+     end function
+     integer(c_int) function icar_hip_diagnostic_update(ctx) bind(C, name="icar_hip_diagnostic_update")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_dqdt_upload(ctx, field, host) bind(C, name="icar_hip_dqdt_upload")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: field; type(c_ptr), value :: host
+     end function
+     integer(c_int) function icar_hip_apply_forcing(ctx, dt, fields, fb, n, w, e, s, nn) bind(C, name="icar_hip_apply_forcing")
+       import; type(c_ptr), value :: ctx; real(c_double), value :: dt; integer(c_int), intent(in) :: fields(*), fb(*)
+       integer(c_int), value :: n, w, e, s, nn
+     end function
+     integer(c_int) function icar_hip_enforce_limits(ctx, fields, n) bind(C, name="icar_hip_enforce_limits")
+       import; type(c_ptr), value :: ctx; integer(c_int), intent(in) :: fields(*); integer(c_int), value :: n
+     end function
+     integer(c_size_t) function icar_hip_halo_count(ctx, dir, halo) bind(C, name="icar_hip_halo_count")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: dir, halo
+     end function
+     integer(c_int) function icar_hip_halo_pack(ctx, dir, halo, fields, n, dbuf) bind(C, name="icar_hip_halo_pack")
+       import; type(c_ptr), value :: ctx, dbuf; integer(c_int), value :: dir, halo, n; integer(c_int), intent(in) :: fields(*)
+     end function
+     integer(c_int) function icar_hip_halo_unpack(ctx, dir, halo, fields, n, dbuf) bind(C, name="icar_hip_halo_unpack")
+       import; type(c_ptr), value :: ctx, dbuf; integer(c_int), value :: dir, halo, n; integer(c_int), intent(in) :: fields(*)
+     end function
+     integer(c_int) function icar_hip_thompson_tiles(ctx, dt, ntiles, tiles, kts, kte, ids, ide, jds, jde, kds, kde) &
+          bind(C, name="icar_hip_thompson_tiles")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dt; integer(c_int), value :: ntiles, kts, kte, ids, ide, jds, jde, kds, kde
+       integer(c_int), intent(in) :: tiles(4,*)
+     end function
+     integer(c_int) function icar_hip_mass_conservative_acceleration(ctx, update) bind(C, name="icar_hip_mass_conservative_acceleration")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: update
      end function
      integer(c_int) function icar_hip_iterative_winds_correct_w(ctx, update) bind(C, name="icar_hip_iterative_winds_correct_w")
        import; type(c_ptr), value :: ctx; integer(c_int), value :: update
@@ -225,6 +262,87 @@ contains
     type(hip_ctx_t), intent(in) :: ctx
     real, intent(in) :: dx
     call check(icar_hip_balance_uvw(ctx%p, real(dx,c_float)), "balance_uvw")
+  end subroutine
+
+  !> diagnostic_update (time_step.f90:49-198)
+  subroutine hip_diagnostic_update(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_diagnostic_update(ctx%p), "diagnostic_update")
+  end subroutine
+
+  !> variable%meta_data%dqdt_3d -> device (the forcing tendency apply_forcing adds)
+  subroutine hip_dqdt_upload(ctx, field, a)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: field
+    real(c_float), intent(in), target, contiguous :: a(:,:,:)
+    call check(icar_hip_dqdt_upload(ctx%p, field, c_loc(a)), "dqdt_upload")
+  end subroutine
+
+  !> domain%apply_forcing(dt) (domain_obj.f90:2383-2448): force_boundaries(i) -> only the true domain edges
+  subroutine hip_apply_forcing(ctx, dt_seconds, fields, force_boundaries, west, east, south, north)
+    type(hip_ctx_t), intent(in) :: ctx
+    double precision, intent(in) :: dt_seconds
+    integer(c_int), intent(in) :: fields(:)
+    logical, intent(in) :: force_boundaries(:), west, east, south, north
+    integer(c_int) :: fb(size(fields))
+    fb = merge(1_c_int, 0_c_int, force_boundaries)
+    call check(icar_hip_apply_forcing(ctx%p, real(dt_seconds,c_double), fields, fb, int(size(fields),c_int), &
+               merge(1_c_int,0_c_int,west), merge(1_c_int,0_c_int,east), merge(1_c_int,0_c_int,south), merge(1_c_int,0_c_int,north)), &
+               "apply_forcing")
+  end subroutine
+
+  !> domain%enforce_limits() (domain_obj.f90:2228-2243)
+  subroutine hip_enforce_limits(ctx, fields)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: fields(:)
+    call check(icar_hip_enforce_limits(ctx%p, fields, int(size(fields),c_int)), "enforce_limits")
+  end subroutine
+
+  !> halo faces of all exchanged scalars in one device buffer per neighbour (exchangeable_obj.f90:248-356).
+  !! dir: 0 north, 1 south, 2 east, 3 west.  dbuf is a DEVICE pointer (hipMalloc / GPU-aware MPI window).
+  integer(c_size_t) function hip_halo_count(ctx, dir, halo)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: dir, halo
+    hip_halo_count = icar_hip_halo_count(ctx%p, int(dir,c_int), int(halo,c_int))
+  end function
+
+  subroutine hip_halo_pack(ctx, dir, halo, fields, dbuf)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: dir, halo
+    integer(c_int), intent(in) :: fields(:)
+    type(c_ptr), intent(in) :: dbuf
+    call check(icar_hip_halo_pack(ctx%p, int(dir,c_int), int(halo,c_int), fields, int(size(fields),c_int), dbuf), "halo_pack")
+  end subroutine
+
+  subroutine hip_halo_unpack(ctx, dir, halo, fields, dbuf)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: dir, halo
+    integer(c_int), intent(in) :: fields(:)
+    type(c_ptr), intent(in) :: dbuf
+    call check(icar_hip_halo_unpack(ctx%p, int(dir,c_int), int(halo,c_int), fields, int(size(fields),c_int), dbuf), "halo_unpack")
+  end subroutine
+
+  !> process_halo's strips (mp_driver.f90:609-658) in one launch: tiles(1:4, t) = its, ite, jts, jte of strip t
+  subroutine hip_thompson_tiles(ctx, dt, tiles, kts, kte, ids, ide, jds, jde, kds, kde)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dt
+    integer(c_int), intent(in) :: tiles(:,:)
+    integer, intent(in) :: kts, kte, ids, ide, jds, jde, kds, kde
+    call check(icar_hip_thompson_tiles(ctx%p, real(dt,c_float), int(size(tiles,2),c_int), tiles, int(kts,c_int), int(kte,c_int), &
+               int(ids,c_int), int(ide,c_int), int(jds,c_int), int(jde,c_int), int(kds,c_int), int(kde,c_int)), "thompson_tiles")
+  end subroutine
+
+  !> mass_conservative_acceleration (wind.f90:500-511) with ICAR_F_ZR_U / ICAR_F_ZR_V uploaded
+  subroutine hip_mass_conservative_acceleration(ctx, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    logical, intent(in) :: update
+    call check(icar_hip_mass_conservative_acceleration(ctx%p, merge(1_c_int,0_c_int,update)), "mass_conservative_acceleration")
+  end subroutine
+
+  subroutine hip_balance_uvw_update(ctx, dx)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dx
+    call check(icar_hip_balance_uvw_update(ctx%p, real(dx,c_float)), "balance_uvw_update")
   end subroutine
 
   !> iterative_winds (wind.f90:371-498) on ONE image (exchange_u / exchange_v are no-ops there): balance_uvw, the model-top
