@@ -62,7 +62,7 @@ def balance_uvw(u, v, jaco_u, jaco_v, jaco_w, dz, dx):
 
 
 def make_case(nx, ny, nz, dx=1000.0, hill_height=0.0, u0=10.0, v0=3.0, uniform_dz=None,
-              blob_amp=0.004, noise=0.0, seed=1234, n_hydro=0, cool=0.0, exact=False):
+              blob_amp=0.004, noise=0.0, seed=1234, n_hydro=0, cool=0.0, exact=False, terrain=None):
     """Build the synthetic state described in SURVEY.md section 8(d).
 
     exact=True builds the same kind of state from IEEE-exact operations only (+,-,*,/,sqrt; rational
@@ -75,7 +75,10 @@ def make_case(nx, ny, nz, dx=1000.0, hill_height=0.0, u0=10.0, v0=3.0, uniform_d
     """
     f32 = np.float32
     dzl = dz_levels(nz, uniform_dz)
-    if hill_height > 0 and exact:
+    if terrain is not None:
+        terrain = np.ascontiguousarray(terrain, f32)
+        assert terrain.shape == (ny, nx)
+    elif hill_height > 0 and exact:
         xg = (np.arange(nx, dtype=np.float64) / max(nx - 1, 1) * 2 - 1); yg = (np.arange(ny, dtype=np.float64) / max(ny - 1, 1) * 2 - 1)
         bx = (1 - xg * xg) * (1 - xg * xg); by = (1 - yg * yg) * (1 - yg * yg)
         terrain = (by[:, None] * bx[None, :] * hill_height).astype(f32)
