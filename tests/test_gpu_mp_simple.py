@@ -174,3 +174,48 @@ def test_mp_simple_full_size_column_subset_vs_oracle(oracle):
         assert np.array_equal(got, ref), f"{k}: {(got != ref).sum()} of {got.size} subset cells differ"
     assert d.get("rain_mass").max() > 1e-5
     d.close()
+
+
+def test_cooled_column_scenario(oracle):
+    """The scenario of the reference's src/tests/test_mp_simple.f90 (print-only there): a 5-level column at 800 hPa,
+    280 K, qv = 5 g/kg, dz = 200 m, dt = 20 s, cooled by 0.1 K per call for 100 calls -- condensation sets in when the
+    column saturates, precipitation keeps coming out, and snow appears once it is below freezing.  Every column of a
+    small tile holds that column; device vs oracle (device math) bit-for-bit after every call."""
+    nx, ny, nz, dt = 70, 4, 5, 20.0
+    f = lambda v: np.full((ny, nz, nx), v, np.float32)
+    p = f(80000.0)
+    exner = ((p.astype(np.float64) / 1e5) ** (287.058 / 1012.0)).astype(np.float32)
+    th = (np.float32(280.0) / exner).astype(np.float32)
+    c = ideal.make_case(nx, ny, nz, uniform_dz=200.0)
+    c.update(pressure=p, exner=exner, potential_temperature=th, density=f(1.0), water_vapor=f(0.005), cloud_water=f(0.0),
+             rain=f(0.0), snow=f(0.0), dz_mass=f(200.0))
+    s = {k: c[k].copy() for k in ["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water", "rain", "snow", "dz_mass"]}
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_SB04
+    mp_init(opt, d)
+    acc_r = np.zeros((ny, nx), np.float64); acc_s = np.zeros((ny, nx), np.float64)
+    cool = (np.float32(0.1) / exner).astype(np.float32)                    # temperature = temperature - 0.1
+    first_cloud = first_snow = None
+    oracle.set_math_mode(1)
+    try:
+        for it in range(100):
+            rain = np.zeros((ny, nx), np.float32); snow = np.zeros((ny, nx), np.float32)
+            assert oracle.mp_simple(s["pressure"], s["potential_temperature"], s["exner"], s["density"], s["water_vapor"], s["cloud_water"],
+                                    s["rain"], s["snow"], rain, snow, dt, s["dz_mass"], 2, nx - 1, 2, ny - 1, 1, nz) == 0
+            acc_r += rain; acc_s += snow
+            mp(d, opt, dt); d.model_time_seconds += dt
+            for k, m in (("potential_temperature", "potential_temperature"), ("water_vapor", "water_vapor"), ("cloud_water", "cloud_water_mass"),
+                         ("rain", "rain_mass"), ("snow", "snow_mass")):
+                assert np.array_equal(d.get(m), s[k]), f"call {it}: {k}"
+            if first_cloud is None and s["cloud_water"].max() > 0: first_cloud = it
+            if first_snow is None and s["snow"].max() > 0: first_snow = it
+            s["potential_temperature"] -= cool
+            d.set("potential_temperature", s["potential_temperature"])
+    finally:
+        oracle.set_math_mode(0)
+    assert np.array_equal(d.get("accumulated_precipitation"), acc_r) and np.array_equal(d.get("accumulated_snowfall"), acc_s)
+    assert first_cloud is not None and 40 < first_cloud < 90, first_cloud          # saturation of 5 g/kg at 800 hPa: ~274 K
+    assert first_snow is not None and first_snow > first_cloud
+    assert acc_r[1:-1, 1:-1].min() > 0 and acc_s[1:-1, 1:-1].min() > 0             # "keeps getting precipitation out (including snow)"
+    assert acc_r[0].max() == 0                                                     # the boundary ring is not processed
+    d.close()
