@@ -173,3 +173,43 @@ def test_mpdata_sparse_fields_skip_zero_regions(oracle, fct):
     assert 0 < ff[1] < 0.5 and 0 < fb[2] < 0.7, (list(ff), list(fb))
     assert ff[4] == 0.0 and fb[4] == 0.0                     # an all-zero field is skipped entirely
     d.close()
+
+
+@pytest.mark.parametrize("fct", [True, False])
+def test_periodic_ring_step_function_scenario(oracle, fct):
+    """The scenario of the reference's src/tests/test_mpdata.f90::test_3d (print-only there): a 3 x 3 x 100 ring, Courant
+    number 0.25 along y, a step from 1 to 2, wrap-around after every advect3d, MPDATA order 2.  The wrap is done on the
+    device with the halo faces themselves (my north face -> my south halo and vice versa = the periodic self-exchange).
+    Device vs oracle bit-for-bit after 2 trips round the ring, with and without FCT; with FCT the step stays inside [1, 2]
+    and is still a step."""
+    nx, ny, nz, cfl = 3, 100, 3, 0.25
+    f32 = np.float32
+    one = lambda s: np.ones(s, f32)
+    c = dict(nx=nx, ny=ny, nz=nz, dx=f32(1.0), dz_levels=one(nz), u=np.zeros((ny, nz, nx + 1), f32), v=np.full((ny + 1, nz, nx), cfl, f32),
+             w=np.zeros((ny, nz, nx), f32), density=one((ny, nz, nx)), jacobian=one((ny, nz, nx)), jacobian_u=one((ny, nz, nx + 1)),
+             jacobian_v=one((ny + 1, nz, nx)), jacobian_w=one((ny, nz, nx)), advection_dz=one((ny, nz, nx)))
+    q = np.ones((ny, nz, nx), f32)
+    q[ny // 2:] = 2.0                                            # i > ny/2 (1-based) -> 2
+    q[0] = q[ny - 2]; q[ny - 1] = q[1]
+    c["water_vapor"] = q.copy()
+    d = single_image_domain(c)
+    opt = options_t()
+    opt.physics.advection = kADV_MPDATA; opt.adv_options.mpdata_order = 2; opt.adv_options.flux_corrected_transport = fct
+    opt.advect_vars(["water_vapor"])
+    nsteps = 2 * int((ny - 2) / cfl)
+    nb, sb = d.new_buffer(d.halo_count(0, 1)), d.new_buffer(d.halo_count(1, 1))
+    qo = q[None].copy()
+    for _ in range(nsteps):
+        advect(d, opt, 1.0)                                      # dt = dx = 1: V_m = v * dt / dx = the Courant number itself
+        d.halo_pack(0, 1, [0], nb); d.halo_pack(1, 1, [0], sb)  # rows ny-2 and 1 ...
+        d.halo_unpack(1, 1, [0], nb); d.halo_unpack(0, 1, [0], sb)   # ... into rows 0 and ny-1
+        oracle.advect(2, qo, *adv_args(c), 1.0, mpdata_order=2, fct=fct)
+        qo[0, 0] = qo[0, ny - 2]; qo[0, ny - 1] = qo[0, 1]
+    got = d.get("water_vapor")
+    d.close()
+    assert bits_equal(got, qo[0]), f"{nbitdiff(got, qo[0])} cells differ after {nsteps} steps"
+    line = got[1:-1, 0, 1].astype(np.float64)
+    assert abs(line.mean() - q[1:-1, 0, 1].mean()) < 1e-3       # the ring keeps its mass (the wrap rows are copies, not fluxes)
+    if fct:
+        assert line.min() >= 1.0 - 1e-6 and line.max() <= 2.0 + 1e-6
+        assert line.max() > 1.9 and line.min() < 1.1             # ... and still has a step after two trips
