@@ -191,6 +191,33 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
     return 0;
 }
 
+// maxval(abs(u)), maxval(abs(v)), maxval(abs(w)) of the other cfl_strictness settings (time_step.f90:238-259, :293-305)
+__global__ void __launch_bounds__(256)
+k_max_abs3(size_t nu, size_t nv, size_t nw, const float *__restrict__ u, const float *__restrict__ v,
+           const float *__restrict__ w, unsigned *__restrict__ out)
+{
+    const float *x = blockIdx.y == 0 ? u : blockIdx.y == 1 ? v : w;
+    const size_t n = blockIdx.y == 0 ? nu : blockIdx.y == 1 ? nv : nw;
+    float cur = 0.0f;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) cur = fmaxf(cur, fabsf(x[t]));
+    for (int o = 32; o > 0; o >>= 1) cur = fmaxf(cur, __shfl_down(cur, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + blockIdx.y, __float_as_uint(cur));
+}
+
+int icar_max_abs_winds_run(icar_hip_ctx *c, float *out3)
+{
+    const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V), *w = icar_field_f(c, ICAR_F_W);
+    if (!u || !v || !w) return 1;
+    HIPCHK(hipMemsetAsync(c->d_red, 0, 3 * sizeof(float), c->stream));
+    ScopedTimer t(c, "cfl");
+    hipLaunchKernelGGL(k_max_abs3, dim3(512, 3), dim3(256), 0, c->stream, icar_field_count(c, ICAR_F_U), icar_field_count(c, ICAR_F_V),
+                       icar_field_count(c, ICAR_F_W), u, v, w, (unsigned *)c->d_red);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out3, c->d_red, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // W1: balance_uvw (wind.f90:81-169): w from the horizontal divergence, bottom-up per column
 // ------------------------------------------------------------------------------------------------
@@ -470,6 +497,12 @@ int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
 {
     if (!c || (n > 0 && !fields)) { icar_set_error("enforce_limits: null argument"); return 1; }
     return icar_enforce_limits_run(c, fields, n);
+}
+
+int icar_hip_max_abs_winds(icar_hip_ctx *c, float *out3)
+{
+    if (!c || !out3) { icar_set_error("max_abs_winds: null argument"); return 1; }
+    return icar_max_abs_winds_run(c, out3);
 }
 
 int icar_hip_balance_uvw(icar_hip_ctx *c, float dx)

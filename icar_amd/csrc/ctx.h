@@ -74,6 +74,7 @@ int icar_advect_occupancy(icar_hip_ctx *c, int n, float *frac_fluxes, float *fra
 int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err);
 int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out);
+int icar_max_abs_winds_run(icar_hip_ctx *c, float *out3);
 int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update);
 int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update);
 int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update);

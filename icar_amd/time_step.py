@@ -8,14 +8,35 @@ from .halo import co_min
 
 
 def compute_dt(domain, options):
-    """time_step.f90:217-330, cfl_strictness 3 (the default): CFL / max(sum of face-max winds)."""
-    if options.parameters.cfl_strictness != 3:
-        raise NotImplementedError("only cfl_strictness=3 (the reference default) is on the device path")
-    dzl = np.ascontiguousarray(options.parameters.dz_levels, np.float32)
-    out = ctypes.c_float()
-    check(lib().icar_hip_max_courant(domain.ctx, ctypes.c_float(domain.dx), dzl.ctypes.data_as(ctypes.c_void_p),
-                                     ctypes.byref(out)), "icar_hip_max_courant")
-    dt = np.float32(options.parameters.cfl_reduction_factor) / np.float32(out.value)
+    """time_step.f90:217-330 for every cfl_strictness (1..5; 3 is the default): the reductions run on the device, the few
+    REAL(4) operations that combine them are the reference's, in its order (units included: settings 1 and 5 compare
+    m/s with a Courant number, as the reference does).  use_density is not on the path (its branches are empty)."""
+    f32 = np.float32
+    strict = int(options.parameters.cfl_strictness)
+    maxwind1d = maxwind3d = f32(0)
+    if strict in (1, 2, 5):
+        m = (ctypes.c_float * 3)()
+        check(lib().icar_hip_max_abs_winds(domain.ctx, m), "icar_hip_max_abs_winds")
+        mu, mv, mw = f32(m[0]), f32(m[1]), f32(m[2])
+    sqrt3 = f32(f32(np.sqrt(f32(3.0))) * f32(1.001))
+    if strict == 1:
+        maxwind1d = max(max(mu, mv), mw)
+        maxwind3d = f32(maxwind1d * sqrt3)
+    elif strict == 5:
+        maxwind3d = f32(f32(mu + mv) + mw)
+    else:
+        dzl = np.ascontiguousarray(options.parameters.dz_levels, np.float32)
+        out = ctypes.c_float()
+        check(lib().icar_hip_max_courant(domain.ctx, ctypes.c_float(domain.dx), dzl.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.byref(out)), "icar_hip_max_courant")
+        maxwind3d = f32(out.value)
+        if strict == 2:
+            maxwind3d = f32(maxwind3d * f32(0.577350269))
+            maxwind1d = max(max(mu, mv), mw)
+            maxwind3d = max(maxwind1d, maxwind3d)
+        elif strict == 4:
+            maxwind3d = f32(maxwind3d * sqrt3)
+    dt = f32(options.parameters.cfl_reduction_factor) / f32(maxwind3d)
     if dt < 1e-1:
         raise IcarHipError("ERROR time step too small")      # time_step.f90:322-328 `stop`
     return float(dt)

@@ -159,6 +159,8 @@ int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, 
 /* ---- T2: CFL reduction for compute_dt (src/main/time_step.f90:217-330, cfl_strictness 3) -----
  * out = max over the tile of max(|u_i|,|u_i+1|)/dx + max(|v_j|,|v_j+1|)/dx + max(|w_k|,|w_k-1|)/dz_levels(k) */
 int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, float *out);
+/* the other cfl_strictness settings (:238-259, :293-305) also need out[0..2] = maxval(abs(u)), maxval(abs(v)), maxval(abs(w)) */
+int icar_hip_max_abs_winds(icar_hip_ctx *ctx, float out[3]);
 
 /* ---- T3: diagnostic_update (src/main/time_step.f90:49-198) ------------------------------------
  * exner=(p/1e5)^(Rd/cp), interface pressure/temperature, surface pressure, T=theta*exner,

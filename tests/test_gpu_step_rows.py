@@ -123,6 +123,29 @@ def test_balance_uvw_and_compute_dt(oracle):
     d.close()
 
 
+@pytest.mark.parametrize("strict", [1, 2, 3, 4, 5])
+def test_compute_dt_every_cfl_strictness(oracle, strict):
+    """compute_dt (time_step.f90:217-330) for cfl_strictness 1..5: the reductions (max over cells of the summed face maxima;
+    maxval(abs(u|v|w))) come from the device, the REAL(4) combination is the reference's.  Maxima are exact, so the
+    result equals the host evaluation of the same formula bit for bit."""
+    c = case(58, 27, 13, seed=20 + strict)
+    c["w"] = (c["w"] * np.float32(3.0)).astype(np.float32)
+    d = single_image_domain(c)
+    opt = options_t(); opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.cfl_strictness = strict
+    f32 = np.float32
+    mu, mv, mw = f32(np.abs(c["u"]).max()), f32(np.abs(c["v"]).max()), f32(np.abs(c["w"]).max())
+    cell = f32(oracle.max_courant(c["u"], c["v"], c["w"], c["dz_levels"], float(c["dx"])))
+    sqrt3 = f32(f32(np.sqrt(f32(3.0))) * f32(1.001))
+    want = {1: f32(max(mu, mv, mw) * sqrt3), 2: max(max(mu, mv, mw), f32(cell * f32(0.577350269))), 3: cell, 4: f32(cell * sqrt3),
+            5: f32(f32(mu + mv) + mw)}[strict]
+    if f32(0.9) / want < 0.1:                                   # settings 1 and 5 compare m/s with a Courant number (reference quirk)
+        with pytest.raises(Exception, match="time step too small"):
+            compute_dt(d, opt)
+    else:
+        assert compute_dt(d, opt) == float(f32(0.9) / want)
+    d.close()
+
+
 def test_update_winds_first_and_later_calls(oracle):
     """update_winds (wind.f90:289-360), windtype 0: first call balances w from u, v; later calls balance the forcing
     tendencies u/v/w%dqdt_3d.  Same kernel, same oracle routine on the other arrays."""
