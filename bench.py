@@ -321,7 +321,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.nx}x{args.ny}x{args.nz} owned cells per GPU, {args.adv} order-2+FCT advection of "
+            "config": {"workload": f"{args.nx}x{args.ny}x{args.nz} owned cells per GPU, "
+                                   f"{'mpdata order-2+FCT' if args.adv == 'mpdata' else 'upwind'} advection of "
                                    f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
                        "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",
                        "dt_s": dt, "mp_active_column_fraction": active},
