@@ -123,15 +123,30 @@ k_apply_forcing(Dims d, ForceArgs a, double dt, int west, int east, int south, i
 {
     const int m = blockIdx.z;
     const int nxm = d.nx + (a.stag[m] == 1), nym = d.ny + (a.stag[m] == 2);
-    const size_t n = (size_t)nxm * d.nz * nym;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
-        bool doit = true;
-        if (a.fb[m]) {          // domain_obj.f90:2411-2423: W/E columns without the corner rows, S/N full rows
-            const int i = (int)(t % nxm), j = (int)(t / ((size_t)nxm * d.nz));
-            doit = (west && i == 0 && j > 0 && j < nym - 1) || (east && i == nxm - 1 && j > 0 && j < nym - 1)
-                || (south && j == 0) || (north && j == nym - 1);
+    float *__restrict__ x = a.x[m];
+    const float *__restrict__ dq = a.dq[m];
+    if (!a.fb[m]) {                                             // whole field: u, v, w, pressure ...
+        const size_t n = (size_t)nxm * d.nz * nym;
+        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x)
+            x[t] = (float)((double)x[t] + ((double)dq[t] * dt));   // REAL + REAL*REAL(8)
+        return;
+    }
+    // domain_obj.f90:2411-2423: only the true domain edges -- S/N full rows, W/E columns without the corner rows.
+    // Enumerate just those cells: [south row | north row | west column | east column]
+    const int nrow = nxm * d.nz, ncol = d.nz * (nym - 2);
+    const int total = 2 * nrow + 2 * ncol;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        int i, k, j; bool on;
+        if (t < 2 * nrow) {
+            const int r = t < nrow ? t : t - nrow;
+            i = r % nxm; k = r / nxm; j = t < nrow ? 0 : nym - 1; on = t < nrow ? south : north;
+        } else {
+            const int s2 = t - 2 * nrow, r = s2 < ncol ? s2 : s2 - ncol;
+            k = r % d.nz; j = 1 + r / d.nz; i = s2 < ncol ? 0 : nxm - 1; on = s2 < ncol ? west : east;
         }
-        if (doit) a.x[m][t] = (float)((double)a.x[m][t] + ((double)a.dq[m][t] * dt));   // REAL + REAL*REAL(8)
+        if (!on) continue;
+        const size_t c = (size_t)i + (size_t)nxm * (k + (size_t)d.nz * j);
+        x[c] = (float)((double)x[c] + ((double)dq[c] * dt));
     }
 }
 
