@@ -15,32 +15,43 @@ __device__ __forceinline__ float exner_function(float pressure)
     return (float)d_exp((double)(Rd / cp) * d_log((double)(pressure / 100000.0f)));
 }
 
-__global__ void __launch_bounds__(256)
+#define DIAG_BY 8
+__global__ void __launch_bounds__(64 * DIAG_BY)
 k_diag_thermo(Dims d, const float *__restrict__ p, const float *__restrict__ th, float *__restrict__ exner,
               float *__restrict__ p_i, float *__restrict__ psfc, float *__restrict__ T, float *__restrict__ T_i,
               float *__restrict__ rho, const float *__restrict__ u, const float *__restrict__ v,
               float *__restrict__ u_mass, float *__restrict__ v_mass)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
-    if (i >= d.nx || k >= d.nz) return;
-    const int c = d.idx(i, k, j);
-    const float pc = p[c];
-    const float ex = exner_function(pc);
-    exner[c] = ex;
-    const float t = th[c] * ex;                                   // :95
-    if (T) T[c] = t;
-    if (rho) rho[c] = pc / (Rd * t);                               // :101
+    // the interface values need the temperature of the level below (above, at the surface): each thread evaluates the one
+    // pow of ITS cell and hands T to its k-neighbours through LDS; only the first level of a block's k-chunk (and the
+    // surface level, which looks up) evaluates a second one
+    __shared__ float s_t[DIAG_BY][64];
+    const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * DIAG_BY + threadIdx.y, j = blockIdx.z;
+    const bool in = (i < d.nx && k < d.nz);
+    const int c = in ? d.idx(i, k, j) : 0;
+    float pc = 0.0f, t = 0.0f;
+    if (in) {
+        pc = p[c];
+        const float ex = exner_function(pc);
+        exner[c] = ex;
+        t = th[c] * ex;                                           // :95
+        if (T) T[c] = t;
+        if (rho) rho[c] = pc / (Rd * t);                           // :101
+    }
+    s_t[threadIdx.y][threadIdx.x] = t;
+    __syncthreads();
+    if (!in) return;
     // interface values (:88-98): level kms extrapolates from kms+1, others average with the level below
     if (p_i || T_i) {
         float pn, tn;
         if (k == 0) {
             const float p1 = p[c + d.sk];
-            const float t1 = th[c + d.sk] * exner_function(p1);
+            const float t1 = (threadIdx.y + 1 < DIAG_BY && k + 1 < d.nz) ? s_t[threadIdx.y + 1][threadIdx.x] : th[c + d.sk] * exner_function(p1);
             pn = pc + (pc - p1) / 2; tn = t + (t - t1) / 2;
             if (psfc) psfc[i + d.nx * j] = pn;
         } else {
             const float pm = p[c - d.sk];
-            const float tm = th[c - d.sk] * exner_function(pm);
+            const float tm = threadIdx.y > 0 ? s_t[threadIdx.y - 1][threadIdx.x] : th[c - d.sk] * exner_function(pm);
             pn = (pm + pc) / 2; tn = (tm + t) / 2;
         }
         if (p_i) p_i[c] = pn;
@@ -171,7 +182,7 @@ int icar_diagnostic_update_run(icar_hip_ctx *c)
     const float *u = (const float *)c->field[ICAR_F_U], *v = (const float *)c->field[ICAR_F_V];
     float *um = u ? icar_field_f(c, ICAR_F_U_MASS, false) : nullptr, *vm = v ? icar_field_f(c, ICAR_F_V_MASS, false) : nullptr;
     ScopedTimer t(c, "diag");
-    dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
+    dim3 g((c->d.nx + 63) / 64, (c->d.nz + DIAG_BY - 1) / DIAG_BY, c->d.ny), b(64, DIAG_BY);
     hipLaunchKernelGGL(k_diag_thermo, g, b, 0, c->stream, c->d, p, th, ex, pi, ps, T, Ti, rho, u, v, um, vm);
     ColumnArgs ca;
     ca.ivt = (float *)c->field[ICAR_F_IVT]; ca.iwv = (float *)c->field[ICAR_F_IWV];
