@@ -12,7 +12,7 @@ O = os.path.join(ROOT, "gpurun_out", "r01")
 shutil.copy(os.path.join(O, "bench_line.json"), os.path.join(HERE, "r01_bench_line.json"))
 if os.path.exists(os.path.join(O, "winds.json")):
     shutil.copy(os.path.join(O, "winds.json"), os.path.join(HERE, "r01_winds.json"))
-db = glob.glob(os.path.join(O, "trace", "**", "*.db"), recursive=True)[0]
+db = max(glob.glob(os.path.join(O, "trace", "**", "*.db"), recursive=True), key=os.path.getmtime)   # gpurun merges: older runs may linger
 md = os.path.join(HERE, "r01_kernel_stats.md")
 open(md, "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline (MI355X, 512x512x40, N=1)\n\n")
 subprocess.check_call([sys.executable, os.path.join(HERE, "summarize_rocpd.py"), db, md], stdout=subprocess.DEVNULL)
