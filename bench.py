@@ -309,6 +309,23 @@ def main():
         except Exception:
             traffic = None
 
+    stream_gbs = None
+    if rank == 0:
+        # the spec peak next to what a plain streaming copy sustains on THIS box (read + write of 1 GiB,
+        # torch's device-to-device copy kernel), measured outside the timed region
+        try:
+            a = torch.empty(1 << 28, dtype=torch.float32, device=device); b = torch.empty_like(a)
+            b.copy_(a); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record(); torch.cuda.synchronize()
+            stream_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del a, b
+        except Exception:  # pragma: no cover
+            stream_gbs = None
+
     if rank == 0:
         # liveness: how much of the tile the microphysics is doing work in
         qc = d.get("cloud_water_mass"); qr = d.get("rain_mass")
@@ -330,6 +347,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
                          "mp_ms_per_step": mp_ms_step,
+                         # informational: scalar-cell updates/s of the advection alone, and the measured
+                         # streaming-copy bandwidth of this box beside the spec peak that `frac` uses
+                         "advect_scalar_cell_updates_per_s": (mem_cells * nscal / (adv_ms * 1e-3)) if adv_ms > 0 else None,
+                         "measured_copy_GBps": stream_gbs,
+                         "frac_of_measured_copy": (achieved / stream_gbs) if stream_gbs else None,
                          # informational: the instruction-issue floor of the same launch.  700 VALU
                          # instructions per scalar-cell is the PMC count of profiles/r01_pmc.md for MPDATA order 2 + FCT;
                          # 1024 SIMDs x 16 lanes x 2.4 GHz lane-instructions per second.
