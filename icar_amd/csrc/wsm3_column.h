@@ -1,0 +1,458 @@
+/* icar_amd/csrc/wsm3_column.h -- WSM3 (Hong, Dudhia, Chen 2004) for ONE column: src/physics/mp_wsm3.f90:218-903 (wsm32D),
+ * :1008-1068 (slope_wsm3), :1266-1505 (nislfv_rain_plm), :951-1006 (wsm3init), statement by statement in the reference's
+ * operation order.  The reference works on (i,k) slabs of one j row; nothing couples the columns of a slab, so the column
+ * is the unit here.  Plain C99 that also compiles as HIP device code: the includer defines
+ *   W3_FN                    function qualifiers (static inline / __device__ __forceinline__)
+ *   W3_EXP W3_LOG W3_POW W3_SQRT   REAL(4) exp, log, x**y, sqrt in the arithmetic of its side
+ *   W3_MAXK                  largest number of levels
+ * Included by icar_amd/csrc/mp_wsm3.hip (the product) and by oracle/wsm3_oracle.c (the CPU checker, which is pinned
+ * bit-for-bit to the compiled reference in tests/test_oracle_wsm3.py).
+ */
+#ifndef ICAR_WSM3_COLUMN_H
+#define ICAR_WSM3_COLUMN_H
+
+/* module parameters mp_wsm3.f90:37-56 */
+#define W3_dtcldcr 120.f
+#define W3_n0r 8.e6f
+#define W3_avtr 841.9f
+#define W3_bvtr 0.8f
+#define W3_r0 .8e-5f
+#define W3_peaut .55f
+#define W3_xncr 3.e8f
+#define W3_xmyu 1.718e-5f
+#define W3_avts 11.72f
+#define W3_bvts .41f
+#define W3_n0smax 1.e11f
+#define W3_lamdarmax 8.e4f
+#define W3_lamdasmax 1.e5f
+#define W3_dicon 11.9f
+#define W3_dimax 500.e-6f
+#define W3_n0s 2.e6f
+#define W3_alpha .12f
+#define W3_qcrmin 1.e-9f
+
+typedef struct wsm3_consts {        /* the SAVE variables wsm3init derives, :57-72 */
+    float qc0, qck1, pidnc, bvtr1, bvtr2, bvtr3, bvtr4, g1pbr, g3pbr, g4pbr, g5pbro2, pvtr, eacrr, pacrr, precr1, precr2,
+          xmmax, roqimax, bvts1, bvts2, bvts3, bvts4, g1pbs, g3pbs, g4pbs, g5pbso2, pvts, pacrs, precs1, precs2, pidn0r, pidn0s,
+          xlv1, pi, rslopermax, rslopesmax, rsloperbmax, rslopesbmax, rsloper2max, rslopes2max, rsloper3max, rslopes3max;
+} wsm3_consts;
+
+typedef struct wsm3_args {          /* what mp_driver.f90:554-585 passes */
+    float delt, g, cpd, cpv, rd, rv, t0c, ep1, ep2, qmin, xls, xlv0, xlf0, den0, denr, cliq, cice, psat;
+} wsm3_args;
+
+W3_FN float w3_max(float a, float b) { return a > b ? a : b; }     /* Fortran max/min of two reals */
+W3_FN float w3_min(float a, float b) { return a < b ? a : b; }
+
+/* slope_wsm3 (:1008-1068) for levels 0..km-1 */
+W3_FN void wsm3_slope(const wsm3_consts *C, int km, const float *qrs, const float *den, const float *denfac, const float *t,
+                      float *rslope, float *rslopeb, float *rslope2, float *rslope3, float *vt)
+{
+    const float t0c = 273.15f;
+    for (int k = 0; k < km; ++k) {
+        float pvt;
+        if (t[k] >= t0c) {
+            pvt = C->pvtr;
+            if (qrs[k] <= W3_qcrmin) {
+                rslope[k] = C->rslopermax; rslopeb[k] = C->rsloperbmax; rslope2[k] = C->rsloper2max; rslope3[k] = C->rsloper3max;
+            } else {
+                rslope[k] = 1.f / W3_SQRT(W3_SQRT(C->pidn0r / (qrs[k] * den[k])));
+                rslopeb[k] = W3_EXP(W3_LOG(rslope[k]) * (W3_bvtr));
+                rslope2[k] = rslope[k] * rslope[k];
+                rslope3[k] = rslope2[k] * rslope[k];
+            }
+        } else {
+            const float supcol = t0c - t[k];
+            const float n0sfac = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
+            pvt = C->pvts;
+            if (qrs[k] <= W3_qcrmin) {
+                rslope[k] = C->rslopesmax; rslopeb[k] = C->rslopesbmax; rslope2[k] = C->rslopes2max; rslope3[k] = C->rslopes3max;
+            } else {
+                rslope[k] = 1.f / W3_SQRT(W3_SQRT(C->pidn0s * n0sfac / (qrs[k] * den[k])));
+                rslopeb[k] = W3_EXP(W3_LOG(rslope[k]) * (W3_bvts));
+                rslope2[k] = rslope[k] * rslope[k];
+                rslope3[k] = rslope2[k] * rslope[k];
+            }
+        }
+        vt[k] = pvt * rslopeb[k] * denfac[k];
+        if (qrs[k] <= 0.0f) vt[k] = 0.0f;
+    }
+}
+
+/* nislfv_rain_plm (:1266-1505) for one column: semi-Lagrangian fall with a piecewise-linear reconstruction.
+ * rql is den*q on input and output; ww the terminal velocity (updated when iter == 1); returns precip. */
+W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, const float *denfac, const float *tk, const float *dz,
+                            const float *wwl, float *rql, float dt, int iter)
+{
+    float ww[W3_MAXK], qq[W3_MAXK], wd[W3_MAXK], wa[W3_MAXK], was[W3_MAXK], qn[W3_MAXK], qr[W3_MAXK];
+    float tmp[W3_MAXK], tmp1[W3_MAXK], tmp2[W3_MAXK], tmp3[W3_MAXK];
+    float wi[W3_MAXK + 1], zi[W3_MAXK + 1], za[W3_MAXK + 1], dza[W3_MAXK + 1], qa[W3_MAXK + 1], qmi[W3_MAXK + 1], qpi[W3_MAXK + 1];
+    float precip = 0.0f;
+    float allold = 0.0f;
+    for (int k = 0; k < km; ++k) { qq[k] = rql[k]; ww[k] = wwl[k]; was[k] = 0.0f; }
+    for (int k = 0; k < km; ++k) allold = allold + qq[k];
+    if (allold <= 0.0f) return precip;                       /* cycle i_loop: nothing changes, not even rql */
+    zi[0] = 0.0f;
+    for (int k = 0; k < km; ++k) zi[k + 1] = zi[k] + dz[k];
+    for (int k = 0; k < km; ++k) wd[k] = ww[k];
+    int n = 1;
+    for (;;) {
+        /* 3rd-order interpolation of the fall speed to the interfaces (:1303-1320; the first, linear, estimate :1298-1302 is
+         * overwritten) */
+        const float fa1 = 9.f / 16.f, fa2 = 1.f / 16.f;
+        wi[0] = ww[0];
+        wi[km] = ww[km - 1];
+        for (int k = 1; k < km; ++k) wi[k] = (ww[k] * dz[k - 1] + ww[k - 1] * dz[k]) / (dz[k - 1] + dz[k]);
+        wi[0] = ww[0];
+        wi[1] = 0.5f * (ww[1] + ww[0]);
+        for (int k = 2; k < km - 1; ++k) wi[k] = fa1 * (ww[k] + ww[k - 1]) - fa2 * (ww[k + 1] + ww[k - 2]);
+        wi[km - 1] = 0.5f * (ww[km - 1] + ww[km - 2]);
+        wi[km] = ww[km - 1];
+        for (int k = 1; k < km; ++k) if (ww[k] == 0.0f) wi[k] = ww[k - 1];          /* terminate at the top of the rain shaft */
+        const float con1 = 0.05f;                                                  /* diffusivity of wi */
+        for (int k = km - 1; k >= 0; --k) {
+            const float decfl = (wi[k + 1] - wi[k]) * dt / dz[k];
+            if (decfl > con1) wi[k] = wi[k + 1] - con1 * dz[k] / dt;
+        }
+        for (int k = 0; k <= km; ++k) za[k] = zi[k] - wi[k] * dt;                  /* arrival points */
+        for (int k = 0; k < km; ++k) dza[k] = za[k + 1] - za[k];
+        dza[km] = zi[km] - za[km];
+        for (int k = 0; k < km; ++k) { qa[k] = qq[k] * dz[k] / dza[k]; qr[k] = qa[k] / den[k]; }
+        qa[km] = 0.0f;
+        if (n <= iter) {
+            wsm3_slope(C, km, qr, den, denfac, tk, tmp, tmp1, tmp2, tmp3, wa);
+            if (n >= 2) for (int k = 0; k < km; ++k) wa[k] = 0.5f * (wa[k] + was[k]);
+            for (int k = 0; k < km; ++k) ww[k] = 0.5f * (wd[k] + wa[k]);
+            for (int k = 0; k < km; ++k) was[k] = wa[k];
+            n = n + 1;
+            continue;
+        }
+        break;
+    }
+    /* piecewise-linear reconstruction (:1349-1369) */
+    for (int k = 1; k < km; ++k) {
+        const float dip = (qa[k + 1] - qa[k]) / (dza[k + 1] + dza[k]);
+        const float dim = (qa[k] - qa[k - 1]) / (dza[k - 1] + dza[k]);
+        if (dip * dim <= 0.0f) { qmi[k] = qa[k]; qpi[k] = qa[k]; }
+        else {
+            qpi[k] = qa[k] + 0.5f * (dip + dim) * dza[k];
+            qmi[k] = 2.0f * qa[k] - qpi[k];
+            if (qpi[k] < 0.0f || qmi[k] < 0.0f) { qpi[k] = qa[k]; qmi[k] = qa[k]; }
+        }
+    }
+    qpi[0] = qa[0]; qmi[0] = qa[0]; qmi[km] = qa[km]; qpi[km] = qa[km];
+    for (int k = 0; k < km; ++k) qn[k] = 0.0f;
+    /* interpolation to the regular grid (:1374-1441); kb, kt are 1-based like the reference's */
+    int kb = 1, kt = 1;
+    for (int k = 1; k <= km; ++k) {
+        kb = kb - 1 > 1 ? kb - 1 : 1;
+        kt = kt - 1 > 1 ? kt - 1 : 1;
+        if (zi[k - 1] >= za[km]) break;
+        for (int kk = kb; kk <= km; ++kk) if (zi[k - 1] <= za[kk]) { kb = kk; break; }
+        for (int kk = kt; kk <= km; ++kk) if (zi[k] <= za[kk - 1]) { kt = kk; break; }
+        kt = kt - 1;
+        if (kt == kb) {
+            const float tl = (zi[k - 1] - za[kb - 1]) / dza[kb - 1];
+            const float th = (zi[k] - za[kb - 1]) / dza[kb - 1];
+            const float tl2 = tl * tl, th2 = th * th;
+            const float qqd = 0.5f * (qpi[kb - 1] - qmi[kb - 1]);
+            const float qqh = qqd * th2 + qmi[kb - 1] * th;
+            const float qql = qqd * tl2 + qmi[kb - 1] * tl;
+            qn[k - 1] = (qqh - qql) / (th - tl);
+        } else if (kt > kb) {
+            const float tl = (zi[k - 1] - za[kb - 1]) / dza[kb - 1];
+            const float tl2 = tl * tl;
+            float qqd = 0.5f * (qpi[kb - 1] - qmi[kb - 1]);
+            const float qql = qqd * tl2 + qmi[kb - 1] * tl;
+            const float dql = qa[kb - 1] - qql;
+            float zsum = (1.f - tl) * dza[kb - 1];
+            float qsum = dql * dza[kb - 1];
+            if (kt - kb > 1) for (int m = kb + 1; m <= kt - 1; ++m) { zsum = zsum + dza[m - 1]; qsum = qsum + qa[m - 1] * dza[m - 1]; }
+            const float th = (zi[k] - za[kt - 1]) / dza[kt - 1];
+            const float th2 = th * th;
+            qqd = 0.5f * (qpi[kt - 1] - qmi[kt - 1]);
+            const float dqh = qqd * th2 + qmi[kt - 1] * th;
+            zsum = zsum + th * dza[kt - 1];
+            qsum = qsum + dqh * dza[kt - 1];
+            qn[k - 1] = qsum / zsum;
+        }
+    }
+    /* rain out (:1443-1453) */
+    for (int k = 0; k < km; ++k) {
+        if (za[k] < 0.0f && za[k + 1] < 0.0f) { precip = precip + qa[k] * dza[k]; continue; }
+        else if (za[k] < 0.0f && za[k + 1] >= 0.0f) { precip = precip + qa[k] * (0.0f - za[k]); break; }
+        break;
+    }
+    for (int k = 0; k < km; ++k) rql[k] = qn[k];
+    return precip;                                          /* ww is a local copy in the reference: wwl is not updated */
+}
+
+/* wsm32D (:218-903) for one column.  t, q, qci, qrs in/out; rain..sr are this column's entries of the 2-D arrays. */
+W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *t, float *q, float *qci, float *qrs, const float *w,
+                       const float *den, const float *p, const float *delz, float *rain, float *rainncv, float *snow, float *snowncv,
+                       float *sr)
+{
+    const float delt = A->delt, cpd = A->cpd, cpv = A->cpv, rv = A->rv, t0c = A->t0c, ep2 = A->ep2, qmin = A->qmin, xls = A->xls,
+                xlv0 = A->xlv0, xlf0 = A->xlf0, den0 = A->den0, denr = A->denr, cliq = A->cliq, cice = A->cice, psat = A->psat;
+    float rh[W3_MAXK], qs[W3_MAXK], denfac[W3_MAXK], rslope[W3_MAXK], rslope2[W3_MAXK], rslope3[W3_MAXK], rslopeb[W3_MAXK];
+    float pgen[W3_MAXK], pisd[W3_MAXK], paut[W3_MAXK], pacr[W3_MAXK], pres[W3_MAXK], pcon[W3_MAXK];
+    float fall[W3_MAXK], xl[W3_MAXK], cpm[W3_MAXK], work1[W3_MAXK], work2[W3_MAXK], xni[W3_MAXK], denq[W3_MAXK], n0sfac[W3_MAXK],
+          work1c[W3_MAXK];
+    float tstepsnow = 0.f;
+#define W3_CPMCAL(x) (cpd * (1.f - w3_max(x, qmin)) + w3_max(x, qmin) * cpv)
+#define W3_XLCAL(x) (xlv0 - C->xlv1 * ((x) - t0c))
+#define W3_DIFFUS(x, y) (8.794e-5f * W3_EXP(W3_LOG(x) * (1.81f)) / (y))
+#define W3_VISCOS(x, y) (1.496e-6f * ((x) * W3_SQRT(x)) / ((x) + 120.f) / (y))
+#define W3_XKA(x, y) (1.414e3f * W3_VISCOS(x, y) * (y))
+#define W3_DIFFAC(a, b, c, d, e) ((d) * (a) * (a) / (W3_XKA(c, d) * rv * (c) * (c)) + 1.f / ((e) * W3_DIFFUS(c, b)))
+#define W3_VENFAC(a, b, c) (W3_EXP(W3_LOG((W3_VISCOS(b, c) / W3_DIFFUS(b, a))) * ((.3333333f))) / W3_SQRT(W3_VISCOS(b, c)) * W3_SQRT(W3_SQRT(den0 / (c))))
+#define W3_CONDEN(a, b, c, d, e) ((w3_max(b, qmin) - (c)) / (1.f + (d) * (d) / (rv * (e)) * (c) / ((a) * (a))))
+    for (int k = 0; k < km; ++k) { qci[k] = w3_max(qci[k], 0.0f); qrs[k] = w3_max(qrs[k], 0.0f); }        /* :393-398 */
+    for (int k = 0; k < km; ++k) { cpm[k] = W3_CPMCAL(q[k]); xl[k] = W3_XLCAL(t[k]); }                    /* :400-405 */
+    *rainncv = 0.f; *snowncv = 0.f; *sr = 0.f;                                                            /* :412-417 */
+    long lp = lroundf(delt / W3_dtcldcr);
+    const int loops = lp > 1 ? (int)lp : 1;                                                               /* :418 */
+    float dtcld = delt / (float)loops;
+    if (delt <= W3_dtcldcr) dtcld = delt;
+    for (int loop = 1; loop <= loops; ++loop) {
+        for (int k = 0; k < km; ++k) {                                                                    /* :425-431 */
+            float tv = 1.0f / den[k];
+            tv = tv * den0;
+            denfac[k] = W3_SQRT(tv);
+        }
+        const float cvap = cpv, hvap = xlv0, hsub = xls, ttp = t0c + 0.01f;                               /* :432-441 */
+        const float dldt = cvap - cliq, xa = -dldt / rv, xb = xa + hvap / (rv * ttp);
+        const float dldti = cvap - cice, xai = -dldti / rv, xbi = xai + hsub / (rv * ttp);
+        for (int k = 0; k < km; ++k) {                                                                    /* :442-457 */
+            const float tr = ttp / t[k];
+            if (t[k] < ttp) qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xai))) * W3_EXP(xbi * (1.f - tr));
+            else            qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xa))) * W3_EXP(xb * (1.f - tr));
+            /* qs0 (:450-451) is computed but never used */
+            qs[k] = w3_min(qs[k], 0.99f * p[k]);
+            qs[k] = ep2 * qs[k] / (p[k] - qs[k]);
+            qs[k] = w3_max(qs[k], qmin);
+            rh[k] = w3_max(q[k] / qs[k], qmin);
+        }
+        for (int k = 0; k < km; ++k) {                                                                    /* :458-473 */
+            pres[k] = 0.f; paut[k] = 0.f; pacr[k] = 0.f; pgen[k] = 0.f; pisd[k] = 0.f; pcon[k] = 0.f; fall[k] = 0.f;
+            xni[k] = 1.e3f;
+        }
+        for (int k = 0; k < km; ++k)                                                                      /* :474-479 */
+            xni[k] = w3_min(w3_max(5.38e7f * W3_EXP(W3_LOG((den[k] * w3_max(qci[k], qmin))) * (0.75f)), 1.e3f), 1.e6f);
+        /* ---- fall of rain / snow (:480-505) ---- */
+        wsm3_slope(C, km, qrs, den, denfac, t, rslope, rslopeb, rslope2, rslope3, work1);
+        for (int k = km - 1; k >= 0; --k) denq[k] = den[k] * qrs[k];
+        const float delqrs = wsm3_nislfv_plm(C, km, den, denfac, t, delz, work1, denq, dtcld, 1);
+        for (int k = 0; k < km; ++k) {
+            qrs[k] = w3_max(denq[k] / den[k], 0.f);
+            fall[k] = denq[k] * work1[k] / delz[k];
+        }
+        fall[0] = delqrs / delz[0] / dtcld;
+        /* ---- fall of cloud ice (:506-531) ---- */
+        for (int k = km - 1; k >= 0; --k) {
+            if (t[k] < t0c && qci[k] > 0.f) {
+                const float xmi = den[k] * qci[k] / xni[k];
+                const float diameter = w3_max(W3_dicon * W3_SQRT(xmi), 1.e-25f);
+                work1c[k] = 1.49e4f * W3_EXP(W3_LOG(diameter) * (1.31f));
+            } else work1c[k] = 0.f;
+        }
+        for (int k = km - 1; k >= 0; --k) denq[k] = den[k] * qci[k];
+        const float delqi = wsm3_nislfv_plm(C, km, den, denfac, t, delz, work1c, denq, dtcld, 0);
+        for (int k = 0; k < km; ++k) qci[k] = w3_max(denq[k] / den[k], 0.f);
+        const float fallc1 = delqi / delz[0] / dtcld;
+        /* ---- melting / freezing at the 0 C level (:532-569) ---- */
+        int mstep = 0;
+        for (int k = 1; k <= km; ++k) if (t[k - 1] >= t0c) mstep = k;
+        int kwork2 = mstep, kwork1 = mstep;
+        if (mstep != 0) { if (w[mstep - 1] > 0.f) kwork1 = mstep + 1; }
+        {
+            const int k = kwork1, kk = kwork2;
+            if (k * kk >= 1 && k <= km) {
+                const float qrsci = qrs[k - 1] + qci[k - 1];
+                if (qrsci > 0.f || fall[kk - 1] > 0.f) {
+                    const float frzmlt = w3_min(w3_max(-w[k - 1] * qrsci / delz[k - 1], -qrsci / dtcld), qrsci / dtcld);
+                    const float snomlt = w3_min(w3_max(fall[kk - 1] / den[kk - 1], -qrs[k - 1] / dtcld), qrs[k - 1] / dtcld);
+                    if (k == kk) t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * (frzmlt + snomlt) * dtcld;
+                    else {
+                        t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * frzmlt * dtcld;
+                        t[kk - 1] = t[kk - 1] - xlf0 / cpm[kk - 1] * snomlt * dtcld;
+                    }
+                }
+            }
+        }
+        /* ---- surface precipitation (:570-598) ---- */
+        {
+            float fallsum = fall[0], fallsum_qsi = 0.f;
+            if ((t0c - t[0]) > 0) { fallsum = fallsum + fallc1; fallsum_qsi = fall[0] + fallc1; }
+            if (fallsum > 0.f) {
+                *rainncv = fallsum * delz[0] / denr * dtcld * 1000.f + *rainncv;
+                *rain = fallsum * delz[0] / denr * dtcld * 1000.f + *rain;
+            }
+            if (fallsum_qsi > 0.f) {
+                tstepsnow = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + tstepsnow;
+                *snowncv = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + *snowncv;
+                *snow = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + *snow;
+            }
+            if (fallsum > 0.f) *sr = *snowncv / (*rainncv + 1.e-12f);
+        }
+        /* ---- microphysical rates (:599-736) ---- */
+        wsm3_slope(C, km, qrs, den, denfac, t, rslope, rslopeb, rslope2, rslope3, work1);
+        for (int k = 0; k < km; ++k) {
+            if (t[k] >= t0c) work1[k] = W3_DIFFAC(xl[k], p[k], t[k], den[k], qs[k]);
+            else             work1[k] = W3_DIFFAC(xls, p[k], t[k], den[k], qs[k]);
+            work2[k] = W3_VENFAC(p[k], t[k], den[k]);
+        }
+        for (int k = 0; k < km; ++k) {
+            const float supsat = w3_max(q[k], qmin) - qs[k];
+            const float satdt = supsat / dtcld;
+            if (t[k] >= t0c) {
+                /* warm rain (:622-645) */
+                if (qci[k] > C->qc0) {
+                    paut[k] = C->qck1 * W3_EXP(W3_LOG(qci[k]) * ((7.f / 3.f)));
+                    paut[k] = w3_min(paut[k], qci[k] / dtcld);
+                }
+                if (qrs[k] > W3_qcrmin && qci[k] > qmin)
+                    pacr[k] = w3_min(C->pacrr * rslope3[k] * rslopeb[k] * qci[k] * denfac[k], qci[k] / dtcld);
+                if (qrs[k] > 0.f) {
+                    const float coeres = rslope2[k] * W3_SQRT(rslope[k] * rslopeb[k]);
+                    pres[k] = (rh[k] - 1.f) * (C->precr1 * rslope2[k] + C->precr2 * work2[k] * coeres) / work1[k];
+                    if (pres[k] < 0.f) { pres[k] = w3_max(pres[k], -qrs[k] / dtcld); pres[k] = w3_max(pres[k], satdt / 2); }
+                    else pres[k] = w3_min(pres[k], satdt / 2);
+                }
+            } else {
+                /* cold rain (:646-735) */
+                const float supcol = t0c - t[k];
+                n0sfac[k] = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
+                int ifsat = 0;
+                xni[k] = w3_min(w3_max(5.38e7f * W3_EXP(W3_LOG((den[k] * w3_max(qci[k], qmin))) * (0.75f)), 1.e3f), 1.e6f);
+                const float eacrs = W3_EXP(0.07f * (-supcol));
+                if (qrs[k] > W3_qcrmin && qci[k] > qmin) {
+                    const float xmi = den[k] * qci[k] / xni[k];
+                    const float diameter = w3_min(W3_dicon * W3_SQRT(xmi), W3_dimax);
+                    const float vt2i = 1.49e4f * W3_POW(diameter, 1.31f);
+                    const float vt2s = C->pvts * rslopeb[k] * denfac[k];
+                    const float acrfac = 2.f * rslope3[k] + 2.f * diameter * rslope2[k] + diameter * diameter * rslope[k];
+                    pacr[k] = w3_min(C->pi * qci[k] * eacrs * W3_n0s * n0sfac[k] * fabsf(vt2s - vt2i) * acrfac / 4.f, qci[k] / dtcld);
+                }
+                if (qci[k] > 0.f) {
+                    const float xmi = den[k] * qci[k] / xni[k];
+                    const float diameter = W3_dicon * W3_SQRT(xmi);
+                    pisd[k] = 4.f * diameter * xni[k] * (rh[k] - 1.f) / work1[k];
+                    if (pisd[k] < 0.f) { pisd[k] = w3_max(pisd[k], satdt / 2); pisd[k] = w3_max(pisd[k], -qci[k] / dtcld); }
+                    else pisd[k] = w3_min(pisd[k], satdt / 2);
+                    if (fabsf(pisd[k]) >= fabsf(satdt)) ifsat = 1;
+                }
+                if (qrs[k] > 0.f && ifsat != 1) {
+                    const float coeres = rslope2[k] * W3_SQRT(rslope[k] * rslopeb[k]);
+                    pres[k] = (rh[k] - 1.f) * n0sfac[k] * (C->precs1 * rslope2[k] + C->precs2 * work2[k] * coeres) / work1[k];
+                    const float supice = satdt - pisd[k];
+                    if (pres[k] < 0.f) { pres[k] = w3_max(pres[k], -qrs[k] / dtcld); pres[k] = w3_max(w3_max(pres[k], satdt / 2), supice); }
+                    else pres[k] = w3_min(w3_min(pres[k], satdt / 2), supice);
+                    if (fabsf(pisd[k] + pres[k]) >= fabsf(satdt)) ifsat = 1;
+                }
+                if (supsat > 0 && ifsat != 1) {
+                    const float supice = satdt - pisd[k] - pres[k];
+                    const float xni0 = 1.e3f * W3_EXP(0.1f * supcol);
+                    const float roqi0 = 4.92e-11f * W3_EXP(W3_LOG(xni0) * (1.33f));
+                    pgen[k] = w3_max(0.f, (roqi0 / den[k] - w3_max(qci[k], 0.f)) / dtcld);
+                    pgen[k] = w3_min(w3_min(pgen[k], satdt), supice);
+                }
+                if (qci[k] > 0.f) {
+                    const float qimax = C->roqimax / den[k];
+                    paut[k] = w3_max(0.f, (qci[k] - qimax) / dtcld);
+                }
+            }
+        }
+        /* ---- conservation + update (:737-770) ---- */
+        for (int k = 0; k < km; ++k) {
+            const float qciik = w3_max(qmin, qci[k]);
+            const float delqci = (paut[k] + pacr[k] - pgen[k] - pisd[k]) * dtcld;
+            if (delqci >= qciik) {
+                const float facqci = qciik / delqci;
+                paut[k] = paut[k] * facqci; pacr[k] = pacr[k] * facqci; pgen[k] = pgen[k] * facqci; pisd[k] = pisd[k] * facqci;
+            }
+            const float qik = w3_max(qmin, q[k]);
+            const float delq = (pres[k] + pgen[k] + pisd[k]) * dtcld;
+            if (delq >= qik) {
+                const float facq = qik / delq;
+                pres[k] = pres[k] * facq; pgen[k] = pgen[k] * facq; pisd[k] = pisd[k] * facq;
+            }
+            work2[k] = -pres[k] - pgen[k] - pisd[k];
+            q[k] = q[k] + work2[k] * dtcld;
+            qci[k] = w3_max(qci[k] - (paut[k] + pacr[k] - pgen[k] - pisd[k]) * dtcld, 0.f);
+            qrs[k] = w3_max(qrs[k] + (paut[k] + pacr[k] + pres[k]) * dtcld, 0.f);
+            if (t[k] < t0c) t[k] = t[k] - xls * work2[k] / cpm[k] * dtcld;
+            else            t[k] = t[k] - xl[k] * work2[k] / cpm[k] * dtcld;
+        }
+        /* ---- condensation (:771-808) ---- */
+        for (int k = 0; k < km; ++k) {
+            const float tr = ttp / t[k];
+            qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xa))) * W3_EXP(xb * (1.f - tr));
+            qs[k] = w3_min(qs[k], 0.99f * p[k]);
+            qs[k] = ep2 * qs[k] / (p[k] - qs[k]);
+            qs[k] = w3_max(qs[k], qmin);
+            denfac[k] = W3_SQRT(den0 / den[k]);
+        }
+        for (int k = 0; k < km; ++k) {
+            work1[k] = W3_CONDEN(t[k], q[k], qs[k], xl[k], cpm[k]);
+            work2[k] = qci[k] + work1[k];
+            pcon[k] = w3_min(w3_max(work1[k], 0.f), w3_max(q[k], 0.f)) / dtcld;
+            if (qci[k] > 0.f && work1[k] < 0.f && t[k] > t0c) pcon[k] = w3_max(work1[k], -qci[k]) / dtcld;
+            q[k] = q[k] - pcon[k] * dtcld;
+            qci[k] = w3_max(qci[k] + pcon[k] * dtcld, 0.f);
+            t[k] = t[k] + pcon[k] * xl[k] / cpm[k] * dtcld;
+        }
+        for (int k = 0; k < km; ++k) {                                                                    /* :809-815 */
+            if (qci[k] <= qmin) qci[k] = 0.0f;
+            if (qrs[k] <= W3_qcrmin) qrs[k] = 0.0f;
+        }
+    }
+    (void)tstepsnow; (void)ep2;
+}
+
+
+#ifdef W3_HOST_INIT
+/* wsm3init (:951-1006) with the arguments of mp_driver.f90:105: REAL(4) arithmetic in the reference's order, libm for
+ * exp / atan / x**y (host side, once).  rgmma (:905-922) is the 10000-term product form of 1/Gamma. */
+static float w3_rgmma(float x)
+{
+    const float euler = 0.577215664901532f;
+    float r, y;
+    if (x == 1.f) return 0.f;
+    r = x * expf(euler * x);
+    for (int i = 1; i <= 10000; ++i) { y = (float)i; r = r * (1.000f + x / y) * expf(-x / y); }
+    return 1.f / r;
+}
+
+static void wsm3_init_consts(wsm3_consts *C, float den0, float denr, float dens, float cl, float cpv)
+{
+    C->pi = 4.f * atanf(1.f);
+    C->xlv1 = cl - cpv;
+    C->qc0 = 4.f / 3.f * C->pi * denr * (W3_r0 * W3_r0 * W3_r0) * W3_xncr / den0;
+    C->qck1 = .104f * 9.8f * W3_peaut / powf(W3_xncr * denr, 1.f / 3.f) / W3_xmyu * powf(den0, 4.f / 3.f);
+    C->pidnc = C->pi * denr / 6.f;
+    C->bvtr1 = 1.f + W3_bvtr; C->bvtr2 = 2.5f + .5f * W3_bvtr; C->bvtr3 = 3.f + W3_bvtr; C->bvtr4 = 4.f + W3_bvtr;
+    C->g1pbr = w3_rgmma(C->bvtr1); C->g3pbr = w3_rgmma(C->bvtr3); C->g4pbr = w3_rgmma(C->bvtr4); C->g5pbro2 = w3_rgmma(C->bvtr2);
+    C->pvtr = W3_avtr * C->g4pbr / 6.f;
+    C->eacrr = 1.0f;
+    C->pacrr = C->pi * W3_n0r * W3_avtr * C->g3pbr * .25f * C->eacrr;
+    C->precr1 = 2.f * C->pi * W3_n0r * .78f;
+    C->precr2 = 2.f * C->pi * W3_n0r * .31f * powf(W3_avtr, .5f) * C->g5pbro2;
+    C->xmmax = (W3_dimax / W3_dicon) * (W3_dimax / W3_dicon);
+    { const float d2 = W3_dimax * W3_dimax, d4 = d2 * d2; C->roqimax = 2.08e22f * (d4 * d4); }
+    C->bvts1 = 1.f + W3_bvts; C->bvts2 = 2.5f + .5f * W3_bvts; C->bvts3 = 3.f + W3_bvts; C->bvts4 = 4.f + W3_bvts;
+    C->g1pbs = w3_rgmma(C->bvts1); C->g3pbs = w3_rgmma(C->bvts3); C->g4pbs = w3_rgmma(C->bvts4); C->g5pbso2 = w3_rgmma(C->bvts2);
+    C->pvts = W3_avts * C->g4pbs / 6.f;
+    C->pacrs = C->pi * W3_n0s * W3_avts * C->g3pbs * .25f;
+    C->precs1 = 4.f * W3_n0s * .65f;
+    C->precs2 = 4.f * W3_n0s * .44f * powf(W3_avts, .5f) * C->g5pbso2;
+    C->pidn0r = C->pi * denr * W3_n0r;
+    C->pidn0s = C->pi * dens * W3_n0s;
+    C->rslopermax = 1.f / W3_lamdarmax; C->rslopesmax = 1.f / W3_lamdasmax;
+    C->rsloperbmax = powf(C->rslopermax, W3_bvtr); C->rslopesbmax = powf(C->rslopesmax, W3_bvts);
+    C->rsloper2max = C->rslopermax * C->rslopermax; C->rslopes2max = C->rslopesmax * C->rslopesmax;
+    C->rsloper3max = C->rsloper2max * C->rslopermax; C->rslopes3max = C->rslopes2max * C->rslopesmax;
+}
+#endif
+
+#endif

@@ -231,3 +231,26 @@ def calc_direction(u, v):
     fn = lib().orc_calc_direction
     fn.restype = ctypes.c_float
     return float(fn(_f(u), _f(v)))
+
+
+# ---- WSM3 (oracle/wsm3_oracle.c) -------------------------------------------------------------------------------------
+WSM3_CONSTS = ["qc0", "qck1", "pidnc", "bvtr1", "bvtr2", "bvtr3", "bvtr4", "g1pbr", "g3pbr", "g4pbr", "g5pbro2", "pvtr", "eacrr", "pacrr",
+               "precr1", "precr2", "xmmax", "roqimax", "bvts1", "bvts2", "bvts3", "bvts4", "g1pbs", "g3pbs", "g4pbs", "g5pbso2", "pvts",
+               "pacrs", "precs1", "precs2", "pidn0r", "pidn0s", "xlv1", "pi", "rslopermax", "rslopesmax", "rsloperbmax", "rslopesbmax",
+               "rsloper2max", "rslopes2max", "rsloper3max", "rslopes3max"]
+# what mp_driver.f90:105 / :554-585 pass (icar_constants.f90, wrf_constants.f90): den0, denr, dens, cliq, cpv
+WSM3_INIT_ARGS = (1.28, 1000.0, 100.0, 4190.0, 4.0 * 461.6)
+
+
+def wsm3_init(den0=WSM3_INIT_ARGS[0], denr=WSM3_INIT_ARGS[1], dens=WSM3_INIT_ARGS[2], cl=WSM3_INIT_ARGS[3], cpv=WSM3_INIT_ARGS[4]):
+    out = np.zeros(len(WSM3_CONSTS), np.float32)
+    lib().orc_wsm3_init(_f(den0), _f(denr), _f(dens), _f(cl), _f(np.float32(cpv)), _p(out))
+    return dict(zip(WSM3_CONSTS, out))
+
+
+def wsm3(th, q, qci, qrs, w, den, pii, p, delz, args18, rain, rainncv, snow, snowncv, sr, its, ite, jts, jte, kts, kte):
+    ny, nz, nx = q.shape
+    a = np.ascontiguousarray(args18, np.float32)
+    fn = lib().orc_wsm3; fn.restype = ctypes.c_int
+    return int(fn(_i(nx), _i(nz), _i(ny), _p(th), _p(q), _p(qci), _p(qrs), _p(w), _p(den), _p(pii), _p(p), _p(delz), _p(a),
+                  _p(rain), _p(rainncv), _p(snow), _p(snowncv), _p(sr), *[_i(x) for x in (its, ite, jts, jte, kts, kte)]))

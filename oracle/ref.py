@@ -186,3 +186,18 @@ def smooth_array_3d(a, windowsize, ydim=3):
     ny, nz, nx = a.shape
     lib().ref_smooth_array_3d(_i(nx), _i(nz), _i(ny), _p(a), _i(windowsize), _i(ydim))
     return a
+
+
+# ---- WSM3 (physics/mp_wsm3.f90 compiled unmodified) ------------------------------------------------------------------
+def wsm3_init():
+    """wsm3init as mp_driver.f90:105 calls it -> (module constants in the order of oracle.orc.WSM3_CONSTS, the 18 scalar
+    arguments mp_driver.f90:554-585 passes to wsm3; element 0 = delt is left 0)."""
+    out = np.zeros(44, np.float32); args = np.zeros(18, np.float32)
+    lib().ref_wsm3_init(_p(out), _p(args))
+    return out[:42].copy(), args
+
+
+def wsm3(th, q, qci, qrs, w, den, pii, p, delz, delt, rain, rainncv, snow, snowncv, sr, its, ite, jts, jte, kts, kte):
+    ny, nz, nx = q.shape
+    lib().ref_wsm3(_i(nx), _i(nz), _i(ny), _p(th), _p(q), _p(qci), _p(qrs), _p(w), _p(den), _p(pii), _p(p), _p(delz), _f(delt),
+                   _p(rain), _p(rainncv), _p(snow), _p(snowncv), _p(sr), *[_i(x) for x in (its, ite, jts, jte, kts, kte)])

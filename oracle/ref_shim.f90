@@ -23,6 +23,16 @@ module icar_ref_shim
   use mod_atm_utilities, only: exner_function, calc_direction, calc_speed, calc_u, calc_v, calc_stability, &
                                compute_ivt, compute_iq, sat_mr
   use array_utilities,   only: smooth_array, linear_space, calc_weight
+  use module_mp_wsm3,    only: wsm3, wsm3init, w3_qc0 => qc0, w3_qck1 => qck1, w3_pidnc => pidnc, w3_bvtr1 => bvtr1, &
+       w3_bvtr2 => bvtr2, w3_bvtr3 => bvtr3, w3_bvtr4 => bvtr4, w3_g1pbr => g1pbr, w3_g3pbr => g3pbr, w3_g4pbr => g4pbr, &
+       w3_g5pbro2 => g5pbro2, w3_pvtr => pvtr, w3_eacrr => eacrr, w3_pacrr => pacrr, w3_precr1 => precr1, w3_precr2 => precr2, &
+       w3_xmmax => xmmax, w3_roqimax => roqimax, w3_bvts1 => bvts1, w3_bvts2 => bvts2, w3_bvts3 => bvts3, w3_bvts4 => bvts4, &
+       w3_g1pbs => g1pbs, w3_g3pbs => g3pbs, w3_g4pbs => g4pbs, w3_g5pbso2 => g5pbso2, w3_pvts => pvts, w3_pacrs => pacrs, &
+       w3_precs1 => precs1, w3_precs2 => precs2, w3_pidn0r => pidn0r, w3_pidn0s => pidn0s, w3_xlv1 => xlv1, w3_pi => pi, &
+       w3_rslopermax => rslopermax, w3_rslopesmax => rslopesmax, w3_rsloperbmax => rsloperbmax, w3_rslopesbmax => rslopesbmax, &
+       w3_rsloper2max => rsloper2max, w3_rslopes2max => rslopes2max, w3_rsloper3max => rsloper3max, w3_rslopes3max => rslopes3max
+  use mod_wrf_constants, only: wc_cpv => cpv, wc_cliq => cliq, wc_cice => cice, wc_psat => psat, wc_XLS => XLS, wc_XLV => XLV, &
+       wc_XLF => XLF, wc_rhoair0 => rhoair0, wc_rhowater => rhowater, wc_rhosnow => rhosnow, wc_epsilon => epsilon
   use prif,              only: stub_num_images
   use adv_mpdata,        only: mpdata
   use adv_upwind,        only: upwind
@@ -273,5 +283,36 @@ contains
     integer(c_int), value :: nx, nz, ny, windowsize, ydim
     real(c_float), intent(inout) :: wind(nx,nz,ny)
     call smooth_array(wind, windowsize, ydim)
+  end subroutine
+
+  !> wsm3init (mp_wsm3.f90:951-1006) as mp_driver.f90:105 calls it; out(1:44) = the module constants it derives, in the order
+  !! of the use statement above; args(1:18) = what mp_driver.f90:554-585 passes to wsm3:
+  !! delt(unused here), g, cpd, cpv, rd, rv, t0c, ep1, ep2, qmin, XLS, XLV0, XLF0, den0, denr, cliq, cice, psat
+  subroutine ref_wsm3_init(out, args) bind(C, name="ref_wsm3_init")
+    real(c_float), intent(out) :: out(44), args(18)
+    call wsm3init(wc_rhoair0, wc_rhowater, wc_rhosnow, wc_cliq, wc_cpv, allowed_to_read=.true.)
+    out = [w3_qc0, w3_qck1, w3_pidnc, w3_bvtr1, w3_bvtr2, w3_bvtr3, w3_bvtr4, w3_g1pbr, w3_g3pbr, w3_g4pbr, w3_g5pbro2, w3_pvtr, &
+           w3_eacrr, w3_pacrr, w3_precr1, w3_precr2, w3_xmmax, w3_roqimax, w3_bvts1, w3_bvts2, w3_bvts3, w3_bvts4, w3_g1pbs, &
+           w3_g3pbs, w3_g4pbs, w3_g5pbso2, w3_pvts, w3_pacrs, w3_precs1, w3_precs2, w3_pidn0r, w3_pidn0s, w3_xlv1, w3_pi, &
+           w3_rslopermax, w3_rslopesmax, w3_rsloperbmax, w3_rslopesbmax, w3_rsloper2max, w3_rslopes2max, w3_rsloper3max, &
+           w3_rslopes3max, 0.0, 0.0]
+    args = [0.0, gravity, cp, wc_cpv, Rd, Rw, 273.15, EP1, EP2, wc_epsilon, wc_XLS, wc_XLV, wc_XLF, wc_rhoair0, wc_rhowater, &
+            wc_cliq, wc_cice, wc_psat]
+  end subroutine
+
+  !> wsm3 (mp_wsm3.f90:74) on a tile exactly as mp_driver.f90:554-585 calls it (has_req* = 0).  Arrays (nx,nz,ny) / (nx,ny).
+  subroutine ref_wsm3(nx, nz, ny, th, q, qci, qrs, w, den, pii, p, delz, delt, rain, rainncv, snow, snowncv, sr, &
+                      its, ite, jts, jte, kts, kte) bind(C, name="ref_wsm3")
+    integer(c_int), value :: nx, nz, ny, its, ite, jts, jte, kts, kte
+    real(c_float), value :: delt
+    real(c_float), intent(inout), dimension(nx,nz,ny) :: th, q, qci, qrs
+    real(c_float), intent(in), dimension(nx,nz,ny) :: w, den, pii, p, delz
+    real(c_float), intent(inout), dimension(nx,ny) :: rain, rainncv, snow, snowncv, sr
+    call wsm3(th=th, q=q, qci=qci, qrs=qrs, w=w, den=den, pii=pii, p=p, delz=delz, delt=delt, g=gravity, cpd=cp, cpv=wc_cpv, &
+              rd=Rd, rv=Rw, t0c=273.15, ep1=EP1, ep2=EP2, qmin=wc_epsilon, XLS=wc_XLS, XLV0=wc_XLV, XLF0=wc_XLF, &
+              den0=wc_rhoair0, denr=wc_rhowater, cliq=wc_cliq, cice=wc_cice, psat=wc_psat, rain=rain, rainncv=rainncv, &
+              snow=snow, snowncv=snowncv, sr=sr, has_reqc=0, has_reqi=0, has_reqs=0, &
+              ids=1, ide=nx, jds=1, jde=ny, kds=1, kde=nz, ims=1, ime=nx, jms=1, jme=ny, kms=1, kme=nz, &
+              its=its, ite=ite, jts=jts, jte=jte, kts=kts, kte=kte)
   end subroutine
 end module icar_ref_shim
