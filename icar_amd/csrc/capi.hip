@@ -321,6 +321,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     if (c->occ) hipFree(c->occ);
     if (c->needf) hipFree(c->needf);
     if (c->iw_adj) hipFree(c->iw_adj);
+    icar_wsm3_free(c);
     icar_thompson_free(c);
     icar_linwinds_free(c);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -497,6 +498,18 @@ int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
 {
     if (!c || (n > 0 && !fields)) { icar_set_error("enforce_limits: null argument"); return 1; }
     return icar_enforce_limits_run(c, fields, n);
+}
+
+int icar_hip_wsm3_init(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_wsm3_init_run(c);
+}
+
+int icar_hip_wsm3(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    return icar_wsm3_run(c, dt, its, ite, jts, jte, kts, kte);
 }
 
 int icar_hip_max_abs_winds(icar_hip_ctx *c, float *out3)

@@ -23,6 +23,7 @@ struct TimingGroup { double total_ms = 0; int launches = 0; };
 
 struct ThompsonTables;   // mp_thompson.hip
 struct LinWinds;         // linear_winds.hip
+struct Wsm3State;        // mp_wsm3.hip
 
 struct icar_hip_ctx {
     int device = 0;
@@ -46,6 +47,7 @@ struct icar_hip_ctx {
     int *d_flag = nullptr;
     ThompsonTables *thompson = nullptr;
     LinWinds *linwinds = nullptr;
+    Wsm3State *wsm3 = nullptr;
     // timing
     bool timing = false;
     std::map<std::string, TimingGroup> timers;
@@ -91,6 +93,9 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
 int icar_thompson_prepare_constants(icar_hip_ctx *c);
 void icar_thompson_free(icar_hip_ctx *c);
 void icar_linwinds_free(icar_hip_ctx *c);
+void icar_wsm3_free(icar_hip_ctx *c);
+int icar_wsm3_init_run(icar_hip_ctx *c);
+int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte);
 int icar_linwinds_setup_run(icar_hip_ctx *c, const icar_hip_lt_options *o, const float *terrain, int nxg, int nyg, int ids, int jds, float dx);
 int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, float zb, float zt, float minimum_step, double *u_out, double *v_out);
 int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *zt, int nlev);

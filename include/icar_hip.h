@@ -156,6 +156,13 @@ int icar_hip_thompson_table(icar_hip_ctx *ctx, const char *name, double *out, si
  * interior shrunk by subset; returns the number of tiles (integer-exact restatement). */
 int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, int tiles[4][4]);
 
+/* ---- WSM3 (src/physics/mp_wsm3.f90), the kMP_WSM3 slot of mp()'s dispatch (mp_driver.f90:103-106, :552-585) -------------
+ * wsm3_init == wsm3init(rhoair0, rhowater, rhosnow, cliq, cpv).  wsm3 == process_subdomain's call: qci = CLOUD_WATER,
+ * qrs = RAIN, w = W_REAL, den = DENSITY, pii = EXNER, delz = DZ_MASS; precipitation / snowfall of the call are added to the
+ * REAL(8) ICAR_F_PRECIPITATION / ICAR_F_SNOWFALL (:587-595).  Tile bounds 1-based inclusive like its..kte. */
+int icar_hip_wsm3_init(icar_hip_ctx *ctx);
+int icar_hip_wsm3(icar_hip_ctx *ctx, float dt, int its, int ite, int jts, int jte, int kts, int kte);
+
 /* ---- T2: CFL reduction for compute_dt (src/main/time_step.f90:217-330, cfl_strictness 3) -----
  * out = max over the tile of max(|u_i|,|u_i+1|)/dx + max(|v_j|,|v_j+1|)/dx + max(|w_k|,|w_k-1|)/dz_levels(k) */
 int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, float *out);
