@@ -44,65 +44,59 @@ typedef struct wsm3_args {          /* what mp_driver.f90:554-585 passes */
 W3_FN float w3_max(float a, float b) { return a > b ? a : b; }     /* Fortran max/min of two reals */
 W3_FN float w3_min(float a, float b) { return a < b ? a : b; }
 
-/* slope_wsm3 (:1008-1068) for levels 0..km-1 */
-W3_FN void wsm3_slope(const wsm3_consts *C, int km, const float *qrs, const float *den, const float *denfac, const float *t,
-                      float *rslope, float *rslopeb, float *rslope2, float *rslope3, float *vt)
+/* slope_wsm3 (:1008-1068) for ONE level: returns vt, the slopes through the pointers */
+W3_FN float wsm3_slope1(const wsm3_consts *C, float qrs, float den, float denfac, float t,
+                        float *rslope, float *rslopeb, float *rslope2, float *rslope3)
 {
     const float t0c = 273.15f;
-    for (int k = 0; k < km; ++k) {
-        float pvt;
-        if (t[k] >= t0c) {
-            pvt = C->pvtr;
-            if (qrs[k] <= W3_qcrmin) {
-                rslope[k] = C->rslopermax; rslopeb[k] = C->rsloperbmax; rslope2[k] = C->rsloper2max; rslope3[k] = C->rsloper3max;
-            } else {
-                rslope[k] = 1.f / W3_SQRT(W3_SQRT(C->pidn0r / (qrs[k] * den[k])));
-                rslopeb[k] = W3_EXP(W3_LOG(rslope[k]) * (W3_bvtr));
-                rslope2[k] = rslope[k] * rslope[k];
-                rslope3[k] = rslope2[k] * rslope[k];
-            }
+    float pvt;
+    if (t >= t0c) {
+        pvt = C->pvtr;
+        if (qrs <= W3_qcrmin) {
+            *rslope = C->rslopermax; *rslopeb = C->rsloperbmax; *rslope2 = C->rsloper2max; *rslope3 = C->rsloper3max;
         } else {
-            const float supcol = t0c - t[k];
-            const float n0sfac = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
-            pvt = C->pvts;
-            if (qrs[k] <= W3_qcrmin) {
-                rslope[k] = C->rslopesmax; rslopeb[k] = C->rslopesbmax; rslope2[k] = C->rslopes2max; rslope3[k] = C->rslopes3max;
-            } else {
-                rslope[k] = 1.f / W3_SQRT(W3_SQRT(C->pidn0s * n0sfac / (qrs[k] * den[k])));
-                rslopeb[k] = W3_EXP(W3_LOG(rslope[k]) * (W3_bvts));
-                rslope2[k] = rslope[k] * rslope[k];
-                rslope3[k] = rslope2[k] * rslope[k];
-            }
+            *rslope = 1.f / W3_SQRT(W3_SQRT(C->pidn0r / (qrs * den)));
+            *rslopeb = W3_EXP(W3_LOG(*rslope) * (W3_bvtr));
+            *rslope2 = *rslope * *rslope;
+            *rslope3 = *rslope2 * *rslope;
         }
-        vt[k] = pvt * rslopeb[k] * denfac[k];
-        if (qrs[k] <= 0.0f) vt[k] = 0.0f;
+    } else {
+        const float supcol = t0c - t;
+        const float n0sfac = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
+        pvt = C->pvts;
+        if (qrs <= W3_qcrmin) {
+            *rslope = C->rslopesmax; *rslopeb = C->rslopesbmax; *rslope2 = C->rslopes2max; *rslope3 = C->rslopes3max;
+        } else {
+            *rslope = 1.f / W3_SQRT(W3_SQRT(C->pidn0s * n0sfac / (qrs * den)));
+            *rslopeb = W3_EXP(W3_LOG(*rslope) * (W3_bvts));
+            *rslope2 = *rslope * *rslope;
+            *rslope3 = *rslope2 * *rslope;
+        }
     }
+    float vt = pvt * *rslopeb * denfac;
+    if (qrs <= 0.0f) vt = 0.0f;
+    return vt;
 }
 
 /* nislfv_rain_plm (:1266-1505) for one column: semi-Lagrangian fall with a piecewise-linear reconstruction.
- * rql is den*q on input and output; ww the terminal velocity (updated when iter == 1); returns precip. */
+ * rql is den*q on input and output; wwl the terminal velocity (a local copy is refined once when iter == 1; the caller's
+ * array is not changed, as in the reference).  iter is 0 or 1 (the two calls WSM3 makes).  Returns precip.
+ * The reference's scratch copies qq (= rql), wd (= wwl) and the unused slope outputs of its iteration are not materialised. */
 W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, const float *denfac, const float *tk, const float *dz,
                             const float *wwl, float *rql, float dt, int iter)
 {
-    float ww[W3_MAXK], qq[W3_MAXK], wd[W3_MAXK], wa[W3_MAXK], was[W3_MAXK], qn[W3_MAXK], qr[W3_MAXK];
-    float tmp[W3_MAXK], tmp1[W3_MAXK], tmp2[W3_MAXK], tmp3[W3_MAXK];
+    float ww[W3_MAXK], qn[W3_MAXK];
     float wi[W3_MAXK + 1], zi[W3_MAXK + 1], za[W3_MAXK + 1], dza[W3_MAXK + 1], qa[W3_MAXK + 1], qmi[W3_MAXK + 1], qpi[W3_MAXK + 1];
     float precip = 0.0f;
     float allold = 0.0f;
-    for (int k = 0; k < km; ++k) { qq[k] = rql[k]; ww[k] = wwl[k]; was[k] = 0.0f; }
-    for (int k = 0; k < km; ++k) allold = allold + qq[k];
+    for (int k = 0; k < km; ++k) { ww[k] = wwl[k]; allold = allold + rql[k]; }
     if (allold <= 0.0f) return precip;                       /* cycle i_loop: nothing changes, not even rql */
     zi[0] = 0.0f;
     for (int k = 0; k < km; ++k) zi[k + 1] = zi[k] + dz[k];
-    for (int k = 0; k < km; ++k) wd[k] = ww[k];
     int n = 1;
     for (;;) {
-        /* 3rd-order interpolation of the fall speed to the interfaces (:1303-1320; the first, linear, estimate :1298-1302 is
-         * overwritten) */
+        /* 3rd-order interpolation of the fall speed to the interfaces (:1303-1320; the linear estimate :1298-1302 is overwritten) */
         const float fa1 = 9.f / 16.f, fa2 = 1.f / 16.f;
-        wi[0] = ww[0];
-        wi[km] = ww[km - 1];
-        for (int k = 1; k < km; ++k) wi[k] = (ww[k] * dz[k - 1] + ww[k - 1] * dz[k]) / (dz[k - 1] + dz[k]);
         wi[0] = ww[0];
         wi[1] = 0.5f * (ww[1] + ww[0]);
         for (int k = 2; k < km - 1; ++k) wi[k] = fa1 * (ww[k] + ww[k - 1]) - fa2 * (ww[k + 1] + ww[k - 2]);
@@ -117,13 +111,14 @@ W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, cons
         for (int k = 0; k <= km; ++k) za[k] = zi[k] - wi[k] * dt;                  /* arrival points */
         for (int k = 0; k < km; ++k) dza[k] = za[k + 1] - za[k];
         dza[km] = zi[km] - za[km];
-        for (int k = 0; k < km; ++k) { qa[k] = qq[k] * dz[k] / dza[k]; qr[k] = qa[k] / den[k]; }
+        for (int k = 0; k < km; ++k) qa[k] = rql[k] * dz[k] / dza[k];
         qa[km] = 0.0f;
-        if (n <= iter) {
-            wsm3_slope(C, km, qr, den, denfac, tk, tmp, tmp1, tmp2, tmp3, wa);
-            if (n >= 2) for (int k = 0; k < km; ++k) wa[k] = 0.5f * (wa[k] + was[k]);
-            for (int k = 0; k < km; ++k) ww[k] = 0.5f * (wd[k] + wa[k]);
-            for (int k = 0; k < km; ++k) was[k] = wa[k];
+        if (n <= iter) {                                     /* n == 1 here: wa = slope(qa/den); ww = 0.5*(wd + wa) */
+            for (int k = 0; k < km; ++k) {
+                float r1, r2, r3, r4;
+                const float wa = wsm3_slope1(C, qa[k] / den[k], den[k], denfac[k], tk[k], &r1, &r2, &r3, &r4);
+                ww[k] = 0.5f * (wwl[k] + wa);
+            }
             n = n + 1;
             continue;
         }
@@ -184,20 +179,19 @@ W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, cons
         break;
     }
     for (int k = 0; k < km; ++k) rql[k] = qn[k];
-    return precip;                                          /* ww is a local copy in the reference: wwl is not updated */
+    return precip;
 }
 
-/* wsm32D (:218-903) for one column.  t, q, qci, qrs in/out; rain..sr are this column's entries of the 2-D arrays. */
+/* wsm32D (:218-903) for one column.  t, q, qci, qrs in/out; rain..sr are this column's entries of the 2-D arrays.
+ * The reference's per-level work arrays that never cross levels (the rates, the slopes, the condensation) are scalars of one
+ * fused level loop here: every statement still sees exactly the values it sees in the reference. */
 W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *t, float *q, float *qci, float *qrs, const float *w,
                        const float *den, const float *p, const float *delz, float *rain, float *rainncv, float *snow, float *snowncv,
                        float *sr)
 {
     const float delt = A->delt, cpd = A->cpd, cpv = A->cpv, rv = A->rv, t0c = A->t0c, ep2 = A->ep2, qmin = A->qmin, xls = A->xls,
                 xlv0 = A->xlv0, xlf0 = A->xlf0, den0 = A->den0, denr = A->denr, cliq = A->cliq, cice = A->cice, psat = A->psat;
-    float rh[W3_MAXK], qs[W3_MAXK], denfac[W3_MAXK], rslope[W3_MAXK], rslope2[W3_MAXK], rslope3[W3_MAXK], rslopeb[W3_MAXK];
-    float pgen[W3_MAXK], pisd[W3_MAXK], paut[W3_MAXK], pacr[W3_MAXK], pres[W3_MAXK], pcon[W3_MAXK];
-    float fall[W3_MAXK], xl[W3_MAXK], cpm[W3_MAXK], work1[W3_MAXK], work2[W3_MAXK], xni[W3_MAXK], denq[W3_MAXK], n0sfac[W3_MAXK],
-          work1c[W3_MAXK];
+    float rh[W3_MAXK], qs[W3_MAXK], denfac[W3_MAXK], fall[W3_MAXK], xl[W3_MAXK], cpm[W3_MAXK], work1[W3_MAXK], denq[W3_MAXK];
     float tstepsnow = 0.f;
 #define W3_CPMCAL(x) (cpd * (1.f - w3_max(x, qmin)) + w3_max(x, qmin) * cpv)
 #define W3_XLCAL(x) (xlv0 - C->xlv1 * ((x) - t0c))
@@ -207,23 +201,25 @@ W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *
 #define W3_DIFFAC(a, b, c, d, e) ((d) * (a) * (a) / (W3_XKA(c, d) * rv * (c) * (c)) + 1.f / ((e) * W3_DIFFUS(c, b)))
 #define W3_VENFAC(a, b, c) (W3_EXP(W3_LOG((W3_VISCOS(b, c) / W3_DIFFUS(b, a))) * ((.3333333f))) / W3_SQRT(W3_VISCOS(b, c)) * W3_SQRT(W3_SQRT(den0 / (c))))
 #define W3_CONDEN(a, b, c, d, e) ((w3_max(b, qmin) - (c)) / (1.f + (d) * (d) / (rv * (e)) * (c) / ((a) * (a))))
-    for (int k = 0; k < km; ++k) { qci[k] = w3_max(qci[k], 0.0f); qrs[k] = w3_max(qrs[k], 0.0f); }        /* :393-398 */
-    for (int k = 0; k < km; ++k) { cpm[k] = W3_CPMCAL(q[k]); xl[k] = W3_XLCAL(t[k]); }                    /* :400-405 */
+#define W3_XNI(k) w3_min(w3_max(5.38e7f * W3_EXP(W3_LOG((den[k] * w3_max(qci[k], qmin))) * (0.75f)), 1.e3f), 1.e6f)
+    for (int k = 0; k < km; ++k) {
+        qci[k] = w3_max(qci[k], 0.0f); qrs[k] = w3_max(qrs[k], 0.0f);                                      /* :393-398 */
+        cpm[k] = W3_CPMCAL(q[k]); xl[k] = W3_XLCAL(t[k]);                                                 /* :400-405 */
+    }
     *rainncv = 0.f; *snowncv = 0.f; *sr = 0.f;                                                            /* :412-417 */
     long lp = lroundf(delt / W3_dtcldcr);
     const int loops = lp > 1 ? (int)lp : 1;                                                               /* :418 */
     float dtcld = delt / (float)loops;
     if (delt <= W3_dtcldcr) dtcld = delt;
+    const float cvap = cpv, hvap = xlv0, hsub = xls, ttp = t0c + 0.01f;                                   /* :432-441, :771-780 */
+    const float dldt = cvap - cliq, xa = -dldt / rv, xb = xa + hvap / (rv * ttp);
+    const float dldti = cvap - cice, xai = -dldti / rv, xbi = xai + hsub / (rv * ttp);
     for (int loop = 1; loop <= loops; ++loop) {
-        for (int k = 0; k < km; ++k) {                                                                    /* :425-431 */
+        /* ---- state of this minor step (:425-479) and the terminal velocity of rain / snow (:480-484) ---- */
+        for (int k = 0; k < km; ++k) {
             float tv = 1.0f / den[k];
             tv = tv * den0;
             denfac[k] = W3_SQRT(tv);
-        }
-        const float cvap = cpv, hvap = xlv0, hsub = xls, ttp = t0c + 0.01f;                               /* :432-441 */
-        const float dldt = cvap - cliq, xa = -dldt / rv, xb = xa + hvap / (rv * ttp);
-        const float dldti = cvap - cice, xai = -dldti / rv, xbi = xai + hsub / (rv * ttp);
-        for (int k = 0; k < km; ++k) {                                                                    /* :442-457 */
             const float tr = ttp / t[k];
             if (t[k] < ttp) qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xai))) * W3_EXP(xbi * (1.f - tr));
             else            qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xa))) * W3_EXP(xb * (1.f - tr));
@@ -232,32 +228,27 @@ W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *
             qs[k] = ep2 * qs[k] / (p[k] - qs[k]);
             qs[k] = w3_max(qs[k], qmin);
             rh[k] = w3_max(q[k] / qs[k], qmin);
+            float r1, r2, r3, r4;
+            work1[k] = wsm3_slope1(C, qrs[k], den[k], denfac[k], t[k], &r1, &r2, &r3, &r4);
+            denq[k] = den[k] * qrs[k];
         }
-        for (int k = 0; k < km; ++k) {                                                                    /* :458-473 */
-            pres[k] = 0.f; paut[k] = 0.f; pacr[k] = 0.f; pgen[k] = 0.f; pisd[k] = 0.f; pcon[k] = 0.f; fall[k] = 0.f;
-            xni[k] = 1.e3f;
-        }
-        for (int k = 0; k < km; ++k)                                                                      /* :474-479 */
-            xni[k] = w3_min(w3_max(5.38e7f * W3_EXP(W3_LOG((den[k] * w3_max(qci[k], qmin))) * (0.75f)), 1.e3f), 1.e6f);
-        /* ---- fall of rain / snow (:480-505) ---- */
-        wsm3_slope(C, km, qrs, den, denfac, t, rslope, rslopeb, rslope2, rslope3, work1);
-        for (int k = km - 1; k >= 0; --k) denq[k] = den[k] * qrs[k];
+        /* ---- fall of rain / snow (:485-505) ---- */
         const float delqrs = wsm3_nislfv_plm(C, km, den, denfac, t, delz, work1, denq, dtcld, 1);
         for (int k = 0; k < km; ++k) {
             qrs[k] = w3_max(denq[k] / den[k], 0.f);
             fall[k] = denq[k] * work1[k] / delz[k];
         }
         fall[0] = delqrs / delz[0] / dtcld;
-        /* ---- fall of cloud ice (:506-531) ---- */
+        /* ---- fall of cloud ice (:506-531); xni (:474-479) is evaluated where it is used: den and qci have not changed ---- */
         for (int k = km - 1; k >= 0; --k) {
             if (t[k] < t0c && qci[k] > 0.f) {
-                const float xmi = den[k] * qci[k] / xni[k];
+                const float xmi = den[k] * qci[k] / W3_XNI(k);
                 const float diameter = w3_max(W3_dicon * W3_SQRT(xmi), 1.e-25f);
-                work1c[k] = 1.49e4f * W3_EXP(W3_LOG(diameter) * (1.31f));
-            } else work1c[k] = 0.f;
+                work1[k] = 1.49e4f * W3_EXP(W3_LOG(diameter) * (1.31f));
+            } else work1[k] = 0.f;
+            denq[k] = den[k] * qci[k];
         }
-        for (int k = km - 1; k >= 0; --k) denq[k] = den[k] * qci[k];
-        const float delqi = wsm3_nislfv_plm(C, km, den, denfac, t, delz, work1c, denq, dtcld, 0);
+        const float delqi = wsm3_nislfv_plm(C, km, den, denfac, t, delz, work1, denq, dtcld, 0);
         for (int k = 0; k < km; ++k) qci[k] = w3_max(denq[k] / den[k], 0.f);
         const float fallc1 = delqi / delz[0] / dtcld;
         /* ---- melting / freezing at the 0 C level (:532-569) ---- */
@@ -295,121 +286,111 @@ W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *
             }
             if (fallsum > 0.f) *sr = *snowncv / (*rainncv + 1.e-12f);
         }
-        /* ---- microphysical rates (:599-736) ---- */
-        wsm3_slope(C, km, qrs, den, denfac, t, rslope, rslopeb, rslope2, rslope3, work1);
+        /* ---- per level: rates (:599-736), conservation + update (:737-770), condensation (:771-815) ---- */
         for (int k = 0; k < km; ++k) {
-            if (t[k] >= t0c) work1[k] = W3_DIFFAC(xl[k], p[k], t[k], den[k], qs[k]);
-            else             work1[k] = W3_DIFFAC(xls, p[k], t[k], den[k], qs[k]);
-            work2[k] = W3_VENFAC(p[k], t[k], den[k]);
-        }
-        for (int k = 0; k < km; ++k) {
+            float rslope, rslopeb, rslope2, rslope3;
+            (void)wsm3_slope1(C, qrs[k], den[k], denfac[k], t[k], &rslope, &rslopeb, &rslope2, &rslope3);
+            float w1, w2;
+            if (t[k] >= t0c) w1 = W3_DIFFAC(xl[k], p[k], t[k], den[k], qs[k]);
+            else             w1 = W3_DIFFAC(xls, p[k], t[k], den[k], qs[k]);
+            w2 = W3_VENFAC(p[k], t[k], den[k]);
+            float pres = 0.f, paut = 0.f, pacr = 0.f, pgen = 0.f, pisd = 0.f, pcon;
             const float supsat = w3_max(q[k], qmin) - qs[k];
             const float satdt = supsat / dtcld;
             if (t[k] >= t0c) {
                 /* warm rain (:622-645) */
                 if (qci[k] > C->qc0) {
-                    paut[k] = C->qck1 * W3_EXP(W3_LOG(qci[k]) * ((7.f / 3.f)));
-                    paut[k] = w3_min(paut[k], qci[k] / dtcld);
+                    paut = C->qck1 * W3_EXP(W3_LOG(qci[k]) * ((7.f / 3.f)));
+                    paut = w3_min(paut, qci[k] / dtcld);
                 }
                 if (qrs[k] > W3_qcrmin && qci[k] > qmin)
-                    pacr[k] = w3_min(C->pacrr * rslope3[k] * rslopeb[k] * qci[k] * denfac[k], qci[k] / dtcld);
+                    pacr = w3_min(C->pacrr * rslope3 * rslopeb * qci[k] * denfac[k], qci[k] / dtcld);
                 if (qrs[k] > 0.f) {
-                    const float coeres = rslope2[k] * W3_SQRT(rslope[k] * rslopeb[k]);
-                    pres[k] = (rh[k] - 1.f) * (C->precr1 * rslope2[k] + C->precr2 * work2[k] * coeres) / work1[k];
-                    if (pres[k] < 0.f) { pres[k] = w3_max(pres[k], -qrs[k] / dtcld); pres[k] = w3_max(pres[k], satdt / 2); }
-                    else pres[k] = w3_min(pres[k], satdt / 2);
+                    const float coeres = rslope2 * W3_SQRT(rslope * rslopeb);
+                    pres = (rh[k] - 1.f) * (C->precr1 * rslope2 + C->precr2 * w2 * coeres) / w1;
+                    if (pres < 0.f) { pres = w3_max(pres, -qrs[k] / dtcld); pres = w3_max(pres, satdt / 2); }
+                    else pres = w3_min(pres, satdt / 2);
                 }
             } else {
                 /* cold rain (:646-735) */
                 const float supcol = t0c - t[k];
-                n0sfac[k] = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
+                const float n0sfac = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
                 int ifsat = 0;
-                xni[k] = w3_min(w3_max(5.38e7f * W3_EXP(W3_LOG((den[k] * w3_max(qci[k], qmin))) * (0.75f)), 1.e3f), 1.e6f);
+                const float xni = W3_XNI(k);
                 const float eacrs = W3_EXP(0.07f * (-supcol));
                 if (qrs[k] > W3_qcrmin && qci[k] > qmin) {
-                    const float xmi = den[k] * qci[k] / xni[k];
+                    const float xmi = den[k] * qci[k] / xni;
                     const float diameter = w3_min(W3_dicon * W3_SQRT(xmi), W3_dimax);
                     const float vt2i = 1.49e4f * W3_POW(diameter, 1.31f);
-                    const float vt2s = C->pvts * rslopeb[k] * denfac[k];
-                    const float acrfac = 2.f * rslope3[k] + 2.f * diameter * rslope2[k] + diameter * diameter * rslope[k];
-                    pacr[k] = w3_min(C->pi * qci[k] * eacrs * W3_n0s * n0sfac[k] * fabsf(vt2s - vt2i) * acrfac / 4.f, qci[k] / dtcld);
+                    const float vt2s = C->pvts * rslopeb * denfac[k];
+                    const float acrfac = 2.f * rslope3 + 2.f * diameter * rslope2 + diameter * diameter * rslope;
+                    pacr = w3_min(C->pi * qci[k] * eacrs * W3_n0s * n0sfac * fabsf(vt2s - vt2i) * acrfac / 4.f, qci[k] / dtcld);
                 }
                 if (qci[k] > 0.f) {
-                    const float xmi = den[k] * qci[k] / xni[k];
+                    const float xmi = den[k] * qci[k] / xni;
                     const float diameter = W3_dicon * W3_SQRT(xmi);
-                    pisd[k] = 4.f * diameter * xni[k] * (rh[k] - 1.f) / work1[k];
-                    if (pisd[k] < 0.f) { pisd[k] = w3_max(pisd[k], satdt / 2); pisd[k] = w3_max(pisd[k], -qci[k] / dtcld); }
-                    else pisd[k] = w3_min(pisd[k], satdt / 2);
-                    if (fabsf(pisd[k]) >= fabsf(satdt)) ifsat = 1;
+                    pisd = 4.f * diameter * xni * (rh[k] - 1.f) / w1;
+                    if (pisd < 0.f) { pisd = w3_max(pisd, satdt / 2); pisd = w3_max(pisd, -qci[k] / dtcld); }
+                    else pisd = w3_min(pisd, satdt / 2);
+                    if (fabsf(pisd) >= fabsf(satdt)) ifsat = 1;
                 }
                 if (qrs[k] > 0.f && ifsat != 1) {
-                    const float coeres = rslope2[k] * W3_SQRT(rslope[k] * rslopeb[k]);
-                    pres[k] = (rh[k] - 1.f) * n0sfac[k] * (C->precs1 * rslope2[k] + C->precs2 * work2[k] * coeres) / work1[k];
-                    const float supice = satdt - pisd[k];
-                    if (pres[k] < 0.f) { pres[k] = w3_max(pres[k], -qrs[k] / dtcld); pres[k] = w3_max(w3_max(pres[k], satdt / 2), supice); }
-                    else pres[k] = w3_min(w3_min(pres[k], satdt / 2), supice);
-                    if (fabsf(pisd[k] + pres[k]) >= fabsf(satdt)) ifsat = 1;
+                    const float coeres = rslope2 * W3_SQRT(rslope * rslopeb);
+                    pres = (rh[k] - 1.f) * n0sfac * (C->precs1 * rslope2 + C->precs2 * w2 * coeres) / w1;
+                    const float supice = satdt - pisd;
+                    if (pres < 0.f) { pres = w3_max(pres, -qrs[k] / dtcld); pres = w3_max(w3_max(pres, satdt / 2), supice); }
+                    else pres = w3_min(w3_min(pres, satdt / 2), supice);
+                    if (fabsf(pisd + pres) >= fabsf(satdt)) ifsat = 1;
                 }
                 if (supsat > 0 && ifsat != 1) {
-                    const float supice = satdt - pisd[k] - pres[k];
+                    const float supice = satdt - pisd - pres;
                     const float xni0 = 1.e3f * W3_EXP(0.1f * supcol);
                     const float roqi0 = 4.92e-11f * W3_EXP(W3_LOG(xni0) * (1.33f));
-                    pgen[k] = w3_max(0.f, (roqi0 / den[k] - w3_max(qci[k], 0.f)) / dtcld);
-                    pgen[k] = w3_min(w3_min(pgen[k], satdt), supice);
+                    pgen = w3_max(0.f, (roqi0 / den[k] - w3_max(qci[k], 0.f)) / dtcld);
+                    pgen = w3_min(w3_min(pgen, satdt), supice);
                 }
                 if (qci[k] > 0.f) {
                     const float qimax = C->roqimax / den[k];
-                    paut[k] = w3_max(0.f, (qci[k] - qimax) / dtcld);
+                    paut = w3_max(0.f, (qci[k] - qimax) / dtcld);
                 }
             }
-        }
-        /* ---- conservation + update (:737-770) ---- */
-        for (int k = 0; k < km; ++k) {
+            /* conservation + update (:737-770) */
             const float qciik = w3_max(qmin, qci[k]);
-            const float delqci = (paut[k] + pacr[k] - pgen[k] - pisd[k]) * dtcld;
+            const float delqci = (paut + pacr - pgen - pisd) * dtcld;
             if (delqci >= qciik) {
                 const float facqci = qciik / delqci;
-                paut[k] = paut[k] * facqci; pacr[k] = pacr[k] * facqci; pgen[k] = pgen[k] * facqci; pisd[k] = pisd[k] * facqci;
+                paut = paut * facqci; pacr = pacr * facqci; pgen = pgen * facqci; pisd = pisd * facqci;
             }
             const float qik = w3_max(qmin, q[k]);
-            const float delq = (pres[k] + pgen[k] + pisd[k]) * dtcld;
+            const float delq = (pres + pgen + pisd) * dtcld;
             if (delq >= qik) {
                 const float facq = qik / delq;
-                pres[k] = pres[k] * facq; pgen[k] = pgen[k] * facq; pisd[k] = pisd[k] * facq;
+                pres = pres * facq; pgen = pgen * facq; pisd = pisd * facq;
             }
-            work2[k] = -pres[k] - pgen[k] - pisd[k];
-            q[k] = q[k] + work2[k] * dtcld;
-            qci[k] = w3_max(qci[k] - (paut[k] + pacr[k] - pgen[k] - pisd[k]) * dtcld, 0.f);
-            qrs[k] = w3_max(qrs[k] + (paut[k] + pacr[k] + pres[k]) * dtcld, 0.f);
-            if (t[k] < t0c) t[k] = t[k] - xls * work2[k] / cpm[k] * dtcld;
-            else            t[k] = t[k] - xl[k] * work2[k] / cpm[k] * dtcld;
-        }
-        /* ---- condensation (:771-808) ---- */
-        for (int k = 0; k < km; ++k) {
+            w2 = -pres - pgen - pisd;
+            q[k] = q[k] + w2 * dtcld;
+            qci[k] = w3_max(qci[k] - (paut + pacr - pgen - pisd) * dtcld, 0.f);
+            qrs[k] = w3_max(qrs[k] + (paut + pacr + pres) * dtcld, 0.f);
+            if (t[k] < t0c) t[k] = t[k] - xls * w2 / cpm[k] * dtcld;
+            else            t[k] = t[k] - xl[k] * w2 / cpm[k] * dtcld;
+            /* condensation (:781-808) */
             const float tr = ttp / t[k];
-            qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xa))) * W3_EXP(xb * (1.f - tr));
-            qs[k] = w3_min(qs[k], 0.99f * p[k]);
-            qs[k] = ep2 * qs[k] / (p[k] - qs[k]);
-            qs[k] = w3_max(qs[k], qmin);
-            denfac[k] = W3_SQRT(den0 / den[k]);
-        }
-        for (int k = 0; k < km; ++k) {
-            work1[k] = W3_CONDEN(t[k], q[k], qs[k], xl[k], cpm[k]);
-            work2[k] = qci[k] + work1[k];
-            pcon[k] = w3_min(w3_max(work1[k], 0.f), w3_max(q[k], 0.f)) / dtcld;
-            if (qci[k] > 0.f && work1[k] < 0.f && t[k] > t0c) pcon[k] = w3_max(work1[k], -qci[k]) / dtcld;
-            q[k] = q[k] - pcon[k] * dtcld;
-            qci[k] = w3_max(qci[k] + pcon[k] * dtcld, 0.f);
-            t[k] = t[k] + pcon[k] * xl[k] / cpm[k] * dtcld;
-        }
-        for (int k = 0; k < km; ++k) {                                                                    /* :809-815 */
-            if (qci[k] <= qmin) qci[k] = 0.0f;
+            float qsw = psat * (W3_EXP(W3_LOG(tr) * (xa))) * W3_EXP(xb * (1.f - tr));
+            qsw = w3_min(qsw, 0.99f * p[k]);
+            qsw = ep2 * qsw / (p[k] - qsw);
+            qsw = w3_max(qsw, qmin);
+            w1 = W3_CONDEN(t[k], q[k], qsw, xl[k], cpm[k]);
+            pcon = w3_min(w3_max(w1, 0.f), w3_max(q[k], 0.f)) / dtcld;
+            if (qci[k] > 0.f && w1 < 0.f && t[k] > t0c) pcon = w3_max(w1, -qci[k]) / dtcld;
+            q[k] = q[k] - pcon * dtcld;
+            qci[k] = w3_max(qci[k] + pcon * dtcld, 0.f);
+            t[k] = t[k] + pcon * xl[k] / cpm[k] * dtcld;
+            if (qci[k] <= qmin) qci[k] = 0.0f;                                                            /* :809-815 */
             if (qrs[k] <= W3_qcrmin) qrs[k] = 0.0f;
         }
     }
-    (void)tstepsnow; (void)ep2;
+    (void)tstepsnow;
 }
-
 
 #ifdef W3_HOST_INIT
 /* wsm3init (:951-1006) with the arguments of mp_driver.f90:105: REAL(4) arithmetic in the reference's order, libm for
