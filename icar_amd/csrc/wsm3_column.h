@@ -182,214 +182,250 @@ W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, cons
     return precip;
 }
 
-/* wsm32D (:218-903) for one column.  t, q, qci, qrs in/out; rain..sr are this column's entries of the 2-D arrays.
- * The reference's per-level work arrays that never cross levels (the rates, the slopes, the condensation) are scalars of one
- * fused level loop here: every statement still sees exactly the values it sees in the reference. */
+/* ---- wsm32D (:218-903) in three pieces.  Everything except the two falls, the melting level and the surface flux is
+ * level-local, so the pieces are: per level before the minor loops, per level at the top of a minor loop, per COLUMN (fall,
+ * melt, surface), per level (rates, update, condensation).  wsm3_column() strings them together for one column; the device
+ * runs the level pieces one thread per cell and the column piece one thread per column. ---- */
+typedef struct w3_sat { float ttp, xa, xb, xai, xbi; } w3_sat;
+
+W3_FN w3_sat wsm3_sat_coeffs(const wsm3_args *A)                                                          /* :432-441, :771-780 */
+{
+    w3_sat S;
+    const float cvap = A->cpv, hvap = A->xlv0, hsub = A->xls;
+    S.ttp = A->t0c + 0.01f;
+    const float dldt = cvap - A->cliq; S.xa = -dldt / A->rv; S.xb = S.xa + hvap / (A->rv * S.ttp);
+    const float dldti = cvap - A->cice; S.xai = -dldti / A->rv; S.xbi = S.xai + hsub / (A->rv * S.ttp);
+    return S;
+}
+
+W3_FN float wsm3_dtcld(const wsm3_args *A, int *loops)                                                    /* :418-420 */
+{
+    long lp = lroundf(A->delt / W3_dtcldcr);
+    *loops = lp > 1 ? (int)lp : 1;
+    float dtcld = A->delt / (float)*loops;
+    if (A->delt <= W3_dtcldcr) dtcld = A->delt;
+    return dtcld;
+}
+
+#define W3_CPMCAL(x) (A->cpd * (1.f - w3_max(x, A->qmin)) + w3_max(x, A->qmin) * A->cpv)
+#define W3_XLCAL(x) (A->xlv0 - C->xlv1 * ((x) - A->t0c))
+#define W3_DIFFUS(x, y) (8.794e-5f * W3_EXP(W3_LOG(x) * (1.81f)) / (y))
+#define W3_VISCOS(x, y) (1.496e-6f * ((x) * W3_SQRT(x)) / ((x) + 120.f) / (y))
+#define W3_XKA(x, y) (1.414e3f * W3_VISCOS(x, y) * (y))
+#define W3_DIFFAC(a, b, c, d, e) ((d) * (a) * (a) / (W3_XKA(c, d) * A->rv * (c) * (c)) + 1.f / ((e) * W3_DIFFUS(c, b)))
+#define W3_VENFAC(a, b, c) (W3_EXP(W3_LOG((W3_VISCOS(b, c) / W3_DIFFUS(b, a))) * ((.3333333f))) / W3_SQRT(W3_VISCOS(b, c)) * W3_SQRT(W3_SQRT(A->den0 / (c))))
+#define W3_CONDEN(a, b, c, d, e) ((w3_max(b, A->qmin) - (c)) / (1.f + (d) * (d) / (A->rv * (e)) * (c) / ((a) * (a))))
+#define W3_XNI(den_, qci_) w3_min(w3_max(5.38e7f * W3_EXP(W3_LOG(((den_) * w3_max(qci_, A->qmin))) * (0.75f)), 1.e3f), 1.e6f)
+
+/* once per call and level: clamp (:393-398), cpm and xl (:400-405) */
+W3_FN void wsm3_level_init(const wsm3_consts *C, const wsm3_args *A, float q, float t, float *qci, float *qrs, float *cpm, float *xl)
+{
+    *qci = w3_max(*qci, 0.0f); *qrs = w3_max(*qrs, 0.0f);
+    *cpm = W3_CPMCAL(q); *xl = W3_XLCAL(t);
+}
+
+/* top of a minor loop, per level (:425-457, :480-484, :506-520): denfac, qs, rh, the terminal velocities and den*q of rain/snow
+ * and of cloud ice.  (den, qci and t do not change between here and the ice fall, so its velocity is evaluated here.) */
+W3_FN void wsm3_level_prep(const wsm3_consts *C, const wsm3_args *A, const w3_sat *S, float t, float q, float qci, float qrs, float den,
+                           float p, float *denfac, float *qs, float *rh, float *vt, float *denqrs, float *vti, float *denqci)
+{
+    float tv = 1.0f / den;
+    tv = tv * A->den0;
+    *denfac = W3_SQRT(tv);
+    const float tr = S->ttp / t;
+    float qs_;
+    if (t < S->ttp) qs_ = A->psat * (W3_EXP(W3_LOG(tr) * (S->xai))) * W3_EXP(S->xbi * (1.f - tr));
+    else            qs_ = A->psat * (W3_EXP(W3_LOG(tr) * (S->xa))) * W3_EXP(S->xb * (1.f - tr));
+    /* qs0 (:450-451) is computed but never used */
+    qs_ = w3_min(qs_, 0.99f * p);
+    qs_ = A->ep2 * qs_ / (p - qs_);
+    qs_ = w3_max(qs_, A->qmin);
+    *qs = qs_;
+    *rh = w3_max(q / qs_, A->qmin);
+    float r1, r2, r3, r4;
+    *vt = wsm3_slope1(C, qrs, den, *denfac, t, &r1, &r2, &r3, &r4);
+    *denqrs = den * qrs;
+    if (t < A->t0c && qci > 0.f) {
+        const float xmi = den * qci / W3_XNI(den, qci);
+        const float diameter = w3_max(W3_dicon * W3_SQRT(xmi), 1.e-25f);
+        *vti = 1.49e4f * W3_EXP(W3_LOG(diameter) * (1.31f));
+    } else *vti = 0.f;
+    *denqci = den * qci;
+}
+
+/* per column (:485-598): fall of rain/snow and of cloud ice, melting/freezing at the 0 C level, surface precipitation.
+ * denqrs / denqci are work arrays (in: den*q, out: the fallen field); rain, snow accumulate this call's surface flux. */
+W3_FN void wsm3_column_fall(const wsm3_consts *C, const wsm3_args *A, int km, float dtcld, float *t, float *qci, float *qrs, const float *w,
+                            const float *den, const float *delz, const float *denfac, const float *cpm, const float *vt, float *denqrs,
+                            const float *vti, float *denqci, float *rain, float *rainncv, float *snow, float *snowncv, float *sr)
+{
+    const float t0c = A->t0c, xlf0 = A->xlf0, denr = A->denr;
+    const float delqrs = wsm3_nislfv_plm(C, km, den, denfac, t, delz, vt, denqrs, dtcld, 1);
+    for (int k = 0; k < km; ++k) qrs[k] = w3_max(denqrs[k] / den[k], 0.f);
+    const float fall1 = delqrs / delz[0] / dtcld;                 /* fall(i,1); fall(i,k>1) = denqrs*vt/delz is formed where it is read */
+    const float delqi = wsm3_nislfv_plm(C, km, den, denfac, t, delz, vti, denqci, dtcld, 0);
+    for (int k = 0; k < km; ++k) qci[k] = w3_max(denqci[k] / den[k], 0.f);
+    const float fallc1 = delqi / delz[0] / dtcld;
+    /* melting / freezing at the 0 C level (:532-569) */
+    int mstep = 0;
+    for (int k = 1; k <= km; ++k) if (t[k - 1] >= t0c) mstep = k;
+    int kwork2 = mstep, kwork1 = mstep;
+    if (mstep != 0) { if (w[mstep - 1] > 0.f) kwork1 = mstep + 1; }
+    {
+        const int k = kwork1, kk = kwork2;
+        if (k * kk >= 1 && k <= km) {
+            const float qrsci = qrs[k - 1] + qci[k - 1];
+            const float fallkk = (kk == 1) ? fall1 : denqrs[kk - 1] * vt[kk - 1] / delz[kk - 1];
+            if (qrsci > 0.f || fallkk > 0.f) {
+                const float frzmlt = w3_min(w3_max(-w[k - 1] * qrsci / delz[k - 1], -qrsci / dtcld), qrsci / dtcld);
+                const float snomlt = w3_min(w3_max(fallkk / den[kk - 1], -qrs[k - 1] / dtcld), qrs[k - 1] / dtcld);
+                if (k == kk) t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * (frzmlt + snomlt) * dtcld;
+                else {
+                    t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * frzmlt * dtcld;
+                    t[kk - 1] = t[kk - 1] - xlf0 / cpm[kk - 1] * snomlt * dtcld;
+                }
+            }
+        }
+    }
+    /* surface precipitation (:570-598) */
+    float fallsum = fall1, fallsum_qsi = 0.f;
+    if ((t0c - t[0]) > 0) { fallsum = fallsum + fallc1; fallsum_qsi = fall1 + fallc1; }
+    if (fallsum > 0.f) {
+        *rainncv = fallsum * delz[0] / denr * dtcld * 1000.f + *rainncv;
+        *rain = fallsum * delz[0] / denr * dtcld * 1000.f + *rain;
+    }
+    if (fallsum_qsi > 0.f) {
+        *snowncv = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + *snowncv;
+        *snow = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + *snow;
+    }
+    if (fallsum > 0.f) *sr = *snowncv / (*rainncv + 1.e-12f);
+}
+
+/* per level: rates (:599-736), conservation + update (:737-770), condensation (:771-815) */
+W3_FN void wsm3_level_rates(const wsm3_consts *C, const wsm3_args *A, const w3_sat *S, float dtcld, float *t_, float *q_, float *qci_, float *qrs_,
+                            float den, float p, float denfac, float qs, float rh, float cpm, float xl)
+{
+    const float t0c = A->t0c, qmin = A->qmin, xls = A->xls;
+    float t = *t_, q = *q_, qci = *qci_, qrs = *qrs_;
+    float rslope, rslopeb, rslope2, rslope3;
+    (void)wsm3_slope1(C, qrs, den, denfac, t, &rslope, &rslopeb, &rslope2, &rslope3);
+    float w1, w2;
+    if (t >= t0c) w1 = W3_DIFFAC(xl, p, t, den, qs);
+    else          w1 = W3_DIFFAC(xls, p, t, den, qs);
+    w2 = W3_VENFAC(p, t, den);
+    float pres = 0.f, paut = 0.f, pacr = 0.f, pgen = 0.f, pisd = 0.f, pcon;
+    const float supsat = w3_max(q, qmin) - qs;
+    const float satdt = supsat / dtcld;
+    if (t >= t0c) {
+        /* warm rain (:622-645) */
+        if (qci > C->qc0) {
+            paut = C->qck1 * W3_EXP(W3_LOG(qci) * ((7.f / 3.f)));
+            paut = w3_min(paut, qci / dtcld);
+        }
+        if (qrs > W3_qcrmin && qci > qmin) pacr = w3_min(C->pacrr * rslope3 * rslopeb * qci * denfac, qci / dtcld);
+        if (qrs > 0.f) {
+            const float coeres = rslope2 * W3_SQRT(rslope * rslopeb);
+            pres = (rh - 1.f) * (C->precr1 * rslope2 + C->precr2 * w2 * coeres) / w1;
+            if (pres < 0.f) { pres = w3_max(pres, -qrs / dtcld); pres = w3_max(pres, satdt / 2); }
+            else pres = w3_min(pres, satdt / 2);
+        }
+    } else {
+        /* cold rain (:646-735) */
+        const float supcol = t0c - t;
+        const float n0sfac = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
+        int ifsat = 0;
+        const float xni = W3_XNI(den, qci);
+        const float eacrs = W3_EXP(0.07f * (-supcol));
+        if (qrs > W3_qcrmin && qci > qmin) {
+            const float xmi = den * qci / xni;
+            const float diameter = w3_min(W3_dicon * W3_SQRT(xmi), W3_dimax);
+            const float vt2i = 1.49e4f * W3_POW(diameter, 1.31f);
+            const float vt2s = C->pvts * rslopeb * denfac;
+            const float acrfac = 2.f * rslope3 + 2.f * diameter * rslope2 + diameter * diameter * rslope;
+            pacr = w3_min(C->pi * qci * eacrs * W3_n0s * n0sfac * fabsf(vt2s - vt2i) * acrfac / 4.f, qci / dtcld);
+        }
+        if (qci > 0.f) {
+            const float xmi = den * qci / xni;
+            const float diameter = W3_dicon * W3_SQRT(xmi);
+            pisd = 4.f * diameter * xni * (rh - 1.f) / w1;
+            if (pisd < 0.f) { pisd = w3_max(pisd, satdt / 2); pisd = w3_max(pisd, -qci / dtcld); }
+            else pisd = w3_min(pisd, satdt / 2);
+            if (fabsf(pisd) >= fabsf(satdt)) ifsat = 1;
+        }
+        if (qrs > 0.f && ifsat != 1) {
+            const float coeres = rslope2 * W3_SQRT(rslope * rslopeb);
+            pres = (rh - 1.f) * n0sfac * (C->precs1 * rslope2 + C->precs2 * w2 * coeres) / w1;
+            const float supice = satdt - pisd;
+            if (pres < 0.f) { pres = w3_max(pres, -qrs / dtcld); pres = w3_max(w3_max(pres, satdt / 2), supice); }
+            else pres = w3_min(w3_min(pres, satdt / 2), supice);
+            if (fabsf(pisd + pres) >= fabsf(satdt)) ifsat = 1;
+        }
+        if (supsat > 0 && ifsat != 1) {
+            const float supice = satdt - pisd - pres;
+            const float xni0 = 1.e3f * W3_EXP(0.1f * supcol);
+            const float roqi0 = 4.92e-11f * W3_EXP(W3_LOG(xni0) * (1.33f));
+            pgen = w3_max(0.f, (roqi0 / den - w3_max(qci, 0.f)) / dtcld);
+            pgen = w3_min(w3_min(pgen, satdt), supice);
+        }
+        if (qci > 0.f) {
+            const float qimax = C->roqimax / den;
+            paut = w3_max(0.f, (qci - qimax) / dtcld);
+        }
+    }
+    /* conservation + update (:737-770) */
+    const float qciik = w3_max(qmin, qci);
+    const float delqci = (paut + pacr - pgen - pisd) * dtcld;
+    if (delqci >= qciik) {
+        const float facqci = qciik / delqci;
+        paut = paut * facqci; pacr = pacr * facqci; pgen = pgen * facqci; pisd = pisd * facqci;
+    }
+    const float qik = w3_max(qmin, q);
+    const float delq = (pres + pgen + pisd) * dtcld;
+    if (delq >= qik) {
+        const float facq = qik / delq;
+        pres = pres * facq; pgen = pgen * facq; pisd = pisd * facq;
+    }
+    w2 = -pres - pgen - pisd;
+    q = q + w2 * dtcld;
+    qci = w3_max(qci - (paut + pacr - pgen - pisd) * dtcld, 0.f);
+    qrs = w3_max(qrs + (paut + pacr + pres) * dtcld, 0.f);
+    if (t < t0c) t = t - xls * w2 / cpm * dtcld;
+    else         t = t - xl * w2 / cpm * dtcld;
+    /* condensation (:781-808) */
+    const float tr = S->ttp / t;
+    float qsw = A->psat * (W3_EXP(W3_LOG(tr) * (S->xa))) * W3_EXP(S->xb * (1.f - tr));
+    qsw = w3_min(qsw, 0.99f * p);
+    qsw = A->ep2 * qsw / (p - qsw);
+    qsw = w3_max(qsw, qmin);
+    w1 = W3_CONDEN(t, q, qsw, xl, cpm);
+    pcon = w3_min(w3_max(w1, 0.f), w3_max(q, 0.f)) / dtcld;
+    if (qci > 0.f && w1 < 0.f && t > t0c) pcon = w3_max(w1, -qci) / dtcld;
+    q = q - pcon * dtcld;
+    qci = w3_max(qci + pcon * dtcld, 0.f);
+    t = t + pcon * xl / cpm * dtcld;
+    if (qci <= qmin) qci = 0.0f;                                                                          /* :809-815 */
+    if (qrs <= W3_qcrmin) qrs = 0.0f;
+    *t_ = t; *q_ = q; *qci_ = qci; *qrs_ = qrs;
+}
+
+/* the whole of wsm32D for one column */
 W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *t, float *q, float *qci, float *qrs, const float *w,
                        const float *den, const float *p, const float *delz, float *rain, float *rainncv, float *snow, float *snowncv,
                        float *sr)
 {
-    const float delt = A->delt, cpd = A->cpd, cpv = A->cpv, rv = A->rv, t0c = A->t0c, ep2 = A->ep2, qmin = A->qmin, xls = A->xls,
-                xlv0 = A->xlv0, xlf0 = A->xlf0, den0 = A->den0, denr = A->denr, cliq = A->cliq, cice = A->cice, psat = A->psat;
-    float rh[W3_MAXK], qs[W3_MAXK], denfac[W3_MAXK], fall[W3_MAXK], xl[W3_MAXK], cpm[W3_MAXK], work1[W3_MAXK], denq[W3_MAXK];
-    float tstepsnow = 0.f;
-#define W3_CPMCAL(x) (cpd * (1.f - w3_max(x, qmin)) + w3_max(x, qmin) * cpv)
-#define W3_XLCAL(x) (xlv0 - C->xlv1 * ((x) - t0c))
-#define W3_DIFFUS(x, y) (8.794e-5f * W3_EXP(W3_LOG(x) * (1.81f)) / (y))
-#define W3_VISCOS(x, y) (1.496e-6f * ((x) * W3_SQRT(x)) / ((x) + 120.f) / (y))
-#define W3_XKA(x, y) (1.414e3f * W3_VISCOS(x, y) * (y))
-#define W3_DIFFAC(a, b, c, d, e) ((d) * (a) * (a) / (W3_XKA(c, d) * rv * (c) * (c)) + 1.f / ((e) * W3_DIFFUS(c, b)))
-#define W3_VENFAC(a, b, c) (W3_EXP(W3_LOG((W3_VISCOS(b, c) / W3_DIFFUS(b, a))) * ((.3333333f))) / W3_SQRT(W3_VISCOS(b, c)) * W3_SQRT(W3_SQRT(den0 / (c))))
-#define W3_CONDEN(a, b, c, d, e) ((w3_max(b, qmin) - (c)) / (1.f + (d) * (d) / (rv * (e)) * (c) / ((a) * (a))))
-#define W3_XNI(k) w3_min(w3_max(5.38e7f * W3_EXP(W3_LOG((den[k] * w3_max(qci[k], qmin))) * (0.75f)), 1.e3f), 1.e6f)
-    for (int k = 0; k < km; ++k) {
-        qci[k] = w3_max(qci[k], 0.0f); qrs[k] = w3_max(qrs[k], 0.0f);                                      /* :393-398 */
-        cpm[k] = W3_CPMCAL(q[k]); xl[k] = W3_XLCAL(t[k]);                                                 /* :400-405 */
-    }
+    float rh[W3_MAXK], qs[W3_MAXK], denfac[W3_MAXK], xl[W3_MAXK], cpm[W3_MAXK], vt[W3_MAXK], denqrs[W3_MAXK], vti[W3_MAXK], denqci[W3_MAXK];
+    for (int k = 0; k < km; ++k) wsm3_level_init(C, A, q[k], t[k], &qci[k], &qrs[k], &cpm[k], &xl[k]);
     *rainncv = 0.f; *snowncv = 0.f; *sr = 0.f;                                                            /* :412-417 */
-    long lp = lroundf(delt / W3_dtcldcr);
-    const int loops = lp > 1 ? (int)lp : 1;                                                               /* :418 */
-    float dtcld = delt / (float)loops;
-    if (delt <= W3_dtcldcr) dtcld = delt;
-    const float cvap = cpv, hvap = xlv0, hsub = xls, ttp = t0c + 0.01f;                                   /* :432-441, :771-780 */
-    const float dldt = cvap - cliq, xa = -dldt / rv, xb = xa + hvap / (rv * ttp);
-    const float dldti = cvap - cice, xai = -dldti / rv, xbi = xai + hsub / (rv * ttp);
+    int loops;
+    const float dtcld = wsm3_dtcld(A, &loops);
+    const w3_sat S = wsm3_sat_coeffs(A);
     for (int loop = 1; loop <= loops; ++loop) {
-        /* ---- state of this minor step (:425-479) and the terminal velocity of rain / snow (:480-484) ---- */
-        for (int k = 0; k < km; ++k) {
-            float tv = 1.0f / den[k];
-            tv = tv * den0;
-            denfac[k] = W3_SQRT(tv);
-            const float tr = ttp / t[k];
-            if (t[k] < ttp) qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xai))) * W3_EXP(xbi * (1.f - tr));
-            else            qs[k] = psat * (W3_EXP(W3_LOG(tr) * (xa))) * W3_EXP(xb * (1.f - tr));
-            /* qs0 (:450-451) is computed but never used */
-            qs[k] = w3_min(qs[k], 0.99f * p[k]);
-            qs[k] = ep2 * qs[k] / (p[k] - qs[k]);
-            qs[k] = w3_max(qs[k], qmin);
-            rh[k] = w3_max(q[k] / qs[k], qmin);
-            float r1, r2, r3, r4;
-            work1[k] = wsm3_slope1(C, qrs[k], den[k], denfac[k], t[k], &r1, &r2, &r3, &r4);
-            denq[k] = den[k] * qrs[k];
-        }
-        /* ---- fall of rain / snow (:485-505) ---- */
-        const float delqrs = wsm3_nislfv_plm(C, km, den, denfac, t, delz, work1, denq, dtcld, 1);
-        for (int k = 0; k < km; ++k) {
-            qrs[k] = w3_max(denq[k] / den[k], 0.f);
-            fall[k] = denq[k] * work1[k] / delz[k];
-        }
-        fall[0] = delqrs / delz[0] / dtcld;
-        /* ---- fall of cloud ice (:506-531); xni (:474-479) is evaluated where it is used: den and qci have not changed ---- */
-        for (int k = km - 1; k >= 0; --k) {
-            if (t[k] < t0c && qci[k] > 0.f) {
-                const float xmi = den[k] * qci[k] / W3_XNI(k);
-                const float diameter = w3_max(W3_dicon * W3_SQRT(xmi), 1.e-25f);
-                work1[k] = 1.49e4f * W3_EXP(W3_LOG(diameter) * (1.31f));
-            } else work1[k] = 0.f;
-            denq[k] = den[k] * qci[k];
-        }
-        const float delqi = wsm3_nislfv_plm(C, km, den, denfac, t, delz, work1, denq, dtcld, 0);
-        for (int k = 0; k < km; ++k) qci[k] = w3_max(denq[k] / den[k], 0.f);
-        const float fallc1 = delqi / delz[0] / dtcld;
-        /* ---- melting / freezing at the 0 C level (:532-569) ---- */
-        int mstep = 0;
-        for (int k = 1; k <= km; ++k) if (t[k - 1] >= t0c) mstep = k;
-        int kwork2 = mstep, kwork1 = mstep;
-        if (mstep != 0) { if (w[mstep - 1] > 0.f) kwork1 = mstep + 1; }
-        {
-            const int k = kwork1, kk = kwork2;
-            if (k * kk >= 1 && k <= km) {
-                const float qrsci = qrs[k - 1] + qci[k - 1];
-                if (qrsci > 0.f || fall[kk - 1] > 0.f) {
-                    const float frzmlt = w3_min(w3_max(-w[k - 1] * qrsci / delz[k - 1], -qrsci / dtcld), qrsci / dtcld);
-                    const float snomlt = w3_min(w3_max(fall[kk - 1] / den[kk - 1], -qrs[k - 1] / dtcld), qrs[k - 1] / dtcld);
-                    if (k == kk) t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * (frzmlt + snomlt) * dtcld;
-                    else {
-                        t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * frzmlt * dtcld;
-                        t[kk - 1] = t[kk - 1] - xlf0 / cpm[kk - 1] * snomlt * dtcld;
-                    }
-                }
-            }
-        }
-        /* ---- surface precipitation (:570-598) ---- */
-        {
-            float fallsum = fall[0], fallsum_qsi = 0.f;
-            if ((t0c - t[0]) > 0) { fallsum = fallsum + fallc1; fallsum_qsi = fall[0] + fallc1; }
-            if (fallsum > 0.f) {
-                *rainncv = fallsum * delz[0] / denr * dtcld * 1000.f + *rainncv;
-                *rain = fallsum * delz[0] / denr * dtcld * 1000.f + *rain;
-            }
-            if (fallsum_qsi > 0.f) {
-                tstepsnow = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + tstepsnow;
-                *snowncv = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + *snowncv;
-                *snow = fallsum_qsi * delz[0] / denr * dtcld * 1000.f + *snow;
-            }
-            if (fallsum > 0.f) *sr = *snowncv / (*rainncv + 1.e-12f);
-        }
-        /* ---- per level: rates (:599-736), conservation + update (:737-770), condensation (:771-815) ---- */
-        for (int k = 0; k < km; ++k) {
-            float rslope, rslopeb, rslope2, rslope3;
-            (void)wsm3_slope1(C, qrs[k], den[k], denfac[k], t[k], &rslope, &rslopeb, &rslope2, &rslope3);
-            float w1, w2;
-            if (t[k] >= t0c) w1 = W3_DIFFAC(xl[k], p[k], t[k], den[k], qs[k]);
-            else             w1 = W3_DIFFAC(xls, p[k], t[k], den[k], qs[k]);
-            w2 = W3_VENFAC(p[k], t[k], den[k]);
-            float pres = 0.f, paut = 0.f, pacr = 0.f, pgen = 0.f, pisd = 0.f, pcon;
-            const float supsat = w3_max(q[k], qmin) - qs[k];
-            const float satdt = supsat / dtcld;
-            if (t[k] >= t0c) {
-                /* warm rain (:622-645) */
-                if (qci[k] > C->qc0) {
-                    paut = C->qck1 * W3_EXP(W3_LOG(qci[k]) * ((7.f / 3.f)));
-                    paut = w3_min(paut, qci[k] / dtcld);
-                }
-                if (qrs[k] > W3_qcrmin && qci[k] > qmin)
-                    pacr = w3_min(C->pacrr * rslope3 * rslopeb * qci[k] * denfac[k], qci[k] / dtcld);
-                if (qrs[k] > 0.f) {
-                    const float coeres = rslope2 * W3_SQRT(rslope * rslopeb);
-                    pres = (rh[k] - 1.f) * (C->precr1 * rslope2 + C->precr2 * w2 * coeres) / w1;
-                    if (pres < 0.f) { pres = w3_max(pres, -qrs[k] / dtcld); pres = w3_max(pres, satdt / 2); }
-                    else pres = w3_min(pres, satdt / 2);
-                }
-            } else {
-                /* cold rain (:646-735) */
-                const float supcol = t0c - t[k];
-                const float n0sfac = w3_max(w3_min(W3_EXP(W3_alpha * supcol), W3_n0smax / W3_n0s), 1.f);
-                int ifsat = 0;
-                const float xni = W3_XNI(k);
-                const float eacrs = W3_EXP(0.07f * (-supcol));
-                if (qrs[k] > W3_qcrmin && qci[k] > qmin) {
-                    const float xmi = den[k] * qci[k] / xni;
-                    const float diameter = w3_min(W3_dicon * W3_SQRT(xmi), W3_dimax);
-                    const float vt2i = 1.49e4f * W3_POW(diameter, 1.31f);
-                    const float vt2s = C->pvts * rslopeb * denfac[k];
-                    const float acrfac = 2.f * rslope3 + 2.f * diameter * rslope2 + diameter * diameter * rslope;
-                    pacr = w3_min(C->pi * qci[k] * eacrs * W3_n0s * n0sfac * fabsf(vt2s - vt2i) * acrfac / 4.f, qci[k] / dtcld);
-                }
-                if (qci[k] > 0.f) {
-                    const float xmi = den[k] * qci[k] / xni;
-                    const float diameter = W3_dicon * W3_SQRT(xmi);
-                    pisd = 4.f * diameter * xni * (rh[k] - 1.f) / w1;
-                    if (pisd < 0.f) { pisd = w3_max(pisd, satdt / 2); pisd = w3_max(pisd, -qci[k] / dtcld); }
-                    else pisd = w3_min(pisd, satdt / 2);
-                    if (fabsf(pisd) >= fabsf(satdt)) ifsat = 1;
-                }
-                if (qrs[k] > 0.f && ifsat != 1) {
-                    const float coeres = rslope2 * W3_SQRT(rslope * rslopeb);
-                    pres = (rh[k] - 1.f) * n0sfac * (C->precs1 * rslope2 + C->precs2 * w2 * coeres) / w1;
-                    const float supice = satdt - pisd;
-                    if (pres < 0.f) { pres = w3_max(pres, -qrs[k] / dtcld); pres = w3_max(w3_max(pres, satdt / 2), supice); }
-                    else pres = w3_min(w3_min(pres, satdt / 2), supice);
-                    if (fabsf(pisd + pres) >= fabsf(satdt)) ifsat = 1;
-                }
-                if (supsat > 0 && ifsat != 1) {
-                    const float supice = satdt - pisd - pres;
-                    const float xni0 = 1.e3f * W3_EXP(0.1f * supcol);
-                    const float roqi0 = 4.92e-11f * W3_EXP(W3_LOG(xni0) * (1.33f));
-                    pgen = w3_max(0.f, (roqi0 / den[k] - w3_max(qci[k], 0.f)) / dtcld);
-                    pgen = w3_min(w3_min(pgen, satdt), supice);
-                }
-                if (qci[k] > 0.f) {
-                    const float qimax = C->roqimax / den[k];
-                    paut = w3_max(0.f, (qci[k] - qimax) / dtcld);
-                }
-            }
-            /* conservation + update (:737-770) */
-            const float qciik = w3_max(qmin, qci[k]);
-            const float delqci = (paut + pacr - pgen - pisd) * dtcld;
-            if (delqci >= qciik) {
-                const float facqci = qciik / delqci;
-                paut = paut * facqci; pacr = pacr * facqci; pgen = pgen * facqci; pisd = pisd * facqci;
-            }
-            const float qik = w3_max(qmin, q[k]);
-            const float delq = (pres + pgen + pisd) * dtcld;
-            if (delq >= qik) {
-                const float facq = qik / delq;
-                pres = pres * facq; pgen = pgen * facq; pisd = pisd * facq;
-            }
-            w2 = -pres - pgen - pisd;
-            q[k] = q[k] + w2 * dtcld;
-            qci[k] = w3_max(qci[k] - (paut + pacr - pgen - pisd) * dtcld, 0.f);
-            qrs[k] = w3_max(qrs[k] + (paut + pacr + pres) * dtcld, 0.f);
-            if (t[k] < t0c) t[k] = t[k] - xls * w2 / cpm[k] * dtcld;
-            else            t[k] = t[k] - xl[k] * w2 / cpm[k] * dtcld;
-            /* condensation (:781-808) */
-            const float tr = ttp / t[k];
-            float qsw = psat * (W3_EXP(W3_LOG(tr) * (xa))) * W3_EXP(xb * (1.f - tr));
-            qsw = w3_min(qsw, 0.99f * p[k]);
-            qsw = ep2 * qsw / (p[k] - qsw);
-            qsw = w3_max(qsw, qmin);
-            w1 = W3_CONDEN(t[k], q[k], qsw, xl[k], cpm[k]);
-            pcon = w3_min(w3_max(w1, 0.f), w3_max(q[k], 0.f)) / dtcld;
-            if (qci[k] > 0.f && w1 < 0.f && t[k] > t0c) pcon = w3_max(w1, -qci[k]) / dtcld;
-            q[k] = q[k] - pcon * dtcld;
-            qci[k] = w3_max(qci[k] + pcon * dtcld, 0.f);
-            t[k] = t[k] + pcon * xl[k] / cpm[k] * dtcld;
-            if (qci[k] <= qmin) qci[k] = 0.0f;                                                            /* :809-815 */
-            if (qrs[k] <= W3_qcrmin) qrs[k] = 0.0f;
-        }
+        for (int k = 0; k < km; ++k)
+            wsm3_level_prep(C, A, &S, t[k], q[k], qci[k], qrs[k], den[k], p[k], &denfac[k], &qs[k], &rh[k], &vt[k], &denqrs[k], &vti[k], &denqci[k]);
+        wsm3_column_fall(C, A, km, dtcld, t, qci, qrs, w, den, delz, denfac, cpm, vt, denqrs, vti, denqci, rain, rainncv, snow, snowncv, sr);
+        for (int k = 0; k < km; ++k)
+            wsm3_level_rates(C, A, &S, dtcld, &t[k], &q[k], &qci[k], &qrs[k], den[k], p[k], denfac[k], qs[k], rh[k], cpm[k], xl[k]);
     }
-    (void)tstepsnow;
 }
 
 #ifdef W3_HOST_INIT
