@@ -43,7 +43,7 @@ __device__ __forceinline__ float w3_powf(float x, float y)
 struct Wsm3State {
     wsm3_consts c; bool ready = false;
     float *t = nullptr, *cpm = nullptr, *xl = nullptr, *denfac = nullptr, *qs = nullptr, *rh = nullptr, *vt = nullptr, *denqrs = nullptr,
-          *vti = nullptr, *denqci = nullptr, *rain = nullptr, *snow = nullptr;
+          *vti = nullptr, *denqci = nullptr, *rain = nullptr, *snow = nullptr, *delq = nullptr;
     size_t n3 = 0;
 };
 
@@ -73,28 +73,35 @@ k_wsm3_prep(Dims d, wsm3_consts C, wsm3_args A, W3Work W, const float *__restric
     W.denfac[c] = denfac; W.qs[c] = qs; W.rh[c] = rh; W.vt[c] = vt; W.denqrs[c] = denqrs; W.vti[c] = vti; W.denqci[c] = denqci;
 }
 
-// per column: fall of rain/snow and cloud ice, melting level, surface flux (this call's REAL(4) sums in W.rain / W.snow)
+// per column and species (blockIdx.z: 0 rain/snow, 1 cloud ice): the semi-Lagrangian fall.  The column arrays are read and
+// written in place (element stride nx, coalesced across the lanes of a wave); only the fall routine's nine work arrays are
+// private.  The two species are independent until the melting level, which doubles the number of (serial) threads.
 __global__ void __launch_bounds__(64)
-k_wsm3_fall(Dims d, wsm3_consts C, wsm3_args A, W3Work W, float *__restrict__ qci, float *__restrict__ qrs, const float *__restrict__ w,
-            const float *__restrict__ den, const float *__restrict__ delz, float dtcld, int i0, int i1, int j0, int k0, int km)
+k_wsm3_fall(Dims d, wsm3_consts C, W3Work W, float *__restrict__ qci, float *__restrict__ qrs, const float *__restrict__ den,
+            const float *__restrict__ delz, float *__restrict__ delq, float dtcld, int i0, int i1, int j0, int k0, int km)
 {
     const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y;
     if (i > i1) return;
-    float t[W3_MAXK], cqci[W3_MAXK], cqrs[W3_MAXK], cw[W3_MAXK], cden[W3_MAXK], cdz[W3_MAXK], cdenfac[W3_MAXK], ccpm[W3_MAXK], cvt[W3_MAXK],
-          cdq[W3_MAXK], cvti[W3_MAXK], cdqi[W3_MAXK];
-    for (int k = 0; k < km; ++k) {
-        const int c = d.idx(i, k0 + k, j);
-        t[k] = W.t[c]; cqci[k] = qci[c]; cqrs[k] = qrs[c]; cw[k] = w[c]; cden[k] = den[c]; cdz[k] = delz[c]; cdenfac[k] = W.denfac[c];
-        ccpm[k] = W.cpm[c]; cvt[k] = W.vt[c]; cdq[k] = W.denqrs[c]; cvti[k] = W.vti[c]; cdqi[k] = W.denqci[c];
-    }
-    const int c2 = i + d.nx * j;
+    const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
+    const bool ice = blockIdx.z == 1;
+    const float r = wsm3_fall_species(&C, km, d.sk, dtcld, W.t + c0, (ice ? qci : qrs) + c0, den + c0, delz + c0, W.denfac + c0,
+                                      (ice ? W.vti : W.vt) + c0, (ice ? W.denqci : W.denqrs) + c0, ice ? 0 : 1);
+    delq[(size_t)blockIdx.z * d.nx * d.ny + c2] = r;
+}
+
+// per column: melting level and surface flux (this call's REAL(4) sums in W.rain / W.snow)
+__global__ void __launch_bounds__(64)
+k_wsm3_melt(Dims d, wsm3_args A, W3Work W, const float *__restrict__ qci, const float *__restrict__ qrs, const float *__restrict__ w,
+            const float *__restrict__ den, const float *__restrict__ delz, const float *__restrict__ delq, float dtcld,
+            int i0, int i1, int j0, int k0, int km)
+{
+    const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y;
+    if (i > i1) return;
+    const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
     float rain = W.rain[c2], snow = W.snow[c2], rainncv = 0.f, snowncv = 0.f, sr = 0.f;   // rainncv / snowncv / sr only feed sr, which ICAR drops
-    wsm3_column_fall(&C, &A, km, dtcld, t, cqci, cqrs, cw, cden, cdz, cdenfac, ccpm, cvt, cdq, cvti, cdqi, &rain, &rainncv, &snow, &snowncv, &sr);
+    wsm3_melt_surface(&A, km, d.sk, dtcld, delq[c2], delq[(size_t)d.nx * d.ny + c2], W.t + c0, qci + c0, qrs + c0, w + c0, den + c0, delz + c0,
+                      W.cpm + c0, W.vt + c0, W.denqrs + c0, &rain, &rainncv, &snow, &snowncv, &sr);
     W.rain[c2] = rain; W.snow[c2] = snow;
-    for (int k = 0; k < km; ++k) {
-        const int c = d.idx(i, k0 + k, j);
-        W.t[c] = t[k]; qci[c] = cqci[k]; qrs[c] = cqrs[k];
-    }
 }
 
 // per cell: rates, update, condensation; LAST: th = t / pii (:171-175)
@@ -129,7 +136,7 @@ void icar_wsm3_free(icar_hip_ctx *c)
 {
     if (!c->wsm3) return;
     float **ps[] = {&c->wsm3->t, &c->wsm3->cpm, &c->wsm3->xl, &c->wsm3->denfac, &c->wsm3->qs, &c->wsm3->rh, &c->wsm3->vt, &c->wsm3->denqrs,
-                    &c->wsm3->vti, &c->wsm3->denqci, &c->wsm3->rain, &c->wsm3->snow};
+                    &c->wsm3->vti, &c->wsm3->denqci, &c->wsm3->rain, &c->wsm3->snow, &c->wsm3->delq};
     for (float **p : ps) if (*p) hipFree(*p);
     delete c->wsm3; c->wsm3 = nullptr;
 }
@@ -161,6 +168,7 @@ int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
         float **p3[] = {&S->t, &S->cpm, &S->xl, &S->denfac, &S->qs, &S->rh, &S->vt, &S->denqrs, &S->vti, &S->denqci};
         for (float **x : p3) HIPCHK(hipMalloc(x, c->n3 * sizeof(float)));
         HIPCHK(hipMalloc(&S->rain, (size_t)c->d.nx * c->d.ny * sizeof(float))); HIPCHK(hipMalloc(&S->snow, (size_t)c->d.nx * c->d.ny * sizeof(float)));
+        HIPCHK(hipMalloc(&S->delq, 2 * (size_t)c->d.nx * c->d.ny * sizeof(float)));
     }
     // what mp_driver.f90:554-585 passes: gravity, cp, cpv, Rd, Rw, 273.15, EP1, EP2, epsilon, XLS, XLV, XLF, rhoair0, rhowater,
     // cliq, cice, psat (icar_constants.f90:391-420, wrf_constants.f90:10-67)
@@ -178,7 +186,8 @@ int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     for (int loop = 1; loop <= loops; ++loop) {
         if (loop == 1) hipLaunchKernelGGL((k_wsm3_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, i0, i1, j0, k0, km);
         else           hipLaunchKernelGGL((k_wsm3_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, i0, i1, j0, k0, km);
-        hipLaunchKernelGGL(k_wsm3_fall, g2, b2, 0, c->stream, c->d, S->c, A, W, qci, qrs, w, den, dz, dtcld, i0, i1, j0, k0, km);
+        hipLaunchKernelGGL(k_wsm3_fall, dim3(nxb, nyt, 2), b2, 0, c->stream, c->d, S->c, W, qci, qrs, den, dz, S->delq, dtcld, i0, i1, j0, k0, km);
+        hipLaunchKernelGGL(k_wsm3_melt, g2, b2, 0, c->stream, c->d, A, W, qci, qrs, w, den, dz, S->delq, dtcld, i0, i1, j0, k0, km);
         if (loop == loops) hipLaunchKernelGGL((k_wsm3_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, dtcld, i0, i1, j0, k0, km);
         else               hipLaunchKernelGGL((k_wsm3_rates<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, dtcld, i0, i1, j0, k0, km);
     }

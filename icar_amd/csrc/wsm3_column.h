@@ -82,17 +82,17 @@ W3_FN float wsm3_slope1(const wsm3_consts *C, float qrs, float den, float denfac
  * rql is den*q on input and output; wwl the terminal velocity (a local copy is refined once when iter == 1; the caller's
  * array is not changed, as in the reference).  iter is 0 or 1 (the two calls WSM3 makes).  Returns precip.
  * The reference's scratch copies qq (= rql), wd (= wwl) and the unused slope outputs of its iteration are not materialised. */
-W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, const float *denfac, const float *tk, const float *dz,
+W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, int st, const float *den, const float *denfac, const float *tk, const float *dz,
                             const float *wwl, float *rql, float dt, int iter)
-{
+{   /* st: element stride of the column arrays (1 for a packed column, nx on the device where level k of a column is k*nx away) */
     float ww[W3_MAXK], qn[W3_MAXK];
     float wi[W3_MAXK + 1], zi[W3_MAXK + 1], za[W3_MAXK + 1], dza[W3_MAXK + 1], qa[W3_MAXK + 1], qmi[W3_MAXK + 1], qpi[W3_MAXK + 1];
     float precip = 0.0f;
     float allold = 0.0f;
-    for (int k = 0; k < km; ++k) { ww[k] = wwl[k]; allold = allold + rql[k]; }
+    for (int k = 0; k < km; ++k) { ww[k] = wwl[k * st]; allold = allold + rql[k * st]; }
     if (allold <= 0.0f) return precip;                       /* cycle i_loop: nothing changes, not even rql */
     zi[0] = 0.0f;
-    for (int k = 0; k < km; ++k) zi[k + 1] = zi[k] + dz[k];
+    for (int k = 0; k < km; ++k) zi[k + 1] = zi[k] + dz[k * st];
     int n = 1;
     for (;;) {
         /* 3rd-order interpolation of the fall speed to the interfaces (:1303-1320; the linear estimate :1298-1302 is overwritten) */
@@ -105,19 +105,21 @@ W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, cons
         for (int k = 1; k < km; ++k) if (ww[k] == 0.0f) wi[k] = ww[k - 1];          /* terminate at the top of the rain shaft */
         const float con1 = 0.05f;                                                  /* diffusivity of wi */
         for (int k = km - 1; k >= 0; --k) {
-            const float decfl = (wi[k + 1] - wi[k]) * dt / dz[k];
-            if (decfl > con1) wi[k] = wi[k + 1] - con1 * dz[k] / dt;
+            const float dzk = dz[k * st];
+            const float decfl = (wi[k + 1] - wi[k]) * dt / dzk;
+            if (decfl > con1) wi[k] = wi[k + 1] - con1 * dzk / dt;
         }
         for (int k = 0; k <= km; ++k) za[k] = zi[k] - wi[k] * dt;                  /* arrival points */
         for (int k = 0; k < km; ++k) dza[k] = za[k + 1] - za[k];
         dza[km] = zi[km] - za[km];
-        for (int k = 0; k < km; ++k) qa[k] = rql[k] * dz[k] / dza[k];
+        for (int k = 0; k < km; ++k) qa[k] = rql[k * st] * dz[k * st] / dza[k];
         qa[km] = 0.0f;
         if (n <= iter) {                                     /* n == 1 here: wa = slope(qa/den); ww = 0.5*(wd + wa) */
             for (int k = 0; k < km; ++k) {
                 float r1, r2, r3, r4;
-                const float wa = wsm3_slope1(C, qa[k] / den[k], den[k], denfac[k], tk[k], &r1, &r2, &r3, &r4);
-                ww[k] = 0.5f * (wwl[k] + wa);
+                const float dk = den[k * st];
+                const float wa = wsm3_slope1(C, qa[k] / dk, dk, denfac[k * st], tk[k * st], &r1, &r2, &r3, &r4);
+                ww[k] = 0.5f * (wwl[k * st] + wa);
             }
             n = n + 1;
             continue;
@@ -178,13 +180,13 @@ W3_FN float wsm3_nislfv_plm(const wsm3_consts *C, int km, const float *den, cons
         else if (za[k] < 0.0f && za[k + 1] >= 0.0f) { precip = precip + qa[k] * (0.0f - za[k]); break; }
         break;
     }
-    for (int k = 0; k < km; ++k) rql[k] = qn[k];
+    for (int k = 0; k < km; ++k) rql[k * st] = qn[k];
     return precip;
 }
 
 /* ---- wsm32D (:218-903) in three pieces.  Everything except the two falls, the melting level and the surface flux is
- * level-local, so the pieces are: per level before the minor loops, per level at the top of a minor loop, per COLUMN (fall,
- * melt, surface), per level (rates, update, condensation).  wsm3_column() strings them together for one column; the device
+ * level-local, so the pieces are: per level before the minor loops, per level at the top of a minor loop, per COLUMN and
+ * species (the fall), per COLUMN (melting level, surface flux), per level (rates, update, condensation).  wsm3_column() strings them together for one column; the device
  * runs the level pieces one thread per cell and the column piece one thread per column. ---- */
 typedef struct w3_sat { float ttp, xa, xb, xai, xbi; } w3_sat;
 
@@ -255,39 +257,45 @@ W3_FN void wsm3_level_prep(const wsm3_consts *C, const wsm3_args *A, const w3_sa
 
 /* per column (:485-598): fall of rain/snow and of cloud ice, melting/freezing at the 0 C level, surface precipitation.
  * denqrs / denqci are work arrays (in: den*q, out: the fallen field); rain, snow accumulate this call's surface flux. */
-W3_FN void wsm3_column_fall(const wsm3_consts *C, const wsm3_args *A, int km, float dtcld, float *t, float *qci, float *qrs, const float *w,
-                            const float *den, const float *delz, const float *denfac, const float *cpm, const float *vt, float *denqrs,
-                            const float *vti, float *denqci, float *rain, float *rainncv, float *snow, float *snowncv, float *sr)
+/* one falling species of a column (:485-498 rain/snow with iter = 1, :521-528 cloud ice with iter = 0): the semi-Lagrangian
+ * fall on den*q, then q = max(den*q / den, 0).  Returns the surface flux integral delq. */
+W3_FN float wsm3_fall_species(const wsm3_consts *C, int km, int st, float dtcld, const float *t, float *qx, const float *den, const float *delz,
+                              const float *denfac, const float *vt, float *denq, int iter)
+{
+    const float delq = wsm3_nislfv_plm(C, km, st, den, denfac, t, delz, vt, denq, dtcld, iter);
+    for (int k = 0; k < km; ++k) qx[k * st] = w3_max(denq[k * st] / den[k * st], 0.f);
+    return delq;
+}
+
+/* melting / freezing at the 0 C level (:532-569) and the surface precipitation (:570-598) of a column, after both falls */
+W3_FN void wsm3_melt_surface(const wsm3_args *A, int km, int st, float dtcld, float delqrs, float delqi, float *t, const float *qci, const float *qrs,
+                             const float *w, const float *den, const float *delz, const float *cpm, const float *vt, const float *denqrs,
+                             float *rain, float *rainncv, float *snow, float *snowncv, float *sr)
 {
     const float t0c = A->t0c, xlf0 = A->xlf0, denr = A->denr;
-    const float delqrs = wsm3_nislfv_plm(C, km, den, denfac, t, delz, vt, denqrs, dtcld, 1);
-    for (int k = 0; k < km; ++k) qrs[k] = w3_max(denqrs[k] / den[k], 0.f);
     const float fall1 = delqrs / delz[0] / dtcld;                 /* fall(i,1); fall(i,k>1) = denqrs*vt/delz is formed where it is read */
-    const float delqi = wsm3_nislfv_plm(C, km, den, denfac, t, delz, vti, denqci, dtcld, 0);
-    for (int k = 0; k < km; ++k) qci[k] = w3_max(denqci[k] / den[k], 0.f);
     const float fallc1 = delqi / delz[0] / dtcld;
-    /* melting / freezing at the 0 C level (:532-569) */
     int mstep = 0;
-    for (int k = 1; k <= km; ++k) if (t[k - 1] >= t0c) mstep = k;
+    for (int k = 1; k <= km; ++k) if (t[(k - 1) * st] >= t0c) mstep = k;
     int kwork2 = mstep, kwork1 = mstep;
-    if (mstep != 0) { if (w[mstep - 1] > 0.f) kwork1 = mstep + 1; }
+    if (mstep != 0) { if (w[(mstep - 1) * st] > 0.f) kwork1 = mstep + 1; }
     {
         const int k = kwork1, kk = kwork2;
         if (k * kk >= 1 && k <= km) {
-            const float qrsci = qrs[k - 1] + qci[k - 1];
-            const float fallkk = (kk == 1) ? fall1 : denqrs[kk - 1] * vt[kk - 1] / delz[kk - 1];
+            const int ck = (k - 1) * st, ckk = (kk - 1) * st;
+            const float qrsci = qrs[ck] + qci[ck];
+            const float fallkk = (kk == 1) ? fall1 : denqrs[ckk] * vt[ckk] / delz[ckk];
             if (qrsci > 0.f || fallkk > 0.f) {
-                const float frzmlt = w3_min(w3_max(-w[k - 1] * qrsci / delz[k - 1], -qrsci / dtcld), qrsci / dtcld);
-                const float snomlt = w3_min(w3_max(fallkk / den[kk - 1], -qrs[k - 1] / dtcld), qrs[k - 1] / dtcld);
-                if (k == kk) t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * (frzmlt + snomlt) * dtcld;
+                const float frzmlt = w3_min(w3_max(-w[ck] * qrsci / delz[ck], -qrsci / dtcld), qrsci / dtcld);
+                const float snomlt = w3_min(w3_max(fallkk / den[ckk], -qrs[ck] / dtcld), qrs[ck] / dtcld);
+                if (k == kk) t[ck] = t[ck] - xlf0 / cpm[ck] * (frzmlt + snomlt) * dtcld;
                 else {
-                    t[k - 1] = t[k - 1] - xlf0 / cpm[k - 1] * frzmlt * dtcld;
-                    t[kk - 1] = t[kk - 1] - xlf0 / cpm[kk - 1] * snomlt * dtcld;
+                    t[ck] = t[ck] - xlf0 / cpm[ck] * frzmlt * dtcld;
+                    t[ckk] = t[ckk] - xlf0 / cpm[ckk] * snomlt * dtcld;
                 }
             }
         }
     }
-    /* surface precipitation (:570-598) */
     float fallsum = fall1, fallsum_qsi = 0.f;
     if ((t0c - t[0]) > 0) { fallsum = fallsum + fallc1; fallsum_qsi = fall1 + fallc1; }
     if (fallsum > 0.f) {
@@ -422,7 +430,9 @@ W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *
     for (int loop = 1; loop <= loops; ++loop) {
         for (int k = 0; k < km; ++k)
             wsm3_level_prep(C, A, &S, t[k], q[k], qci[k], qrs[k], den[k], p[k], &denfac[k], &qs[k], &rh[k], &vt[k], &denqrs[k], &vti[k], &denqci[k]);
-        wsm3_column_fall(C, A, km, dtcld, t, qci, qrs, w, den, delz, denfac, cpm, vt, denqrs, vti, denqci, rain, rainncv, snow, snowncv, sr);
+        const float delqrs = wsm3_fall_species(C, km, 1, dtcld, t, qrs, den, delz, denfac, vt, denqrs, 1);
+        const float delqi = wsm3_fall_species(C, km, 1, dtcld, t, qci, den, delz, denfac, vti, denqci, 0);
+        wsm3_melt_surface(A, km, 1, dtcld, delqrs, delqi, t, qci, qrs, w, den, delz, cpm, vt, denqrs, rain, rainncv, snow, snowncv, sr);
         for (int k = 0; k < km; ++k)
             wsm3_level_rates(C, A, &S, dtcld, &t[k], &q[k], &qci[k], &qrs[k], den[k], p[k], denfac[k], qs[k], rh[k], cpm[k], xl[k]);
     }
