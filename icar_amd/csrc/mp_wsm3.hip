@@ -6,6 +6,8 @@
 #include "ctx.h"
 #include "fp64_math.h"
 #include <cmath>
+#include <cstring>
+#include <cstdlib>
 
 namespace {
 __device__ __forceinline__ float w3_expf(float x) { return (float)d_exp((double)x); }
@@ -43,12 +45,22 @@ __device__ __forceinline__ float w3_powf(float x, float y)
 struct Wsm3State {
     wsm3_consts c; bool ready = false;
     float *t = nullptr, *cpm = nullptr, *xl = nullptr, *denfac = nullptr, *qs = nullptr, *rh = nullptr, *vt = nullptr, *denqrs = nullptr,
-          *vti = nullptr, *denqci = nullptr, *rain = nullptr, *snow = nullptr, *delq = nullptr;
+          *vti = nullptr, *denqci = nullptr, *rain = nullptr, *snow = nullptr, *delq = nullptr, *zi = nullptr;
     size_t n3 = 0;
 };
 
 namespace {
-struct W3Work { float *t, *cpm, *xl, *denfac, *qs, *rh, *vt, *denqrs, *vti, *denqci, *rain, *snow; };
+struct W3Work { float *t, *cpm, *xl, *denfac, *qs, *rh, *vt, *denqrs, *vti, *denqci, *rain, *snow, *zi; };
+
+// zi(k+1) = zi(k) + dz(k) (mp_wsm3.f90:1291-1294), the reference's running sum, once per call and column
+__global__ void __launch_bounds__(64)
+k_wsm3_zi(Dims d, const float *__restrict__ delz, float *__restrict__ zi, int i0, int i1, int j0, int k0, int km)
+{
+    const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y;
+    if (i > i1) return;
+    float run = 0.0f;
+    for (int k = 0; k < km; ++k) { const int c = d.idx(i, k0 + k, j); run = run + delz[c]; zi[c] = run; }
+}
 
 // per cell, top of a minor loop (first: also t = th*pii (:151-155), the clamps, cpm, xl)
 template <bool FIRST>
@@ -71,6 +83,190 @@ k_wsm3_prep(Dims d, wsm3_consts C, wsm3_args A, W3Work W, const float *__restric
     float denfac, qs, rh, vt, denqrs, vti, denqci;
     wsm3_level_prep(&C, &A, &S, t, q[c], qci_, qrs_, den[c], p[c], &denfac, &qs, &rh, &vt, &denqrs, &vti, &denqci);
     W.denfac[c] = denfac; W.qs[c] = qs; W.rh[c] = rh; W.vt[c] = vt; W.denqrs[c] = denqrs; W.vti[c] = vti; W.denqci[c] = denqci;
+}
+
+// ---- the fall with one WAVE per (column, species): lane = level (cell quantities) / interface (wi, zi, za, dza, qa, qmi, qpi
+// live on lanes 0..km).  nislfv_rain_plm (mp_wsm3.f90:1266-1505) is sequential in k only in four places, which stay
+// sequential here so that every sum and every comparison sees the reference's operands:
+//   zi            running sum of dz (a lane-serial loop of km adds)
+//   wi limiter    k = km..1 uses the wi(k+1) it may just have changed: evaluated for all k at once with the unmodified values;
+//                 only from the highest level that trips the limit downward is it re-run serially (rare)
+//   kb / kt       "first kk >= previous-1 with zi <= za(kk)": za is strictly increasing (the limiter guarantees dza >= 0.95 dz),
+//                 so the first kk is the count of arrival heights below zi, the same for every start the reference can have;
+//                 where kt is not found the reference's stale kt is < kb and the level gets qn = 0 either way
+//   sums          the kb+1..kt-1 partial sums and the surface flux are short loops in k order
+// Needs km + 1 <= 64 lanes; all cross-lane reads happen with every lane active.
+// one (column, species) on one wave: lane = level for dz, den, denfac, tk, wwl (terminal velocity), rql (den*q); zi = height of
+// interface `lane` (0 at lane 0).  Returns the surface flux integral; *qn_out = the fallen den*q of this lane's level.
+__device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int km, int lane, float dz, float den, float denfac, float tk,
+                                                     float wwl, float rql, float zi, int iter, float dt, float *qn_out)
+{
+    const bool cell = lane < km;
+    float precip = 0.0f, qn = rql;                                   // an empty column keeps den*q as it is (cycle i_loop)
+    if (__ballot(cell && rql > 0.0f) != 0ull) {                      // allold > 0: den*q >= 0, so the sum is positive iff one term is
+        float ww = cell ? wwl : 0.0f, wi, za, dza, qa;
+        for (int n = 1;; ++n) {
+            const float wm1 = __shfl_up(ww, 1), wm2 = __shfl_up(ww, 2), wp1 = __shfl_down(ww, 1);
+            const float fa1 = 9.f / 16.f, fa2 = 1.f / 16.f;
+            if (lane == 0) wi = ww;
+            else if (lane == 1) wi = 0.5f * (ww + wm1);
+            else if (lane <= km - 2) wi = fa1 * (ww + wm1) - fa2 * (wp1 + wm2);
+            else if (lane == km - 1) wi = 0.5f * (ww + wm1);
+            else wi = wm1;                                           // lane == km: wi(km+1) = ww(km)
+            if (lane >= 1 && lane < km && ww == 0.0f) wi = wm1;      // terminate at the top of the rain shaft
+            const float con1 = 0.05f;                                // limiter, k = km-1 .. 0
+            const float wip1 = __shfl_down(wi, 1);
+            const float dec = (wip1 - wi) * dt / dz;
+            const unsigned long long bad = __ballot(cell && dec > con1);
+            if (bad) {                                               // wave-uniform
+                // Serial only where it has to be: level k must be re-evaluated when wi(k+1) has just been changed; when a
+                // level is left alone, everything below it still sees the values the parallel evaluation saw, so the walk
+                // jumps to the next level that tripped there.
+                const float cdz = con1 * dz / dt;                    // per lane, the reference's con1*dz(k)/dt
+                unsigned long long rem = bad;
+                int k = 63 - __builtin_clzll(rem);
+                while (k >= 0) {
+                    const float wk1 = __shfl(wi, k + 1), wk = __shfl(wi, k), dzk = __shfl(dz, k), ck = __shfl(cdz, k);
+                    const float decfl = (wk1 - wk) * dt / dzk;
+                    rem &= (k == 0) ? 0ull : ((1ull << k) - 1ull);   // levels below k that tripped with the unmodified values
+                    if (decfl > con1) {                              // uniform: all lanes hold the same broadcast operands
+                        if (lane == k) wi = wk1 - ck;
+                        k = k - 1;
+                    } else k = rem ? 63 - __builtin_clzll(rem) : -1;
+                }
+            }
+            za = zi - wi * dt;                                       // interfaces 0..km
+            const float zap1 = __shfl_down(za, 1);
+            dza = (lane < km) ? zap1 - za : zi - za;                 // dza(km+1) = zi(km+1) - za(km+1)
+            qa = cell ? rql * dz / dza : 0.0f;                       // qa(km+1) = 0
+            if (n <= iter) {                                         // wave-uniform
+                float r1, r2, r3, r4;
+                const float wa = wsm3_slope1(C, cell ? qa / den : 0.f, den, denfac, tk, &r1, &r2, &r3, &r4);
+                ww = cell ? 0.5f * (wwl + wa) : 0.0f;
+                continue;
+            }
+            break;
+        }
+        float qmi = qa, qpi = qa;                                    // piecewise-linear reconstruction
+        {
+            const float qap1 = __shfl_down(qa, 1), qam1 = __shfl_up(qa, 1), dzap1 = __shfl_down(dza, 1), dzam1 = __shfl_up(dza, 1);
+            if (lane >= 1 && lane < km) {
+                const float dip = (qap1 - qa) / (dzap1 + dza);
+                const float dim = (qa - qam1) / (dzam1 + dza);
+                if (!(dip * dim <= 0.0f)) {
+                    qpi = qa + 0.5f * (dip + dim) * dza;
+                    qmi = 2.0f * qa - qpi;
+                    if (qpi < 0.0f || qmi < 0.0f) { qpi = qa; qmi = qa; }
+                }
+            }
+        }
+        // interpolation to the regular grid: the output cell of this lane is [zi(lane), zi(lane+1)]
+        const float zlo = zi, zhi = __shfl_down(zi, 1);
+        const float za_top = __shfl(za, km);
+        // arrival heights below zlo among interfaces 1..km (nb) and below zhi among 0..km-1 (nt): za increases strictly, so each
+        // count is the position of the first za >= z -- a 6-step binary search per lane instead of km+1 comparisons
+        int lo1 = 0, hi1 = km + 1, lo2 = 0, hi2 = km;
+        for (int step = 0; step < 6; ++step) {
+            const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+            const float v1 = __shfl(za, m1 < 63 ? m1 : 63), v2 = __shfl(za, m2 < 63 ? m2 : 63);
+            if (lo1 < hi1) { if (v1 < zlo) lo1 = m1 + 1; else hi1 = m1; }
+            if (lo2 < hi2) { if (v2 < zhi) lo2 = m2 + 1; else hi2 = m2; }
+        }
+        const float za0 = __shfl(za, 0);
+        const int nb = lo1 - (za0 < zlo ? 1 : 0), nt = lo2;
+        const bool live = cell && !(zlo >= za_top);                  // not yet `exit intp`
+        const int kb = live ? nb + 1 : 1;                            // 1-based first kk with zi(k) <= za(kk+1); <= km when live
+        const bool found = live && nt < km;                          // first kk with zi(k+1) <= za(kk) exists
+        const int kt = found ? nt : 0;                               // that kk, minus 1
+        const int ib = kb - 1, it = (kt >= 1 ? kt : 1) - 1;
+        const float za_b = __shfl(za, ib), dza_b = __shfl(dza, ib), qpi_b = __shfl(qpi, ib), qmi_b = __shfl(qmi, ib), qa_b = __shfl(qa, ib);
+        const float za_t = __shfl(za, it), dza_t = __shfl(dza, it), qpi_t = __shfl(qpi, it), qmi_t = __shfl(qmi, it);
+        const float tl = (zlo - za_b) / dza_b;
+        const float tl2 = tl * tl;
+        const float qqd_b = 0.5f * (qpi_b - qmi_b);
+        const float qql = qqd_b * tl2 + qmi_b * tl;
+        float zsum = (1.f - tl) * dza_b, qsum = (qa_b - qql) * dza_b;
+        const int cnt = (found && kt > kb) ? kt - kb - 1 : 0;        // m = kb+1 .. kt-1
+        int cmax = cnt;
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(cmax, o); cmax = v > cmax ? v : cmax; }
+        for (int s2 = 1; s2 <= cmax; ++s2) {
+            const int m = kb + s2 - 1 <= 63 ? kb + s2 - 1 : 63;      // 0-based index of m = kb + s2
+            const float dm = __shfl(dza, m), qm = __shfl(qa, m);
+            if (s2 <= cnt) { zsum = zsum + dm; qsum = qsum + qm * dm; }
+        }
+        qn = 0.0f;
+        if (found && kt == kb) {
+            const float th = (zhi - za_b) / dza_b;
+            const float th2 = th * th;
+            const float qqh = qqd_b * th2 + qmi_b * th;
+            qn = (qqh - qql) / (th - tl);
+        } else if (found && kt > kb) {
+            const float th = (zhi - za_t) / dza_t;
+            const float th2 = th * th;
+            const float qqd = 0.5f * (qpi_t - qmi_t);
+            const float dqh = qqd * th2 + qmi_t * th;
+            zsum = zsum + th * dza_t;
+            qsum = qsum + dqh * dza_t;
+            qn = qsum / zsum;
+        }
+        // rain out, k ascending (wave-uniform loop on broadcast values)
+        for (int k = 0; k < km; ++k) {
+            const float zk = __shfl(za, k), zk1 = __shfl(za, k + 1), qk = __shfl(qa, k), dk = __shfl(dza, k);
+            if (zk < 0.0f && zk1 < 0.0f) { precip = precip + qk * dk; continue; }
+            else if (zk < 0.0f && zk1 >= 0.0f) { precip = precip + qk * (0.0f - zk); break; }
+            break;
+        }
+    }
+    *qn_out = qn;
+    return precip;
+}
+
+// a block = 4 waves = one row segment of W3_TC columns of one species: the seven column arrays are staged through LDS as
+// [level][column] tiles (coalesced 128-B row reads; the column-per-wave access pattern itself would touch one cache line per
+// lane), each wave then walks its W3_TC/4 columns with lane = level, and the results go back the same way.
+#define W3_TC 32
+__global__ void __launch_bounds__(256)
+k_wsm3_fall_tile(Dims d, wsm3_consts C, W3Work W, float *__restrict__ qci, float *__restrict__ qrs, const float *__restrict__ den_,
+                 const float *__restrict__ delz, float *__restrict__ delq, float dt, int i0, int i1, int j0, int k0, int km)
+{
+    extern __shared__ float w3_lds[];                                // [7][km][W3_TC + 1]
+    const int ib = i0 + blockIdx.x * W3_TC, j = j0 + blockIdx.y;
+    const bool ice = blockIdx.z == 1;
+    const int ncol = min(W3_TC, i1 - ib + 1);
+    const int LS = W3_TC + 1, plane = km * LS;
+    float *__restrict__ qx = ice ? qci : qrs;
+    float *__restrict__ denq = ice ? W.denqci : W.denqrs;
+    const float *src[7] = {delz, den_, W.denfac, W.t, ice ? W.vti : W.vt, denq, W.zi};
+    for (int a = 0; a < 7; ++a)
+        for (int e = threadIdx.x; e < km * W3_TC; e += 256) {
+            const int k = e / W3_TC, ci = e % W3_TC;
+            if (ci < ncol) w3_lds[a * plane + k * LS + ci] = src[a][d.idx(ib + ci, k0 + k, j)];
+        }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kl = lane < km ? lane : km - 1;                        // lanes beyond the column read a valid level (values unused)
+    for (int t = 0; t < W3_TC / 4; ++t) {
+        const int ci = wave * (W3_TC / 4) + t;
+        if (ci >= ncol) break;                                       // wave-uniform
+        const float dz = w3_lds[0 * plane + kl * LS + ci], den = w3_lds[1 * plane + kl * LS + ci], denfac = w3_lds[2 * plane + kl * LS + ci],
+                    tk = w3_lds[3 * plane + kl * LS + ci], wwl = w3_lds[4 * plane + kl * LS + ci], rql = w3_lds[5 * plane + kl * LS + ci];
+        const int kz = (lane <= km ? lane : km) - 1;
+        const float zi = lane == 0 ? 0.0f : w3_lds[6 * plane + kz * LS + ci];
+        float qn;
+        const float precip = w3_fall_wave_column(&C, km, lane, dz, den, denfac, tk, wwl, rql, zi, ice ? 0 : 1, dt, &qn);
+        if (lane < km) w3_lds[5 * plane + lane * LS + ci] = qn;      // this wave is the only reader / writer of column ci
+        if (lane == 0) delq[(size_t)(ice ? 1 : 0) * d.nx * d.ny + (ib + ci) + d.nx * j] = precip;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < km * W3_TC; e += 256) {
+        const int k = e / W3_TC, ci = e % W3_TC;
+        if (ci < ncol) {
+            const int c = d.idx(ib + ci, k0 + k, j);
+            const float qn = w3_lds[5 * plane + k * LS + ci];
+            denq[c] = qn;                                            // rql(i,:) = qn(:)
+            qx[c] = w3_max(qn / w3_lds[1 * plane + k * LS + ci], 0.f);   // q = max(den*q / den, 0)
+        }
+    }
 }
 
 // per column and species (blockIdx.z: 0 rain/snow, 1 cloud ice): the semi-Lagrangian fall.  The column arrays are read and
@@ -136,7 +332,7 @@ void icar_wsm3_free(icar_hip_ctx *c)
 {
     if (!c->wsm3) return;
     float **ps[] = {&c->wsm3->t, &c->wsm3->cpm, &c->wsm3->xl, &c->wsm3->denfac, &c->wsm3->qs, &c->wsm3->rh, &c->wsm3->vt, &c->wsm3->denqrs,
-                    &c->wsm3->vti, &c->wsm3->denqci, &c->wsm3->rain, &c->wsm3->snow, &c->wsm3->delq};
+                    &c->wsm3->vti, &c->wsm3->denqci, &c->wsm3->rain, &c->wsm3->snow, &c->wsm3->delq, &c->wsm3->zi};
     for (float **p : ps) if (*p) hipFree(*p);
     delete c->wsm3; c->wsm3 = nullptr;
 }
@@ -165,7 +361,7 @@ int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     if (!th || !q || !qci || !qrs || !w || !den || !pii || !p || !dz || !pa || !sa) return 1;
     Wsm3State *S = c->wsm3;
     if (!S->t) {
-        float **p3[] = {&S->t, &S->cpm, &S->xl, &S->denfac, &S->qs, &S->rh, &S->vt, &S->denqrs, &S->vti, &S->denqci};
+        float **p3[] = {&S->t, &S->cpm, &S->xl, &S->denfac, &S->qs, &S->rh, &S->vt, &S->denqrs, &S->vti, &S->denqci, &S->zi};
         for (float **x : p3) HIPCHK(hipMalloc(x, c->n3 * sizeof(float)));
         HIPCHK(hipMalloc(&S->rain, (size_t)c->d.nx * c->d.ny * sizeof(float))); HIPCHK(hipMalloc(&S->snow, (size_t)c->d.nx * c->d.ny * sizeof(float)));
         HIPCHK(hipMalloc(&S->delq, 2 * (size_t)c->d.nx * c->d.ny * sizeof(float)));
@@ -177,16 +373,23 @@ int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     A.ep1 = 461.5f / 287.058f - 1.f; A.ep2 = 287.058f / 461.5f; A.qmin = 1.e-15f; A.xls = 2.85e6f; A.xlv0 = 2.5e6f; A.xlf0 = 3.50e5f;
     A.den0 = 1.28f; A.denr = 1000.f; A.cliq = 4190.f; A.cice = 2106.f; A.psat = 610.78f;
     int loops; const float dtcld = wsm3_dtcld(&A, &loops);
-    W3Work W = {S->t, S->cpm, S->xl, S->denfac, S->qs, S->rh, S->vt, S->denqrs, S->vti, S->denqci, S->rain, S->snow};
+    W3Work W = {S->t, S->cpm, S->xl, S->denfac, S->qs, S->rh, S->vt, S->denqrs, S->vti, S->denqci, S->rain, S->snow, S->zi};
     ScopedTimer tm(c, "mp");
     HIPCHK(hipMemsetAsync(S->rain, 0, (size_t)c->d.nx * c->d.ny * sizeof(float), c->stream));     // process_subdomain: precipitation = 0
     HIPCHK(hipMemsetAsync(S->snow, 0, (size_t)c->d.nx * c->d.ny * sizeof(float), c->stream));
     const int i0 = its - c->ims, i1 = ite - c->ims, j0 = jts - c->jms, k0 = kts - c->kms, nxb = (ite - its + 1 + 63) / 64, nyt = jte - jts + 1;
     const dim3 gc(nxb, (km + 3) / 4, nyt), bc(64, 4), g2(nxb, nyt), b2(64);
+    hipLaunchKernelGGL(k_wsm3_zi, g2, b2, 0, c->stream, c->d, dz, S->zi, i0, i1, j0, k0, km);
     for (int loop = 1; loop <= loops; ++loop) {
         if (loop == 1) hipLaunchKernelGGL((k_wsm3_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, i0, i1, j0, k0, km);
         else           hipLaunchKernelGGL((k_wsm3_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, i0, i1, j0, k0, km);
-        hipLaunchKernelGGL(k_wsm3_fall, dim3(nxb, nyt, 2), b2, 0, c->stream, c->d, S->c, W, qci, qrs, den, dz, S->delq, dtcld, i0, i1, j0, k0, km);
+        static const bool serial_fall = getenv("ICAR_HIP_WSM3_FALL") && !strcmp(getenv("ICAR_HIP_WSM3_FALL"), "serial");   // A/B switch
+        if (km + 1 <= 64 && !serial_fall) {
+            const int ncol_x = ite - its + 1;
+            hipLaunchKernelGGL(k_wsm3_fall_tile, dim3((ncol_x + W3_TC - 1) / W3_TC, nyt, 2), dim3(256), 7 * (size_t)km * (W3_TC + 1) * sizeof(float),
+                               c->stream, c->d, S->c, W, qci, qrs, den, dz, S->delq, dtcld, i0, i1, j0, k0, km);
+        } else
+            hipLaunchKernelGGL(k_wsm3_fall, dim3(nxb, nyt, 2), b2, 0, c->stream, c->d, S->c, W, qci, qrs, den, dz, S->delq, dtcld, i0, i1, j0, k0, km);
         hipLaunchKernelGGL(k_wsm3_melt, g2, b2, 0, c->stream, c->d, A, W, qci, qrs, w, den, dz, S->delq, dtcld, i0, i1, j0, k0, km);
         if (loop == loops) hipLaunchKernelGGL((k_wsm3_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, dtcld, i0, i1, j0, k0, km);
         else               hipLaunchKernelGGL((k_wsm3_rates<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, dtcld, i0, i1, j0, k0, km);
