@@ -76,3 +76,13 @@ def test_wsm3_within_tolerance_of_reference_math(oracle, case):
         bad = np.abs(a - b) > 1e-5 * np.maximum(np.abs(b), 1e-3 * scale)
         assert bad.mean() <= 1e-2, f"{n}: {bad.mean():.2e} of cells beyond rtol 1e-5"
     assert abs(pa.sum() - acc_r.sum()) <= 1e-4 * acc_r.sum() and abs(sa.sum() - acc_s.sum()) <= 1e-4 * max(acc_s.sum(), 1e-9) + 1e-9
+
+
+def test_wsm3_serial_fall_variant_is_bit_exact_too():
+    """The one-thread-per-column form of the fall (ICAR_HIP_WSM3_FALL=serial; the fallback for more than 63 levels) against
+    the same oracle: the switch is read once per process, so the bit-exact cases run again in a child process."""
+    import os, subprocess, sys
+    env = dict(os.environ, ICAR_HIP_WSM3_FALL="serial")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-k", "bit_exact_vs_oracle_device_math", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
