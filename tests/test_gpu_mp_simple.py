@@ -219,3 +219,46 @@ def test_cooled_column_scenario(oracle):
     assert acc_r[1:-1, 1:-1].min() > 0 and acc_s[1:-1, 1:-1].min() > 0             # "keeps getting precipitation out (including snow)"
     assert acc_r[0].max() == 0                                                     # the boundary ring is not processed
     d.close()
+
+
+def test_mp_update_interval_and_top_mp_level(oracle):
+    """mp() bookkeeping of row M0 (mp_driver.f90:692-725): with update_interval > dt the scheme runs only when
+    (model_time + dt) - last_model_time >= update_interval, with mp_dt = model_time - last_model_time (the time since its last
+    run, not dt); top_mp_level caps kte, so the levels above stay as they are.  Device vs the oracle driven by the same
+    bookkeeping, bit for bit."""
+    nx, ny, nz, dt = 66, 18, 24, 40.0
+    upd, top = 100.0, 17
+    c = ideal.make_case(nx, ny, nz, hill_height=700.0, noise=0.01)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.7)).astype(np.float32)
+    names = ["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water", "rain", "snow", "dz_mass"]
+    s = {k: c[k].copy() for k in names}
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_SB04
+    opt.mp_options.update_interval = upd; opt.mp_options.top_mp_level = top
+    mp_init(opt, d)
+    acc = np.zeros((ny, nx), np.float64)
+    last = None; now = 0.0; ran = []
+    oracle.set_math_mode(1)
+    try:
+        for it in range(9):
+            if last is None: last = now - max(upd, dt)
+            if (now + dt) - last >= upd:
+                mp_dt = now - last; last = now; ran.append((it, mp_dt))
+                rain = np.zeros((ny, nx), np.float32); snow = np.zeros((ny, nx), np.float32)
+                assert oracle.mp_simple(s["pressure"], s["potential_temperature"], s["exner"], s["density"], s["water_vapor"], s["cloud_water"],
+                                        s["rain"], s["snow"], rain, snow, float(np.float32(mp_dt)), s["dz_mass"], 2, nx - 1, 2, ny - 1, 1, top) == 0
+                acc += rain
+            s["potential_temperature"] -= np.float32(0.3)
+            mp(d, opt, dt)
+            d.model_time_seconds += dt; now += dt
+            d.set("potential_temperature", d.get("potential_temperature") - np.float32(0.3))
+    finally:
+        oracle.set_math_mode(0)
+    assert [r[0] for r in ran] == [0, 2, 4, 6, 8] and [r[1] for r in ran] == [100.0, 80.0, 80.0, 80.0, 80.0], ran
+    for k, m in (("potential_temperature", "potential_temperature"), ("water_vapor", "water_vapor"), ("cloud_water", "cloud_water_mass"),
+                 ("rain", "rain_mass"), ("snow", "snow_mass")):
+        assert np.array_equal(d.get(m), s[k]), k
+    assert np.array_equal(d.get("accumulated_precipitation"), acc) and acc.max() > 0
+    assert np.array_equal(d.get("water_vapor")[:, top:, :], c["water_vapor"][:, top:, :])       # above top_mp_level nothing happened
+    assert not np.array_equal(d.get("water_vapor")[:, :top, :], c["water_vapor"][:, :top, :])
+    d.close()
