@@ -16,6 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+# Nt_c, TNO, am_s, rho_g, av_s, bv_s, fv_s, av_g, bv_g, av_i, Ef_si, Ef_rs, Ef_rg, Ef_ri, C_cubes, C_sqrd, mu_r, t_adjust
+ALT_MP = [50.e6, 4.0, 0.08, 400.0, 35.0, 0.5, 80.0, 400.0, 0.85, 1800.0, 0.07, 0.9, 0.7, 0.9, 0.4, 0.25, 1.0, 1.0]
+
 CASES = {
     # name: (kind, parameters)
     "adv_upwind_24x20x10": dict(kind="adv", scheme=1, nx=24, ny=20, nz=10, hill=600.0, dens=0, order=2, fct=1, nsteps=3,
@@ -38,6 +41,10 @@ CASES = {
     "thompson_cold_20x10x40": dict(kind="th", nx=20, ny=10, nz=40, hill=1000.0, moist=2.0, cool=2.0, dt=60.0, nsteps=25),
     "thompson_longdt_16x8x40": dict(kind="th", nx=16, ny=8, nz=40, hill=1000.0, moist=2.5, cool=3.0, dt=130.0, nsteps=30),
     "thompson_tables": dict(kind="thtab"),
+    # a second, non-default mp_options set (opt_types.f90:30-41 order; both efficiency-table flags on): its own table cache
+    "thompson_alt_tables": dict(kind="thtab", mp=ALT_MP, flags=[1, 1], cache="/tmp/oracle/run_alt"),
+    "thompson_alt_cold_20x10x40": dict(kind="th", nx=20, ny=10, nz=40, hill=1000.0, moist=2.0, cool=2.0, dt=60.0, nsteps=20,
+                                       mp=ALT_MP, flags=[1, 1], cache="/tmp/oracle/run_alt"),
 }
 TH_KEYS = ["water_vapor", "cloud_water", "rain", "cloud_ice", "snow", "graupel", "ice_number", "rain_number", "potential_temperature"]
 
@@ -50,6 +57,16 @@ def summary(a):
     import numpy as np
     a64 = a.astype(np.float64)
     return dict(sum=float(a64.sum()), min=float(a.min()), max=float(a.max()), sumsq=float((a64 * a64).sum()))
+
+
+def _th_init(ref, p):
+    """thompson_init with the case's mp_options; the reference reads whatever *.dat cache it finds in the CWD without checking
+    the parameters, so every parameter set has its own directory."""
+    import numpy as np
+    if "mp" in p:
+        ref.thompson_init(np.asarray(p["mp"], np.float32), p["flags"], workdir=p["cache"])
+    else:
+        ref.thompson_init(workdir=os.environ.get("ICAR_THOMPSON_CACHE", "/tmp/oracle/run"))
 
 
 def run_case(name):
@@ -79,7 +96,7 @@ def run_case(name):
     elif p["kind"] == "thtab":
         # the reference's own lookup tables: fingerprints + probed entries (the tables total 85 MB)
         import hashlib
-        ref.thompson_init(workdir=os.environ.get("ICAR_THOMPSON_CACHE", "/tmp/oracle/run"))
+        _th_init(ref, p)
         out = {}
         rng = np.random.default_rng(7)
         for tname in ref.THOMPSON_TABLES:
@@ -89,7 +106,7 @@ def run_case(name):
             out["idx_" + tname] = idx; out["val_" + tname] = t[idx]; out["sum_" + tname] = np.float64(t.sum())
     elif p["kind"] == "th":
         nx, ny, nz = p["nx"], p["ny"], p["nz"]
-        ref.thompson_init(workdir=os.environ.get("ICAR_THOMPSON_CACHE", "/tmp/oracle/run"))
+        _th_init(ref, p)
         c = ideal.make_case(nx, ny, nz, hill_height=p["hill"], noise=0.01)
         s = {k: c[k].copy() for k in TH_KEYS + ["exner", "pressure", "dz_mass"]}
         s["water_vapor"] = (s["water_vapor"] * np.float32(p["moist"])).astype(np.float32)

@@ -56,13 +56,15 @@ def test_lookup_tables_bit_identical(th_oracle):
     d.close()
 
 
-def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None):
+def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, mp_options=None):
     c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, uniform_dz=uniform_dz)
     c["water_vapor"] = (c["water_vapor"] * np.float32(moist)).astype(np.float32)
     s = {k: c[k].copy() for k in list(FIELDS) + ["exner", "pressure", "dz_mass"]}
     acc = {k: np.zeros((ny, nx), np.float64) for k in ("rain", "snow", "graupel")}
     d = single_image_domain(c)
     opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    if mp_options is not None:
+        opt.mp_options = mp_options
     mp_init(opt, d)
     oracle.set_math_mode(mode)
     try:
@@ -292,3 +294,30 @@ def test_table_cache_files_byte_identical_to_the_reference(tmp_path):
         assert hashlib.sha256(open(p, "rb").read()).hexdigest() == g["sha256"], f"{f} differs from the reference's file"
     back = tc.read_caches(str(tmp_path))
     assert len(back) == 24 and back["tcg_racg"].size == 28 * 28 * 37 * 37
+
+
+def test_non_default_mp_options(oracle):
+    """A second mp_options set (all 18 parameters changed, both efficiency-table flags on; the oracle is pinned to the reference
+    for it by tests/test_oracle_thompson.py::test_non_default_mp_options_tables_and_columns): the device tables are bit-identical
+    to the oracle's and the cold-graupel column case agrees like the default set does."""
+    from icar_amd.options import mp_options_type
+    mpo = mp_options_type(Nt_c=50.e6, TNO=4.0, am_s=0.08, rho_g=400.0, av_s=35.0, bv_s=0.5, fv_s=80.0, av_g=400.0, bv_g=0.85, av_i=1800.0,
+                          Ef_si=0.07, Ef_rs=0.9, Ef_rg=0.7, Ef_ri=0.9, C_cubes=0.4, C_sqrd=0.25, mu_r=1.0, t_adjust=1.0, Ef_rw_l=True, Ef_sw_l=True)
+    p, f = mpo.as_arrays()
+    oracle.thompson_init(p, f)
+    try:
+        c = ideal.make_case(8, 8, 4)
+        d = single_image_domain(c)
+        opt = options_t(); opt.physics.microphysics = kMP_THOMPSON; opt.mp_options = mpo
+        mp_init(opt, d)
+        for name in TABLES:
+            a = device_table(d, name); b = oracle.thompson_table(name)
+            nb = int((a.view(np.int64) != b.view(np.int64)).sum())
+            assert nb == 0, f"{name}: {nb} of {a.size} entries differ"
+        d.close()
+        out, ref = run_case(oracle, mode=1, mp_options=mpo, **CASES["cold_graupel"])
+        assert ref["snow"].max() > 1e-4 and ref["graupel"].max() > 1e-5
+        check_close(out, ref, rtol=1e-5, frac_allowed=1e-4, label="alt/mode1")
+    finally:
+        po, fo = options_t().mp_options.as_arrays()
+        oracle.thompson_init(po, fo)
