@@ -214,3 +214,67 @@ def test_lut_interpolation_of_constant_and_no_lut_error(oracle):
     np.testing.assert_allclose(d.get("v"), 5.0 - 0.2 * 2.0, rtol=1e-6)
     np.testing.assert_allclose(d.get("nsquared"), 3e-5, rtol=1e-6)
     d.close()
+
+
+@pytest.mark.parametrize("windtype", [1, 5])
+def test_update_winds_linear_chain(oracle, windtype):
+    """update_winds end to end (wind.f90:289-360) with windtype kWIND_LINEAR (1) and kLINEAR_ITERATIVE_WINDS (5):
+    linear_perturb -> [iterative_winds] -> balance_uvw, first call on the winds, second call on dqdt_3d.
+    Bit-exact against the oracle chain in device-math mode."""
+    from icar_amd.wind import update_winds
+    nx, ny, nz, dx, iters = 48, 29, 10, 1000.0, 3
+    a = atmosphere(nx, ny, nz, seed=21, moist=True)
+    rng = np.random.default_rng(33)
+    opt = options_t()
+    opt.physics.windtype = windtype; opt.parameters.wind_iterations = iters
+    opt.lt_options = lt_options_type(buffer=3, n_dir_values=6, n_spd_values=4, n_nsq_values=3, stability_window_size=3,
+                                     vert_smooth=2, variable_N=True, smooth_nsq=True, linear_contribution=0.7,
+                                     linear_update_fraction=0.4)
+    lt = opt.lt_options
+    d = make_domain(nx, ny, nz, dx)
+    LW.setup_linwinds(d, opt, terrain(nx, ny), build=False)
+    ulut = rng.standard_normal((ny, nz, nx + 1, 3, 6, 4)).astype(np.float32)
+    vlut = rng.standard_normal((ny + 1, nz, nx, 3, 6, 4)).astype(np.float32)
+    LW.lut_upload(d, opt, 0, ulut); LW.lut_upload(d, opt, 1, vlut)
+    geo = dict(jacobian=rng.uniform(0.8, 1.2, (ny, nz, nx)), jacobian_u=rng.uniform(0.8, 1.2, (ny, nz, nx + 1)),
+               jacobian_v=rng.uniform(0.8, 1.2, (ny + 1, nz, nx)), jacobian_w=rng.uniform(0.8, 1.2, (ny, nz, nx)),
+               advection_dz=np.broadcast_to(a["dz"][None, :, None], (ny, nz, nx)) * rng.uniform(0.9, 1.1, (ny, nz, nx)))
+    geo = {k: np.ascontiguousarray(x, np.float32) for k, x in geo.items()}
+    for k in ("z", "potential_temperature", "exner", "water_vapor", "cloud_water_mass", "cloud_ice_mass", "rain_mass", "snow_mass", "u", "v"):
+        d.set(k, a[k])
+    for k, x in geo.items():
+        d.set(k, x)
+    lo, hi = lt.resolved()
+    dirv = W.linear_space(lt.dirmin, lt.dirmax, 6); spdv = W.linear_space(lt.spdmin, lt.spdmax, 4); nsqv = W.linear_space(lo, hi, 3)
+    o = dict(variable_N=True, smooth_nsq=True, N_squared=lt.N_squared, max_stability=lt.max_stability, min_stability=lt.min_stability,
+             linear_contribution=lt.linear_contribution, linear_update_fraction=lt.linear_update_fraction)
+    hyd = tuple(a[k] for k in ("cloud_water_mass", "cloud_ice_mass", "rain_mass", "snow_mass"))
+    g5 = (geo["jacobian_u"], geo["jacobian_v"], geo["jacobian_w"], geo["advection_dz"])
+    du = (0.05 * rng.standard_normal(a["u"].shape)).astype(np.float32) + a["u"]
+    dv = (0.05 * rng.standard_normal(a["v"].shape)).astype(np.float32) + a["v"]
+
+    def chain(u, v, up, vp):
+        oracle.spatial_winds(u, v, a["potential_temperature"], a["exner"], a["z"], a["water_vapor"], hyd, ulut, vlut,
+                             up, vp, o, dirv, spdv, nsqv, lt.vert_smooth, lt.stability_window_size)
+        if windtype == 5:
+            u, v, _ = oracle.iterative_winds(u, v, *g5, geo["jacobian"], dx, iters)
+        return u, v, oracle.balance_uvw(u, v, *g5, dx)
+
+    oracle.set_math_mode(1)
+    try:
+        up = np.zeros_like(a["u"]); vp = np.zeros_like(a["v"])
+        u1, v1, w1 = chain(a["u"].copy(), a["v"].copy(), up, vp)
+        u2, v2, w2 = chain(du.copy(), dv.copy(), up, vp)                # the perturbation state carries over (update fraction)
+    finally:
+        oracle.set_math_mode(0)
+    update_winds(d, opt)
+    for n, w in (("u", u1), ("v", v1), ("w", w1)):
+        g = d.get(n)
+        assert bits_equal(g, w), f"first call {n}: {(g != w).sum()} of {g.size} differ, max {abs(g - w).max()}"
+    d.set_dqdt("u", du); d.set_dqdt("v", dv)
+    update_winds(d, opt)
+    for n, w in (("u", u2), ("v", v2), ("w", w2)):
+        g = d.get_dqdt(n)
+        assert bits_equal(g, w), f"second call {n}: {(g != w).sum()} of {g.size} differ, max {abs(g - w).max()}"
+    assert bits_equal(d.get("u"), u1) and abs(u1 - a["u"]).max() > 0.05
+    d.close()
