@@ -334,18 +334,25 @@ k_mpdata_fluxes(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o, int
 // current one is evaluated, so two scalars' worth of loads overlap the ~270 VALU instructions of one evaluation.
 // Arithmetic: identical expressions in identical order -- results are bit-identical to k_mpdata_fluxes.
 // ------------------------------------------------------------------------------------------------
+// element of a REAL(4) array at `uniform base + 32-bit byte offset`: selects the saddr form of global_load / global_store
+// (no per-load 64-bit VALU address arithmetic).  A tile is far below 4 GiB.
+__device__ __forceinline__ float ldb(const float *__restrict__ p, unsigned b) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + b); }
+__device__ __forceinline__ void stb(float *__restrict__ p, unsigned b, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(p) + b) = v; }
+
 struct Stencil16 {
     float c0, xm, xp, yp, ym, xm_yp, xm_ym, xp_ym, zp, zm, xm_zp, xm_zm, xp_zp, zp_ym, zm_ym, zp_yp;
 };
-struct StencilOff { int xm, xp, yp, ym, zp, zm; };
+// y / z offsets (elements) are wave-uniform and fold into the scalar base pointer; the x offsets are per-lane BYTE offsets
+struct StencilOff { int yp, ym, zp, zm; unsigned b0, bxm, bxp; };
 
-__device__ __forceinline__ Stencil16 load_stencil(const float *__restrict__ q, int c, const StencilOff &o)
+__device__ __forceinline__ Stencil16 load_stencil(const float *__restrict__ q, const StencilOff &o)
 {
     Stencil16 s;
-    s.c0 = q[c]; s.xm = q[c + o.xm]; s.xp = q[c + o.xp]; s.yp = q[c + o.yp]; s.ym = q[c + o.ym];
-    s.xm_yp = q[c + o.xm + o.yp]; s.xm_ym = q[c + o.xm + o.ym]; s.xp_ym = q[c + o.xp + o.ym];
-    s.zp = q[c + o.zp]; s.zm = q[c + o.zm]; s.xm_zp = q[c + o.xm + o.zp]; s.xm_zm = q[c + o.xm + o.zm];
-    s.xp_zp = q[c + o.xp + o.zp]; s.zp_ym = q[c + o.zp + o.ym]; s.zm_ym = q[c + o.zm + o.ym]; s.zp_yp = q[c + o.zp + o.yp];
+    s.c0 = ldb(q, o.b0); s.xm = ldb(q, o.bxm); s.xp = ldb(q, o.bxp); s.yp = ldb(q + o.yp, o.b0); s.ym = ldb(q + o.ym, o.b0);
+    s.xm_yp = ldb(q + o.yp, o.bxm); s.xm_ym = ldb(q + o.ym, o.bxm); s.xp_ym = ldb(q + o.ym, o.bxp);
+    s.zp = ldb(q + o.zp, o.b0); s.zm = ldb(q + o.zm, o.b0); s.xm_zp = ldb(q + o.zp, o.bxm); s.xm_zm = ldb(q + o.zm, o.bxm);
+    s.xp_zp = ldb(q + o.zp, o.bxp); s.zp_ym = ldb(q + (o.zp + o.ym), o.b0); s.zm_ym = ldb(q + (o.zm + o.ym), o.b0);
+    s.zp_yp = ldb(q + (o.zp + o.yp), o.b0);
     return s;
 }
 
@@ -358,7 +365,7 @@ k_mpdata_fluxes_pipe(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o
 {
     const TileId tb = xcd_tile(4);
     const int i = tb.x * BX + threadIdx.x;
-    const int k = tb.y * BY + threadIdx.y;
+    const int k = tb.y * BY + __builtin_amdgcn_readfirstlane(threadIdx.y);     // BX == 64: a wave is one k
     const int j = tb.z;
     unsigned needmask = (nv >= 32) ? ~0u : ((1u << nv) - 1u);
     if (occ) {                                                      // see k_mpdata_fluxes
@@ -383,7 +390,7 @@ k_mpdata_fluxes_pipe(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o
     const bool k_in = (k > 0) && (k < d.nz - 1);
     const bool i_in = (i > 0) && (i < d.nx - 1);
     StencilOff o;
-    o.xm = has_u ? -1 : 0; o.xp = (i < d.nx - 1) ? 1 : 0;
+    o.b0 = 4u * (unsigned)c; o.bxm = has_u ? o.b0 - 4u : o.b0; o.bxp = (i < d.nx - 1) ? o.b0 + 4u : o.b0;
     o.ym = has_v ? -sj : 0; o.yp = (j < d.ny - 1) ? sj : 0;
     o.zm = (k > 0) ? -sk : 0; o.zp = has_w ? sk : 0;
 
@@ -424,11 +431,11 @@ k_mpdata_fluxes_pipe(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o
     unsigned active = needmask & all;
     if (!active) return;
     int m = __builtin_ctz(active); active &= active - 1;
-    Stencil16 s = load_stencil(qin.p[m], c, o);
+    Stencil16 s = load_stencil(qin.p[m], o);
     for (;;) {
         const int mn = active ? __builtin_ctz(active) : -1;
         Stencil16 nx_ = s;
-        if (mn >= 0) nx_ = load_stencil(qin.p[mn], c, o);            // in flight while scalar m is evaluated
+        if (mn >= 0) nx_ = load_stencil(qin.p[mn], o);            // in flight while scalar m is evaluated
         // ---- U face (i-1 | i) : adv_mpdata.f90:134-168
         float r_u2 = 0.0f;
         if (has_u) {
@@ -483,7 +490,7 @@ k_mpdata_fluxes_pipe(Dims d, CVarPtrs qin, VarPtrs u2o, VarPtrs v2o, VarPtrs w2o
             }
             r_w2 = val * 0.5f * dzc;
         }
-        u2o.p[m][c] = r_u2; v2o.p[m][c] = r_v2; w2o.p[m][c] = r_w2;
+        stb(u2o.p[m], o.b0, r_u2); stb(v2o.p[m], o.b0, r_v2); stb(w2o.p[m], o.b0, r_w2);
         if (mn < 0) break;
         s = nx_; m = mn; active &= active - 1;
     }
@@ -544,8 +551,12 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
 //   y : each thread marches FJB rows; the north face of row j is the south face of row j+1 and the
 //       j-direction neighbourhoods (q1, l, v2) roll through registers.
 // ------------------------------------------------------------------------------------------------
+#ifndef FBY
 #define FBY 8
+#endif
+#ifndef FJB
 #define FJB 8
+#endif
 template <bool RHO, bool FCT>
 __global__ void __launch_bounds__(64 * FBY)
 k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
@@ -553,7 +564,14 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
                 const unsigned char *__restrict__ needf, int fjb, int xrows)
 {
     __shared__ float s_wb[2][FBY][64];       // double-buffered by row parity: one barrier per row instead of two
-    const int lane = threadIdx.x, ty = threadIdx.y;
+    // jaco*rho and dz*jaco*rho of the thread's own FJB cells: computed by the first active scalar, re-used by the others.
+    // (Re-reading jaco / dz / rho per scalar missed in L2 every time -- a scalar's march lasts far longer than L2 keeps a
+    // line -- and was 0.75 GB of the kernel's 4.0 GB of fetch.)  Private slots: no barrier needed.
+    __shared__ float2 s_den[FJB][FBY][64];
+    bool den_ready = false;
+    // blockDim.x == 64: a wave is one ty, so everything derived from k is wave-uniform -- tell the compiler (readfirstlane)
+    // so that the level offsets fold into the scalar base pointers and the bottom/top branches are scalar branches.
+    const int lane = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const TileId tb = xcd_tile(xrows);
     const int i = 1 + tb.x * 63 + lane;
     const int k = tb.y * (FBY - 1) + ty;
@@ -566,6 +584,12 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     const bool bottom = (k == 0), top = (k == d.nz - 1);
     const int ic = in_i ? i : d.nx - 1, kc = in_k ? k : d.nz - 1;            // clamped => all loads stay in bounds
     const int cb = d.idx(ic, kc, 0);
+    // Addressing: every array is read at `uniform base pointer + per-lane 32-bit BYTE offset` (global_load saddr form),
+    // so a row costs four VALU address updates instead of a 64-bit add per load.  Lane-dependent are only the x clamps.
+    const bool xfirst = (ic - 1 == 0), xlast = (ic == d.nx - 1);
+    const int dxm2 = xfirst ? -4 : -8, dxp = xlast ? 0 : 4, dul = xfirst ? 0 : -4;
+    const bool zfirst = (kc - 1 <= 0), zlast = (kc == d.nz - 1);
+    const int ozm1 = bottom ? 0 : -sk, ozm2 = (kc >= 2) ? -2 * sk : ozm1, ozp = zlast ? 0 : sk;   // scalar
     unsigned rowctr = 0;                                          // rows processed by this block (block-uniform)
     unsigned needmask = ~0u;
     if (needf) {
@@ -584,34 +608,32 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
         const float *__restrict__ u2 = u2i.p[m];
         const float *__restrict__ v2 = v2i.p[m];
         const float *__restrict__ w2 = w2i.p[m];
+        float *__restrict__ o = out.p[m];
         // rolling y neighbourhood around row j: cells j-2..j+2, faces (j-1|j),(j|j+1),(j+1|j+2)
         float qm2 = 0, qm1, q0, qp1, qp2 = 0, lm2 = 0, lm1, l0, lp1, lp2 = 0, vm1 = 0, v0, vp1, vp2 = 0;
         float VS = 0, VN = 0;
+        unsigned bc = 4u * (unsigned)(cb + j0 * sj);
         {
-            const int c = cb + j0 * sj;
-            qm1 = q[c - sj]; q0 = q[c]; qp1 = q[c + sj]; lm1 = l[c - sj]; l0 = l[c]; lp1 = l[c + sj];
-            v0 = v2[c]; vp1 = v2[c + sj];
-            if (j0 - 2 >= 0) { qm2 = q[c - 2 * sj]; lm2 = l[c - 2 * sj]; vm1 = v2[c - sj]; }
+            qm1 = ldb(q - sj, bc); q0 = ldb(q, bc); qp1 = ldb(q + sj, bc);
+            lm1 = ldb(l - sj, bc); l0 = ldb(l, bc); lp1 = ldb(l + sj, bc);
+            v0 = ldb(v2, bc); vp1 = ldb(v2 + sj, bc);
+            if (j0 - 2 >= 0) { qm2 = ldb(q - 2 * sj, bc); lm2 = ldb(l - 2 * sj, bc); vm1 = ldb(v2 - sj, bc); }
             if (FCT) VS = fct_limit(qm2, qm1, q0, qp1, lm2, lm1, l0, lp1, vm1, v0, vp1, j0 - 1 == 0, false, false);
             else VS = v0;
         }
-        for (int j = j0; j <= j1; ++j) {
-            const int c = cb + j * sj;
+        for (int j = j0; j <= j1; ++j, bc += 4u * (unsigned)sj) {
             const bool lastn = (j + 1 == d.ny - 1);
             // ---- all loads of this row up front, unconditional (clamped offsets) so they overlap ----
             const int oj2 = lastn ? sj : 2 * sj;
-            qp2 = q[c + oj2]; lp2 = l[c + oj2]; vp2 = v2[c + oj2];
-            const bool xfirst = (ic - 1 == 0), xlast = (ic == d.nx - 1);
-            const int oxm = xfirst ? -1 : -2, oxp = xlast ? 0 : 1;
-            const float qxm2 = q[c + oxm], qxm1 = q[c - 1], qxp1 = q[c + oxp];
-            const float lxm2 = l[c + oxm], lxm1 = l[c - 1], lxp1 = l[c + oxp];
-            const float uxm = u2[c + (xfirst ? 0 : -1)], ux0 = u2[c], uxp = u2[c + oxp];
+            qp2 = ldb(q + oj2, bc); lp2 = ldb(l + oj2, bc); vp2 = ldb(v2 + oj2, bc);
+            const unsigned bxm2 = bc + (unsigned)dxm2, bxp = bc + (unsigned)dxp, bul = bc + (unsigned)dul;
+            const float qxm2 = ldb(q, bxm2), qxm1 = ldb(q - 1, bc), qxp1 = ldb(q, bxp);
+            const float lxm2 = ldb(l, bxm2), lxm1 = ldb(l - 1, bc), lxp1 = ldb(l, bxp);
+            const float uxm = ldb(u2, bul), ux0 = ldb(u2, bc), uxp = ldb(u2, bxp);
             // z: face (k-1|k); cells k-2,k-1,k,k+1 ; faces stored at the lower cell
-            const bool zfirst = (kc - 1 <= 0), zlast = (kc == d.nz - 1);
-            const int ozm1 = bottom ? 0 : -sk, ozm2 = (kc >= 2) ? -2 * sk : ozm1, ozp = zlast ? 0 : sk;
-            const float qzm2 = q[c + ozm2], qzm1 = q[c + ozm1], qzp1 = q[c + ozp];
-            const float lzm2 = l[c + ozm2], lzm1 = l[c + ozm1], lzp1 = l[c + ozp];
-            const float wzm = w2[c + ozm2], wz0 = w2[c + ozm1], wzp = w2[c];
+            const float qzm2 = ldb(q + ozm2, bc), qzm1 = ldb(q + ozm1, bc), qzp1 = ldb(q + ozp, bc);
+            const float lzm2 = ldb(l + ozm2, bc), lzm1 = ldb(l + ozm1, bc), lzp1 = ldb(l + ozp, bc);
+            const float wzm = ldb(w2 + ozm2, bc), wz0 = ldb(w2 + ozm1, bc), wzp = ldb(w2, bc);
             float UL = 0, WB = 0;
             if (FCT) {
                 if (wave_out) {
@@ -629,10 +651,17 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
             __syncthreads();
             const float WT = (top || ty == FBY - 1) ? 0.0f : s_wb[pb][ty + 1][lane];
             if (do_out) {
-                const float r = RHO ? rho[c] : 1.0f;
-                const float ja = jaco[c];
-                const float den_h = ja * r;
-                const float den_v = dz[c] * ja * r;
+                float den_h, den_v;
+                if (!den_ready) {
+                    const float r = RHO ? ldb(rho, bc) : 1.0f;
+                    const float ja = ldb(jaco, bc);
+                    den_h = ja * r;
+                    den_v = ldb(dz, bc) * ja * r;
+                    s_den[j - j0][ty][lane] = make_float2(den_h, den_v);
+                } else {
+                    const float2 t = s_den[j - j0][ty][lane];
+                    den_h = t.x; den_v = t.y;
+                }
                 const float f1r = flux1(q0, qxp1, UR);
                 const float f1l = flux1(qxm1, q0, UL);
                 const float f3 = flux1(q0, qp1, VN);
@@ -641,11 +670,12 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
                 if (bottom) qq = qq - fdiv(flux1(q0, qzp1, WT), den_v);
                 else if (top) qq = qq - fdiv(q0 * WT - flux1(qzm1, q0, WB), den_v);
                 else qq = qq - fdiv(flux1(q0, qzp1, WT) - flux1(qzm1, q0, WB), den_v);
-                out.p[m][c] = qq;
+                stb(o, bc, qq);
             }
             qm2 = qm1; qm1 = q0; q0 = qp1; qp1 = qp2; lm2 = lm1; lm1 = l0; l0 = lp1; lp1 = lp2;
             vm1 = v0; v0 = vp1; vp1 = vp2; VS = VN;
         }
+        den_ready = true;
     }
 }
 
@@ -779,7 +809,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     }
     // Occupancy of the pass-1 fields: hydrometeor fields are zero over large parts of the domain, and a row segment
     // (fluxes) / block (final pass) whose whole stencil is zero produces exact zeros -- skipped, wave/block-uniformly.
-    static const int fjb = getenv("ICAR_HIP_MPDATA_FJB") ? max(1, atoi(getenv("ICAR_HIP_MPDATA_FJB"))) : FJB;   // rows marched per block
+    static const int fjb = getenv("ICAR_HIP_MPDATA_FJB") ? min(FJB, max(1, atoi(getenv("ICAR_HIP_MPDATA_FJB")))) : FJB;   // rows marched per block (<= FJB: s_den)
     static const int xrows = getenv("ICAR_HIP_MPDATA_XROWS") ? max(1, atoi(getenv("ICAR_HIP_MPDATA_XROWS"))) : 2;   // j slabs per XCD turn
     const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + fjb - 1) / fjb), bf(64, FBY);
     const int nt = (int)g.x;
