@@ -158,7 +158,7 @@ k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
 // that, the unlimited velocity of every face the block touches is zero, fct_limit returns it unchanged and the final
 // donor-cell pass reproduces the (zero) pass-1 field.
 __global__ void k_occ_blocks(const unsigned char *__restrict__ occ, unsigned char *__restrict__ needf, int nt, int nx, int nz, int ny, int nv,
-                             int gx, int gy, int gz, int fby, int fjb)
+                             int gx, int gy, int gz, int fby, int fzs, int fjb)
 {
     // one wave per (scalar, block): the lanes stride over the (j, k, i-segment) entries of the block's neighbourhood
     const size_t t = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
@@ -168,7 +168,7 @@ __global__ void k_occ_blocks(const unsigned char *__restrict__ occ, unsigned cha
     const int m = (int)(t / nb); const size_t r = t % nb;
     const int bx = (int)(r % gx), by = (int)((r / gx) % gy), bz = (int)(r / ((size_t)gx * gy));
     const int i0 = max(1 + bx * 63 - 2, 0) / 64, i1 = min(1 + bx * 63 + 63 + 2, nx - 1) / 64;
-    const int k0 = max(by * (fby - 1) - 2, 0), k1 = min(by * (fby - 1) + fby - 1 + 2, nz - 1);
+    const int k0 = max(by * fzs - 2, 0), k1 = min(by * fzs + fby - 1 + 2, nz - 1);
     const int j0 = max(1 + bz * fjb - 2, 0), j1 = min(1 + bz * fjb + fjb - 1 + 2, ny - 1);
     const unsigned char *o = occ + (size_t)m * nt * nz * ny;
     const int ni = i1 - i0 + 1, nk = k1 - k0 + 1, tot = ni * nk * (j1 - j0 + 1);
@@ -557,13 +557,24 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
 #ifndef FJB
 #define FJB 8
 #endif
+// F2_NOBAR 0 (default): a wave limits the bottom face of its level, the top face comes from the wave above through LDS
+// (one barrier per row; k-chunks overlap by one level).
+// F2_NOBAR 1 (A/B build, profiles/micro/build_variant.py): every wave limits BOTH vertical faces itself -- one more
+// fct_limit per cell, but no LDS hand-over, no barrier and no overlap (FBY outputs per FBY waves).  Same VALU work per
+// output within 3 %; measured 1.00 ms against 0.96 ms: the per-row barrier is NOT what holds this kernel back.
+#ifndef F2_NOBAR
+#define F2_NOBAR 0
+#endif
+#define FZS (F2_NOBAR ? FBY : FBY - 1)
 template <bool RHO, bool FCT>
 __global__ void __launch_bounds__(64 * FBY)
 k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i, CVarPtrs w2i, VarPtrs out, int nv,
                 const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dz,
                 const unsigned char *__restrict__ needf, int fjb, int xrows)
 {
+#if !F2_NOBAR
     __shared__ float s_wb[2][FBY][64];       // double-buffered by row parity: one barrier per row instead of two
+#endif
     // jaco*rho and dz*jaco*rho of the thread's own FJB cells: computed by the first active scalar, re-used by the others.
     // (Re-reading jaco / dz / rho per scalar missed in L2 every time -- a scalar's march lasts far longer than L2 keeps a
     // line -- and was 0.75 GB of the kernel's 4.0 GB of fetch.)  Private slots: no barrier needed.
@@ -574,12 +585,12 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     const int lane = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const TileId tb = xcd_tile(xrows);
     const int i = 1 + tb.x * 63 + lane;
-    const int k = tb.y * (FBY - 1) + ty;
+    const int k = tb.y * FZS + ty;
     const int j0 = 1 + tb.z * fjb;
     const int j1 = min(j0 + fjb - 1, d.ny - 2);
     const int sk = d.sk, sj = d.sj;
     const bool in_i = (i <= d.nx - 1), in_k = (k <= d.nz - 1);
-    const bool wave_out = in_k && (ty <= FBY - 2 || k == d.nz - 1);          // wave-uniform
+    const bool wave_out = in_k && (F2_NOBAR || ty <= FBY - 2 || k == d.nz - 1);          // wave-uniform
     const bool do_out = wave_out && (lane <= 62) && (i <= d.nx - 2);
     const bool bottom = (k == 0), top = (k == d.nz - 1);
     const int ic = in_i ? i : d.nx - 1, kc = in_k ? k : d.nz - 1;            // clamped => all loads stay in bounds
@@ -590,7 +601,14 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     const int dxm2 = xfirst ? -4 : -8, dxp = xlast ? 0 : 4, dul = xfirst ? 0 : -4;
     const bool zfirst = (kc - 1 <= 0), zlast = (kc == d.nz - 1);
     const int ozm1 = bottom ? 0 : -sk, ozm2 = (kc >= 2) ? -2 * sk : ozm1, ozp = zlast ? 0 : sk;   // scalar
+    const int ozp2 = (kc + 2 <= d.nz - 1) ? 2 * sk : ozp;
+    // the level offsets as (wrapping) byte offsets added to the lane offset: five VALU adds per row, but one scalar
+    // base pointer per array instead of one per array and level (those did not fit the SGPR file)
+    const unsigned zb_m2 = 4u * (unsigned)ozm2, zb_m1 = 4u * (unsigned)ozm1, zb_p = 4u * (unsigned)ozp, zb_p2 = 4u * (unsigned)ozp2;
+    const bool ztop1 = (kc + 1 == d.nz - 1);
+#if !F2_NOBAR
     unsigned rowctr = 0;                                          // rows processed by this block (block-uniform)
+#endif
     unsigned needmask = ~0u;
     if (needf) {
         const size_t nblk = (size_t)gridDim.x * gridDim.y * gridDim.z, blk = tb.x + (size_t)gridDim.x * (tb.y + (size_t)gridDim.y * tb.z);
@@ -631,9 +649,15 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
             const float lxm2 = ldb(l, bxm2), lxm1 = ldb(l - 1, bc), lxp1 = ldb(l, bxp);
             const float uxm = ldb(u2, bul), ux0 = ldb(u2, bc), uxp = ldb(u2, bxp);
             // z: face (k-1|k); cells k-2,k-1,k,k+1 ; faces stored at the lower cell
-            const float qzm2 = ldb(q + ozm2, bc), qzm1 = ldb(q + ozm1, bc), qzp1 = ldb(q + ozp, bc);
-            const float lzm2 = ldb(l + ozm2, bc), lzm1 = ldb(l + ozm1, bc), lzp1 = ldb(l + ozp, bc);
-            const float wzm = ldb(w2 + ozm2, bc), wz0 = ldb(w2 + ozm1, bc), wzp = ldb(w2, bc);
+            const unsigned bzm2 = bc + zb_m2, bzm1 = bc + zb_m1, bzp = bc + zb_p;
+            const float qzm2 = ldb(q, bzm2), qzm1 = ldb(q, bzm1), qzp1 = ldb(q, bzp);
+            const float lzm2 = ldb(l, bzm2), lzm1 = ldb(l, bzm1), lzp1 = ldb(l, bzp);
+            const float wzm = ldb(w2, bzm2), wz0 = ldb(w2, bzm1), wzp = ldb(w2, bc);
+#if F2_NOBAR
+            const unsigned bzp2 = bc + zb_p2;
+            const float qzp2 = ldb(q, bzp2), lzp2 = ldb(l, bzp2), wzpp = ldb(w2, bzp);
+            float WT = 0;
+#endif
             float UL = 0, WB = 0;
             if (FCT) {
                 if (wave_out) {
@@ -641,15 +665,24 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
                     UL = fct_limit(qxm2, qxm1, q0, qxp1, lxm2, lxm1, l0, lxp1, uxm, ux0, uxp, xfirst, xlast, false);
                 }
                 if (!bottom) WB = fct_limit(qzm2, qzm1, q0, qzp1, lzm2, lzm1, l0, lzp1, wzm, wz0, wzp, zfirst, zlast, true);
+#if F2_NOBAR
+                // face (k|k+1) == the bottom face of level k+1: the same call one level up
+                if (!top) WT = fct_limit(qzm1, q0, qzp1, qzp2, lzm1, l0, lzp1, lzp2, wz0, wzp, wzpp, bottom, ztop1, true);
+#endif
             } else {
                 VN = vp1; UL = ux0;
                 if (!bottom) WB = wz0;
+#if F2_NOBAR
+                if (!top) WT = wzp;
+#endif
             }
             const float UR = __shfl_down(UL, 1);
+#if !F2_NOBAR
             const int pb = (int)((rowctr++) & 1u);     // the buffer written two rows ago is free: everyone passed a barrier since
             s_wb[pb][ty][lane] = WB;
             __syncthreads();
             const float WT = (top || ty == FBY - 1) ? 0.0f : s_wb[pb][ty + 1][lane];
+#endif
             if (do_out) {
                 float den_h, den_v;
                 if (!den_ready) {
@@ -811,7 +844,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     // (fluxes) / block (final pass) whose whole stencil is zero produces exact zeros -- skipped, wave/block-uniformly.
     static const int fjb = getenv("ICAR_HIP_MPDATA_FJB") ? min(FJB, max(1, atoi(getenv("ICAR_HIP_MPDATA_FJB")))) : FJB;   // rows marched per block (<= FJB: s_den)
     static const int xrows = getenv("ICAR_HIP_MPDATA_XROWS") ? max(1, atoi(getenv("ICAR_HIP_MPDATA_XROWS"))) : 2;   // j slabs per XCD turn
-    const dim3 gf((c->d.nx - 1 + 62) / 63, (c->d.nz - 1 + FBY - 2) / (FBY - 1), (c->d.ny - 2 + fjb - 1) / fjb), bf(64, FBY);
+    const dim3 gf((c->d.nx - 1 + 62) / 63, (F2_NOBAR ? c->d.nz + FBY - 1 : c->d.nz - 1 + FBY - 2) / FZS, (c->d.ny - 2 + fjb - 1) / fjb), bf(64, FBY);
     const int nt = (int)g.x;
     const size_t occ_n = (size_t)ICAR_MAX_ADV * nt * c->d.nz * c->d.ny, nf_n = (size_t)ICAR_MAX_ADV * gf.x * gf.y * gf.z;
     static const bool no_skip = getenv("ICAR_HIP_MPDATA_NO_SKIP") != nullptr;      // A/B switch for profiling
@@ -826,7 +859,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     if (occ) {
         const size_t n2 = (size_t)n * gf.x * gf.y * gf.z;
         hipLaunchKernelGGL(k_occ_blocks, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, c->stream, occ, c->needf, nt, c->d.nx, c->d.nz, c->d.ny, n,
-                           (int)gf.x, (int)gf.y, (int)gf.z, FBY, fjb);
+                           (int)gf.x, (int)gf.y, (int)gf.z, FBY, FZS, fjb);
     }
     for (int iord = 2; iord <= order; ++iord) {
         // the flags describe the pass-1 field of the first corrective iteration only
