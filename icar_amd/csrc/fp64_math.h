@@ -2,6 +2,38 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// fma(a, b, C) / fma(-a, C, c) with a compile-time constant C held in an SGPR pair.  Left to itself the compiler turns a
+// Horner step into `v_mov_b32 x2 ; v_fmac_f64` (the VOP2 form wants the addend in the destination VGPR, and a 64-bit
+// literal cannot be an operand on gfx9): three VALU issues instead of one.  The "s" constraint materialises C with two
+// s_mov_b32 on the scalar pipe instead.  Same operation, same rounding.
+// Measured on k_thompson_pack (profiles/micro, -DICAR_FMA_SC=1): VALU instructions -12 % (1.36e9 -> 1.20e9 per launch),
+// SALU +36 %, bit-identical results -- and the same number of cycles: that kernel is bound by the dependent-issue
+// latency of each wave's instruction stream at 4 waves per SIMD, not by VALU throughput.
+// Off by default: no gain, and plain fma() leaves the scheduling to the compiler.
+#ifndef ICAR_FMA_SC
+#define ICAR_FMA_SC 0
+#endif
+__device__ __forceinline__ double fma_sc(double a, double b, double C)
+{
+#if ICAR_FMA_SC
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(C));
+    return r;
+#else
+    return fma(a, b, C);
+#endif
+}
+__device__ __forceinline__ double fnma_sc(double a, double C, double c)       // fma(-a, C, c)
+{
+#if ICAR_FMA_SC
+    double r;
+    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "s"(C), "v"(c));
+    return r;
+#else
+    return fma(-a, C, c);
+#endif
+}
+
 // Natural log of a positive finite double in ~38 instructions (ocml's log(double) is ~95: it carries a double-double
 // result that a value about to be rounded to REAL(4) does not need).  Classic reduction x = 2^k m, m in [sqrt(1/2),
 // sqrt(2)), s = f/(2+f) with f = m-1, log(m) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the 7-term minimax R of
@@ -26,8 +58,8 @@ __device__ __forceinline__ double d_log(double x)
     double s = f * r;
     s = fma(fma(-d, s, f), r, s);
     const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double t1 = w * fma_sc(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_sc(w, fma_sc(w, fma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
     return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
@@ -38,13 +70,13 @@ __device__ __forceinline__ double d_exp(double x)
 {
     const double invln2 = 1.44269504088896338700e+00, ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double k = rint(x * invln2);
-    double r = fma(-k, ln2_hi, x);
-    r = fma(-k, ln2_lo, r);
+    double r = fnma_sc(k, ln2_hi, x);
+    r = fnma_sc(k, ln2_lo, r);
     double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0); p = fma(p, r, 1.0 / 39916800.0); p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);    p = fma(p, r, 1.0 / 40320.0);    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);       p = fma(p, r, 1.0 / 120.0);      p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);         p = fma(p, r, 0.5);              p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0 / 479001600.0);    p = fma_sc(p, r, 1.0 / 39916800.0); p = fma_sc(p, r, 1.0 / 3628800.0);
+    p = fma_sc(p, r, 1.0 / 362880.0);    p = fma_sc(p, r, 1.0 / 40320.0);    p = fma_sc(p, r, 1.0 / 5040.0);
+    p = fma_sc(p, r, 1.0 / 720.0);       p = fma_sc(p, r, 1.0 / 120.0);      p = fma_sc(p, r, 1.0 / 24.0);
+    p = fma_sc(p, r, 1.0 / 6.0);         p = fma(p, r, 0.5);                 p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return __builtin_amdgcn_ldexp(p, (int)k);
 }

@@ -1101,7 +1101,16 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 struct ThTiles { int n, i0[4], i1[4], j0[4], ib0[4], nbx[4], off[5], xcd_run; };
 
 // cpb whole columns per block (aligned to multiples of cpb in i), thread = level*cpb + column (thompson_lane.inc: BlockComm)
-__global__ void __launch_bounds__(1024, 4)      // any block size <= 1024; register budget for 4 waves per SIMD (128 VGPRs)
+#ifndef TH_PACK_MINW
+#define TH_PACK_MINW 4
+#endif
+#ifndef TH_PACK_ATTR
+#define TH_PACK_ATTR
+#endif
+#ifndef TH_PACK_MAXT
+#define TH_PACK_MAXT 1024
+#endif
+__global__ void __launch_bounds__(TH_PACK_MAXT, TH_PACK_MINW) TH_PACK_ATTR      // any block size <= 1024; register budget for 4 waves per SIMD (128 VGPRs)
 k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,

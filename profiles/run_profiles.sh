@@ -6,13 +6,13 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 O=gpurun_out/r01; rm -rf $O; mkdir -p $O
-python bench.py > $O/bench_line.json 2> $O/bench.err
+timeout 400 python bench.py > $O/bench_line.json 2> $O/bench.err
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $O/trace -- $B > $O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- $B > $O/trace.log 2>&1
 P="python bench.py --steps 4 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o p -- $P > $O/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $P > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $P > $O/pmc_write.log 2>&1
-python profiles/prof_winds.py > $O/winds.json 2> $O/winds.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o p -- $P > $O/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $P > $O/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $P > $O/pmc_write.log 2>&1
+timeout 300 python profiles/prof_winds.py > $O/winds.json 2> $O/winds.err
 ls -R $O | head -40
 tail -c 600 $O/bench_line.json
