@@ -565,6 +565,12 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
 #ifndef F2_NOBAR
 #define F2_NOBAR 0
 #endif
+// F2_XSHFL 1 (A/B build): x neighbours from the neighbouring lanes' registers, lanes 0, 1, 63 load theirs.  Bit-identical,
+// 1.11 ms against 0.97 ms: the divergent three-lane loads cost more than the eight full-wave loads they replace.  (Upper
+// bounds from timing-only builds with wrong edges: no x-neighbour loads 0.90 ms, no z-neighbour loads 0.89 ms, neither 0.84 ms.)
+#ifndef F2_XSHFL
+#define F2_XSHFL 0
+#endif
 #define FZS (F2_NOBAR ? FBY : FBY - 1)
 template <bool RHO, bool FCT>
 __global__ void __launch_bounds__(64 * FBY)
@@ -645,9 +651,27 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
             const int oj2 = lastn ? sj : 2 * sj;
             qp2 = ldb(q + oj2, bc); lp2 = ldb(l + oj2, bc); vp2 = ldb(v2 + oj2, bc);
             const unsigned bxm2 = bc + (unsigned)dxm2, bxp = bc + (unsigned)dxp, bul = bc + (unsigned)dul;
+#if F2_XSHFL
+            // x neighbours of q, l, u2 come from the neighbouring lanes' registers (q0 / l0 were loaded two rows ago as the
+            // j+2 values, ux0 is this row's own load); only lanes 0, 1 and 63 -- whose neighbours belong to the adjacent
+            // tiles -- load: 5 three-lane loads instead of 8 full-wave ones.
+            const float ux0 = ldb(u2, bc);
+            float qxm2 = __shfl_up(q0, 2), qxm1 = __shfl_up(q0, 1), qxp1 = __shfl_down(q0, 1);
+            float lxm2 = __shfl_up(l0, 2), lxm1 = __shfl_up(l0, 1), lxp1 = __shfl_down(l0, 1);
+            float uxm = __shfl_up(ux0, 1), uxp = __shfl_down(ux0, 1);
+            if (lane < 2 || lane == 63) {
+                const bool hi = (lane == 63);
+                const unsigned be = hi ? bxp : bxm2;
+                const float eq = ldb(q, be), el = ldb(l, be), eu = ldb(u2, hi ? bxp : bul);
+                if (hi) { qxp1 = eq; lxp1 = el; uxp = eu; }
+                else    { qxm2 = eq; lxm2 = el; }
+                if (lane == 0) { qxm1 = ldb(q - 1, bc); lxm1 = ldb(l - 1, bc); uxm = eu; }
+            }
+#else
             const float qxm2 = ldb(q, bxm2), qxm1 = ldb(q - 1, bc), qxp1 = ldb(q, bxp);
             const float lxm2 = ldb(l, bxm2), lxm1 = ldb(l - 1, bc), lxp1 = ldb(l, bxp);
             const float uxm = ldb(u2, bul), ux0 = ldb(u2, bc), uxp = ldb(u2, bxp);
+#endif
             // z: face (k-1|k); cells k-2,k-1,k,k+1 ; faces stored at the lower cell
             const unsigned bzm2 = bc + zb_m2, bzm1 = bc + zb_m1, bzp = bc + zb_p;
             const float qzm2 = ldb(q, bzm2), qzm1 = ldb(q, bzm1), qzp1 = ldb(q, bzp);
