@@ -158,7 +158,7 @@ k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
 // that, the unlimited velocity of every face the block touches is zero, fct_limit returns it unchanged and the final
 // donor-cell pass reproduces the (zero) pass-1 field.
 __global__ void k_occ_blocks(const unsigned char *__restrict__ occ, unsigned char *__restrict__ needf, int nt, int nx, int nz, int ny, int nv,
-                             int gx, int gy, int gz, int fby, int fzs, int fjb)
+                             int gx, int gy, int gz, int fby, int fzs, int fjb, int xout)
 {
     // one wave per (scalar, block): the lanes stride over the (j, k, i-segment) entries of the block's neighbourhood
     const size_t t = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
@@ -167,7 +167,7 @@ __global__ void k_occ_blocks(const unsigned char *__restrict__ occ, unsigned cha
     if (t >= nb * nv) return;
     const int m = (int)(t / nb); const size_t r = t % nb;
     const int bx = (int)(r % gx), by = (int)((r / gx) % gy), bz = (int)(r / ((size_t)gx * gy));
-    const int i0 = max(1 + bx * 63 - 2, 0) / 64, i1 = min(1 + bx * 63 + 63 + 2, nx - 1) / 64;
+    const int i0 = max(1 + bx * xout - 2, 0) / 64, i1 = min(1 + bx * xout + xout + 2, nx - 1) / 64;
     const int k0 = max(by * fzs - 2, 0), k1 = min(by * fzs + fby - 1 + 2, nz - 1);
     const int j0 = max(1 + bz * fjb - 2, 0), j1 = min(1 + bz * fjb + fjb - 1 + 2, ny - 1);
     const unsigned char *o = occ + (size_t)m * nt * nz * ny;
@@ -565,12 +565,18 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
 #ifndef F2_NOBAR
 #define F2_NOBAR 0
 #endif
-// F2_XSHFL 1 (A/B build): x neighbours from the neighbouring lanes' registers, lanes 0, 1, 63 load theirs.  Bit-identical,
-// 1.11 ms against 0.97 ms: the divergent three-lane loads cost more than the eight full-wave loads they replace.  (Upper
-// bounds from timing-only builds with wrong edges: no x-neighbour loads 0.90 ms, no z-neighbour loads 0.89 ms, neither 0.84 ms.)
+// F2_XSHFL 1: the x neighbours of q, l and u2 come from the neighbouring lanes' registers (q0 / l0 were loaded two rows
+// earlier as the j+2 values, ux0 is the row's own load) instead of eight more loads per row that mostly missed the L1.
+// Lanes 0, 1 and 63 are halo lanes (they only supply values): 60 outputs per 64 lanes instead of 63.
+// F2_XSHFL 0: 63 outputs per 64 lanes, every lane loads its own x neighbours.
+// (A first shuffle version kept 63 outputs and let lanes 0, 1, 63 load their neighbours: bit-identical, 1.11 ms against
+// 0.97 ms -- the divergent three-lane loads cost more than the eight full-wave loads they replaced.)
 #ifndef F2_XSHFL
-#define F2_XSHFL 0
+#define F2_XSHFL 1
 #endif
+#define F2_XOUT (F2_XSHFL ? 60 : 63)
+#define F2_XL (F2_XSHFL ? 2 : 0)
+#define F2_GX(nx) (F2_XSHFL ? ((nx) - 2 + F2_XOUT - 1) / F2_XOUT : ((nx) - 1 + 62) / 63)
 #define FZS (F2_NOBAR ? FBY : FBY - 1)
 template <bool RHO, bool FCT>
 __global__ void __launch_bounds__(64 * FBY)
@@ -590,28 +596,35 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     // so that the level offsets fold into the scalar base pointers and the bottom/top branches are scalar branches.
     const int lane = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const TileId tb = xcd_tile(xrows);
-    const int i = 1 + tb.x * 63 + lane;
+    const int i = 1 + tb.x * F2_XOUT + lane - F2_XL;
     const int k = tb.y * FZS + ty;
     const int j0 = 1 + tb.z * fjb;
     const int j1 = min(j0 + fjb - 1, d.ny - 2);
     const int sk = d.sk, sj = d.sj;
     const bool in_i = (i <= d.nx - 1), in_k = (k <= d.nz - 1);
     const bool wave_out = in_k && (F2_NOBAR || ty <= FBY - 2 || k == d.nz - 1);          // wave-uniform
-    const bool do_out = wave_out && (lane <= 62) && (i <= d.nx - 2);
+    const bool do_out = wave_out && (lane >= F2_XL) && (lane <= F2_XL + F2_XOUT - 1) && (i <= d.nx - 2);
     const bool bottom = (k == 0), top = (k == d.nz - 1);
-    const int ic = in_i ? i : d.nx - 1, kc = in_k ? k : d.nz - 1;            // clamped => all loads stay in bounds
+    const int ic = in_i ? max(i, 0) : d.nx - 1, kc = in_k ? k : d.nz - 1;    // clamped => all loads stay in bounds
     const int cb = d.idx(ic, kc, 0);
     // Addressing: every array is read at `uniform base pointer + per-lane 32-bit BYTE offset` (global_load saddr form),
     // so a row costs four VALU address updates instead of a 64-bit add per load.  Lane-dependent are only the x clamps.
     const bool xfirst = (ic - 1 == 0), xlast = (ic == d.nx - 1);
+#if !F2_XSHFL
     const int dxm2 = xfirst ? -4 : -8, dxp = xlast ? 0 : 4, dul = xfirst ? 0 : -4;
+#endif
     const bool zfirst = (kc - 1 <= 0), zlast = (kc == d.nz - 1);
     const int ozm1 = bottom ? 0 : -sk, ozm2 = (kc >= 2) ? -2 * sk : ozm1, ozp = zlast ? 0 : sk;   // scalar
     const int ozp2 = (kc + 2 <= d.nz - 1) ? 2 * sk : ozp;
     // the level offsets as (wrapping) byte offsets added to the lane offset: five VALU adds per row, but one scalar
     // base pointer per array instead of one per array and level (those did not fit the SGPR file)
-    const unsigned zb_m2 = 4u * (unsigned)ozm2, zb_m1 = 4u * (unsigned)ozm1, zb_p = 4u * (unsigned)ozp, zb_p2 = 4u * (unsigned)ozp2;
+    const unsigned zb_m2 = 4u * (unsigned)ozm2, zb_m1 = 4u * (unsigned)ozm1, zb_p = 4u * (unsigned)ozp;
+#if F2_NOBAR
+    const unsigned zb_p2 = 4u * (unsigned)ozp2;
     const bool ztop1 = (kc + 1 == d.nz - 1);
+#else
+    (void)ozp2;
+#endif
 #if !F2_NOBAR
     unsigned rowctr = 0;                                          // rows processed by this block (block-uniform)
 #endif
@@ -650,23 +663,15 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
             // ---- all loads of this row up front, unconditional (clamped offsets) so they overlap ----
             const int oj2 = lastn ? sj : 2 * sj;
             qp2 = ldb(q + oj2, bc); lp2 = ldb(l + oj2, bc); vp2 = ldb(v2 + oj2, bc);
+#if !F2_XSHFL
             const unsigned bxm2 = bc + (unsigned)dxm2, bxp = bc + (unsigned)dxp, bul = bc + (unsigned)dul;
+#endif
 #if F2_XSHFL
-            // x neighbours of q, l, u2 come from the neighbouring lanes' registers (q0 / l0 were loaded two rows ago as the
-            // j+2 values, ux0 is this row's own load); only lanes 0, 1 and 63 -- whose neighbours belong to the adjacent
-            // tiles -- load: 5 three-lane loads instead of 8 full-wave ones.
+            // values differ from the loaded ones only where fct_limit ignores them (first / last cell of a line)
             const float ux0 = ldb(u2, bc);
-            float qxm2 = __shfl_up(q0, 2), qxm1 = __shfl_up(q0, 1), qxp1 = __shfl_down(q0, 1);
-            float lxm2 = __shfl_up(l0, 2), lxm1 = __shfl_up(l0, 1), lxp1 = __shfl_down(l0, 1);
-            float uxm = __shfl_up(ux0, 1), uxp = __shfl_down(ux0, 1);
-            if (lane < 2 || lane == 63) {
-                const bool hi = (lane == 63);
-                const unsigned be = hi ? bxp : bxm2;
-                const float eq = ldb(q, be), el = ldb(l, be), eu = ldb(u2, hi ? bxp : bul);
-                if (hi) { qxp1 = eq; lxp1 = el; uxp = eu; }
-                else    { qxm2 = eq; lxm2 = el; }
-                if (lane == 0) { qxm1 = ldb(q - 1, bc); lxm1 = ldb(l - 1, bc); uxm = eu; }
-            }
+            const float qxm2 = __shfl_up(q0, 2), qxm1 = __shfl_up(q0, 1), qxp1 = __shfl_down(q0, 1);
+            const float lxm2 = __shfl_up(l0, 2), lxm1 = __shfl_up(l0, 1), lxp1 = __shfl_down(l0, 1);
+            const float uxm = __shfl_up(ux0, 1), uxp = __shfl_down(ux0, 1);
 #else
             const float qxm2 = ldb(q, bxm2), qxm1 = ldb(q - 1, bc), qxp1 = ldb(q, bxp);
             const float lxm2 = ldb(l, bxm2), lxm1 = ldb(l - 1, bc), lxp1 = ldb(l, bxp);
@@ -798,7 +803,7 @@ int icar_advect_occupancy(icar_hip_ctx *c, int n, float *frac_fluxes, float *fra
     if (!c->occ) { icar_set_error("advect_occupancy: no MPDATA call with occupancy flags yet"); return 1; }
     const int nt = (c->d.nx + BX - 1) / BX, nz = c->d.nz, ny = c->d.ny;
     const size_t per1 = (size_t)nt * nz * ny;
-    const size_t perf = (size_t)((c->d.nx - 1 + 62) / 63) * ((nz - 1 + 8 - 2) / (8 - 1)) * ((ny - 2 + 8 - 1) / 8);
+    const size_t perf = (size_t)F2_GX(c->d.nx) * ((F2_NOBAR ? nz + FBY - 1 : nz - 1 + FBY - 2) / FZS) * ((ny - 2 + FJB - 1) / FJB);
     std::vector<unsigned char> h1(per1 * n), hf(perf * n);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(h1.data(), c->occ, h1.size(), hipMemcpyDeviceToHost));
@@ -868,7 +873,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     // (fluxes) / block (final pass) whose whole stencil is zero produces exact zeros -- skipped, wave/block-uniformly.
     static const int fjb = getenv("ICAR_HIP_MPDATA_FJB") ? min(FJB, max(1, atoi(getenv("ICAR_HIP_MPDATA_FJB")))) : FJB;   // rows marched per block (<= FJB: s_den)
     static const int xrows = getenv("ICAR_HIP_MPDATA_XROWS") ? max(1, atoi(getenv("ICAR_HIP_MPDATA_XROWS"))) : 2;   // j slabs per XCD turn
-    const dim3 gf((c->d.nx - 1 + 62) / 63, (F2_NOBAR ? c->d.nz + FBY - 1 : c->d.nz - 1 + FBY - 2) / FZS, (c->d.ny - 2 + fjb - 1) / fjb), bf(64, FBY);
+    const dim3 gf(F2_GX(c->d.nx), (F2_NOBAR ? c->d.nz + FBY - 1 : c->d.nz - 1 + FBY - 2) / FZS, (c->d.ny - 2 + fjb - 1) / fjb), bf(64, FBY);
     const int nt = (int)g.x;
     const size_t occ_n = (size_t)ICAR_MAX_ADV * nt * c->d.nz * c->d.ny, nf_n = (size_t)ICAR_MAX_ADV * gf.x * gf.y * gf.z;
     static const bool no_skip = getenv("ICAR_HIP_MPDATA_NO_SKIP") != nullptr;      // A/B switch for profiling
@@ -883,7 +888,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     if (occ) {
         const size_t n2 = (size_t)n * gf.x * gf.y * gf.z;
         hipLaunchKernelGGL(k_occ_blocks, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, c->stream, occ, c->needf, nt, c->d.nx, c->d.nz, c->d.ny, n,
-                           (int)gf.x, (int)gf.y, (int)gf.z, FBY, FZS, fjb);
+                           (int)gf.x, (int)gf.y, (int)gf.z, FBY, FZS, fjb, F2_XOUT);
     }
     for (int iord = 2; iord <= order; ++iord) {
         // the flags describe the pass-1 field of the first corrective iteration only
