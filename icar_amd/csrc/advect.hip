@@ -574,6 +574,15 @@ __device__ __forceinline__ float fct_limit(float qm1, float q0, float q1, float 
 #ifndef F2_XSHFL
 #define F2_XSHFL 1
 #endif
+// F2_ZLDS 1: the z neighbours of q, l and w2 (levels k-2, k-1, k+1) come from the neighbouring waves through LDS -- each wave
+// publishes its own row-ahead values (q, l at j+1 are already in its rolling registers) before the row's barrier -- and
+// only the waves at the bottom / top of a block's k-chunk load theirs.  Interior waves: 5 loads per row instead of 13.
+// A/B build only: bit-identical but slower than the loads it replaces -- 0.95 ms with the full denominator cache (48 kB of
+// LDS: 3 blocks per CU), 0.98 ms with half of it (32 kB, jaco re-read), against 0.90 ms; the kernel then needs 67 VGPRs and
+// spills 11 SGPRs, and forcing 64 VGPRs spills 43 SGPRs.
+#ifndef F2_ZLDS
+#define F2_ZLDS 0
+#endif
 #define F2_XOUT (F2_XSHFL ? 60 : 63)
 #define F2_XL (F2_XSHFL ? 2 : 0)
 #define F2_GX(nx) (F2_XSHFL ? ((nx) - 2 + F2_XOUT - 1) / F2_XOUT : ((nx) - 1 + 62) / 63)
@@ -590,7 +599,14 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
     // jaco*rho and dz*jaco*rho of the thread's own FJB cells: computed by the first active scalar, re-used by the others.
     // (Re-reading jaco / dz / rho per scalar missed in L2 every time -- a scalar's march lasts far longer than L2 keeps a
     // line -- and was 0.75 GB of the kernel's 4.0 GB of fetch.)  Private slots: no barrier needed.
+#if F2_ZLDS      // 4 blocks per CU leave 40 kB each: with the 12 kB of s_z only dz*jaco*rho is cached, jaco (rho) is re-read
+    __shared__ float s_den[FJB][FBY][64];
+#else
     __shared__ float2 s_den[FJB][FBY][64];
+#endif
+#if F2_ZLDS
+    __shared__ float s_z[2][3][FBY][64];     // [row parity][q, l, w2][wave][lane]
+#endif
     bool den_ready = false;
     // blockDim.x == 64: a wave is one ty, so everything derived from k is wave-uniform -- tell the compiler (readfirstlane)
     // so that the level offsets fold into the scalar base pointers and the bottom/top branches are scalar branches.
@@ -658,6 +674,11 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
             if (FCT) VS = fct_limit(qm2, qm1, q0, qp1, lm2, lm1, l0, lp1, vm1, v0, vp1, j0 - 1 == 0, false, false);
             else VS = v0;
         }
+#if F2_ZLDS
+        float wcur = ldb(w2, bc);                                // w2 of the own level, row j0
+        { const int p0 = (int)(rowctr & 1u); s_z[p0][0][ty][lane] = q0; s_z[p0][1][ty][lane] = l0; s_z[p0][2][ty][lane] = wcur; }
+        __syncthreads();
+#endif
         for (int j = j0; j <= j1; ++j, bc += 4u * (unsigned)sj) {
             const bool lastn = (j + 1 == d.ny - 1);
             // ---- all loads of this row up front, unconditional (clamped offsets) so they overlap ----
@@ -679,9 +700,22 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
 #endif
             // z: face (k-1|k); cells k-2,k-1,k,k+1 ; faces stored at the lower cell
             const unsigned bzm2 = bc + zb_m2, bzm1 = bc + zb_m1, bzp = bc + zb_p;
+#if F2_ZLDS
+            const int pz = (int)(rowctr & 1u);
+            const float wzp = wcur;
+            const float wnext = ldb(w2 + sj, bc);                // row j+1 (<= ny-1), published below for the next row
+            float qzm2, qzm1, qzp1, lzm2, lzm1, lzp1, wzm, wz0;
+            if (ty >= 2) { qzm2 = s_z[pz][0][ty - 2][lane]; lzm2 = s_z[pz][1][ty - 2][lane]; wzm = s_z[pz][2][ty - 2][lane]; }
+            else         { qzm2 = ldb(q, bzm2); lzm2 = ldb(l, bzm2); wzm = ldb(w2, bzm2); }
+            if (ty >= 1) { qzm1 = s_z[pz][0][ty - 1][lane]; lzm1 = s_z[pz][1][ty - 1][lane]; wz0 = s_z[pz][2][ty - 1][lane]; }
+            else         { qzm1 = ldb(q, bzm1); lzm1 = ldb(l, bzm1); wz0 = ldb(w2, bzm1); }
+            if (ty <= FBY - 2) { qzp1 = s_z[pz][0][ty + 1][lane]; lzp1 = s_z[pz][1][ty + 1][lane]; }
+            else               { qzp1 = ldb(q, bzp); lzp1 = ldb(l, bzp); }
+#else
             const float qzm2 = ldb(q, bzm2), qzm1 = ldb(q, bzm1), qzp1 = ldb(q, bzp);
             const float lzm2 = ldb(l, bzm2), lzm1 = ldb(l, bzm1), lzp1 = ldb(l, bzp);
             const float wzm = ldb(w2, bzm2), wz0 = ldb(w2, bzm1), wzp = ldb(w2, bc);
+#endif
 #if F2_NOBAR
             const unsigned bzp2 = bc + zb_p2;
             const float qzp2 = ldb(q, bzp2), lzp2 = ldb(l, bzp2), wzpp = ldb(w2, bzp);
@@ -709,11 +743,23 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
 #if !F2_NOBAR
             const int pb = (int)((rowctr++) & 1u);     // the buffer written two rows ago is free: everyone passed a barrier since
             s_wb[pb][ty][lane] = WB;
+#if F2_ZLDS
+            s_z[pb ^ 1][0][ty][lane] = qp1; s_z[pb ^ 1][1][ty][lane] = lp1; s_z[pb ^ 1][2][ty][lane] = wnext;
+#endif
             __syncthreads();
             const float WT = (top || ty == FBY - 1) ? 0.0f : s_wb[pb][ty + 1][lane];
 #endif
             if (do_out) {
                 float den_h, den_v;
+#if F2_ZLDS
+                {
+                    const float r = RHO ? ldb(rho, bc) : 1.0f;
+                    const float ja = ldb(jaco, bc);
+                    den_h = ja * r;
+                    if (!den_ready) { den_v = ldb(dz, bc) * ja * r; s_den[j - j0][ty][lane] = den_v; }
+                    else den_v = s_den[j - j0][ty][lane];
+                }
+#else
                 if (!den_ready) {
                     const float r = RHO ? ldb(rho, bc) : 1.0f;
                     const float ja = ldb(jaco, bc);
@@ -724,6 +770,7 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
                     const float2 t = s_den[j - j0][ty][lane];
                     den_h = t.x; den_v = t.y;
                 }
+#endif
                 const float f1r = flux1(q0, qxp1, UR);
                 const float f1l = flux1(qxm1, q0, UL);
                 const float f3 = flux1(q0, qp1, VN);
@@ -736,6 +783,9 @@ k_mpdata_final2(Dims d, CVarPtrs qold, CVarPtrs q1in, CVarPtrs u2i, CVarPtrs v2i
             }
             qm2 = qm1; qm1 = q0; q0 = qp1; qp1 = qp2; lm2 = lm1; lm1 = l0; l0 = lp1; lp1 = lp2;
             vm1 = v0; v0 = vp1; vp1 = vp2; VS = VN;
+#if F2_ZLDS
+            wcur = wnext;
+#endif
         }
         den_ready = true;
     }
