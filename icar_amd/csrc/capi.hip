@@ -179,7 +179,10 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
     const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V), *w = icar_field_f(c, ICAR_F_W);
     if (!u || !v || !w) return 1;
     float *dzl = c->d_red + 16;
-    HIPCHK(hipMemcpyAsync(dzl, dz_levels, sizeof(float) * c->d.nz, hipMemcpyHostToDevice, c->stream));
+    if ((int)c->dzl_host.size() != c->d.nz || memcmp(c->dzl_host.data(), dz_levels, sizeof(float) * c->d.nz) != 0) {
+        c->dzl_host.assign(dz_levels, dz_levels + c->d.nz);      // the copy source must outlive the async copy
+        HIPCHK(hipMemcpyAsync(dzl, c->dzl_host.data(), sizeof(float) * c->d.nz, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipMemsetAsync(c->d_red, 0, sizeof(float), c->stream));
     const int nlines = c->d.nz * c->d.ny;
     dim3 g(std::min((nlines + 3) / 4, 2048)), b(64, 4);

@@ -44,6 +44,7 @@ struct icar_hip_ctx {
     float *iw_adj = nullptr;             // iterative_winds ADJ scratch (iterative_winds.hip)
     // reductions / flags
     float *d_red = nullptr;              // small device scratch for reductions
+    std::vector<float> dzl_host;         // dz_levels last uploaded behind d_red (compute_dt re-sends them only when they change)
     int *d_flag = nullptr;
     ThompsonTables *thompson = nullptr;
     LinWinds *linwinds = nullptr;
