@@ -53,7 +53,7 @@ def build_tile(args, rank, world, device):
     opt.parameters.dx = float(case["dx"])
     opt.parameters.dz_levels = case["dz_levels"]
     mp_var_request(opt); adv_var_request(opt)
-    comm = HaloComm(g, rank + 1) if world > 1 else None
+    comm = HaloComm(g, rank + 1, loopback=(world == 1))
     d = domain_t(g, device=device, dx=float(case["dx"]), image=rank + 1, comm=comm)
     d.bind_torch_stream()            # context kernels, torch ops and RCCL ordering all on one non-default stream
     d.load_case(case)
@@ -67,22 +67,21 @@ def build_tile(args, rank, world, device):
     return d, opt, case, g
 
 
+# the kernels one advect() call launches, per scheme (the roofline's `kernel` label; also the key of profiles/advect_traffic.json)
+ADVECT_KERNELS = {"mpdata": "k_upwind_pass + k_mpdata_fluxes_pipe + k_mpdata_final2", "upwind": "k_upwind_pass"}
+
 FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
 
 
 def one_step(d, opt, group=None, device=None, cool=0.0):
-    from icar_amd.time_step import update_dt
-    from icar_amd.microphysics import mp
+    from icar_amd.time_step import update_dt, mp_and_halo
     from icar_amd.advection import advect
     dt = update_dt(d, opt, group=group, device=device)
     d.diagnostic_update()
-    if d.comm is None or not d.comm.peers:
-        mp(d, opt, dt)                   # no neighbours: strips + interior in one launch (icar_amd/time_step.py)
-    else:
-        mp(d, opt, dt, halo=1)
-        d.halo_send()
-        mp(d, opt, dt, subset=1)
-        d.halo_retrieve()
+    # mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve at EVERY world size: the strips + pack on the main stream,
+    # the interior on the second stream.  With one image the edges wrap around to the tile itself (HaloComm loopback:
+    # same pack / unpack kernels, no transport), so the N=1 line times the launches every rank of an N>1 run pays.
+    mp_and_halo(d, opt, dt)
     advect(d, opt, dt)
     d.apply_forcing(dt, FORCED)
     d.model_time_seconds += dt
@@ -91,7 +90,7 @@ def one_step(d, opt, group=None, device=None, cool=0.0):
 
 def cpu_reference(args, domain, nscalars):
     """The UNMODIFIED reference kernels (oracle/_ref: adv_mpdata.f90 + mp_thompson.f90 / mp_simple.f90 compiled by
-    oracle/build_ref.sh, no OpenMP -> one core) timed on one step of the same 256x256x40 sample.  Informational, next
+    oracle/build_ref.sh, no OpenMP -> one core) timed on one step of the same tile size as the GPU line.  Informational, next
     to cpu_baseline (the OpenMP port that is bit-identical to them).  Thompson's tables are read from the .dat caches
     the device tables were written to (byte-identical to the reference's own, tests/test_gpu_thompson.py), which skips
     the reference's 56 s single-core table build.  Runs in a child process: the Fortran runtime writes to stdout."""
@@ -105,7 +104,7 @@ def cpu_reference(args, domain, nscalars):
             from icar_amd.thompson_cache import write_caches
             write_caches(domain, tmp)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--ref-child", tmp, "--adv", args.adv, "--mp", args.mp,
-                            "--nz", str(args.nz), "--hill", str(args.hill), "--ref-nscal", str(nscalars)],
+                            "--nx", str(args.nx), "--ny", str(args.ny), "--nz", str(args.nz), "--hill", str(args.hill), "--ref-nscal", str(nscalars)],
                            capture_output=True, text=True, timeout=600, preexec_fn=_unlimited_stack)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
@@ -125,7 +124,7 @@ def ref_child(args):
     from oracle import ref
     from icar_amd import ideal
     nscalars = args.ref_nscal
-    nx, ny, nz = 256, 256, args.nz
+    nx, ny, nz = args.nx, args.ny, args.nz             # the SAME tile size as the GPU line
     c = ideal.make_case(nx, ny, nz, hill_height=args.hill, noise=0.01, n_hydro=1)
     c["water_vapor"] = (c["water_vapor"] * np.float32(1.4)).astype(np.float32)
     dt = min(ideal.cfl_dt(c), 120.0)
@@ -153,7 +152,7 @@ def ref_child(args):
                c["jacobian_v"], c["jacobian_w"], c["advection_dz"], c["dz_levels"], float(c["dx"]), dt)
     el = time.perf_counter() - t0
     print("\n" + json.dumps({"value": (nx - 2) * (ny - 2) * nz / el, "unit": "grid-cell updates/s", "cores": 1, "kind": "reference",
-                             "sample": f"1 step of 256x256x{nz}, the reference's own {args.adv} + {args.mp} kernels compiled unmodified "
+                             "sample": f"1 step of {nx}x{ny}x{nz}, the reference's own {args.adv} + {args.mp} kernels compiled unmodified "
                                        f"(flang -O2, no OpenMP), {el:.1f} s"}), flush=True)
 
 
@@ -186,7 +185,7 @@ def cpu_baseline(args, nscalars):
             orc.set_num_threads(usable_cpus())
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "grid-cell updates/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    nx, ny, nz = 256, 256, args.nz
+    nx, ny, nz = args.nx, args.ny, args.nz             # the SAME tile size as the GPU line
     c = ideal.make_case(nx, ny, nz, hill_height=args.hill, noise=0.01, n_hydro=1)
     c["water_vapor"] = (c["water_vapor"] * np.float32(1.4)).astype(np.float32)
     dt = min(ideal.cfl_dt(c), 120.0)
@@ -238,6 +237,18 @@ def cpu_baseline(args, nscalars):
                       f"oracle/*.c CPU restatement (bit-identical to the reference kernels) with OpenMP on {orc.num_threads()} threads, {el:.1f} s"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU, RCCL) under
+    torch.distributed.run on 127.0.0.1 and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,7 +267,12 @@ def main():
     if args.ref_child is not None:
         return ref_child(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with torch.distributed.run "
+                         f"--nproc-per-node N, or run `python bench.py --gpus N` alone and it spawns them")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -271,9 +287,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"bench.py: --gpus {world} over RCCL needs {world} visible GPUs, this box has "
+                                 f"{torch.cuda.device_count()} (ICAR_BENCH_BACKEND=gloo shares one GPU as a functional check)")
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
 
     from icar_amd import capi
     d, opt, case, g = build_tile(args, rank, world, dev_index)
@@ -315,11 +335,17 @@ def main():
     mem_cells = d.nx * d.ny * d.nz
     alg_bytes = mem_cells * (8 * nscal + 16)            # B_adv = 8N+16 bytes per cell
     achieved = alg_bytes / (adv_ms * 1e-3) / 1e9 if adv_ms > 0 else 0.0
+    # HBM bytes per advect() call from the PMC passes (profiles/run_profiles.sh: FETCH_SIZE x2 + WRITE_SIZE, separate
+    # runs of this same command): counters cannot be read inside this process, so the figure is attached only when it was
+    # taken on THIS configuration and THIS kernel generation; otherwise null.
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "advect_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_advect_call")
+            tj = json.load(open(tpath))
+            want = {"nx": d.nx, "ny": d.ny, "nz": d.nz, "adv": args.adv, "nscalars": nscal, "kernels": ADVECT_KERNELS[args.adv]}
+            if tj.get("config") == want:
+                traffic = tj.get("hbm_bytes_per_advect_call")
         except Exception:
             traffic = None
 
@@ -356,8 +382,11 @@ def main():
                                    f"{'mpdata order-2+FCT' if args.adv == 'mpdata' else 'upwind'} advection of "
                                    f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
                        "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",
+                       "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
+                       "halo": "RCCL send/recv per neighbour, strips+pack on the main stream, interior mp on the second stream" if world > 1
+                               else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips on the main stream, interior mp on the second stream",
                        "dt_s": dt, "mp_active_column_fraction": active},
-            "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpdata_fluxes_pipe + k_mpdata_final2)",
+            "roofline": {"bound": "hbm", "kernel": f"advect ({ADVECT_KERNELS[args.adv]})",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
                          "mp_ms_per_step": mp_ms_step,

@@ -15,6 +15,7 @@ class IcarHipError(RuntimeError):
 # every symbol include/icar_hip.h declares (tests/test_abi.py cross-checks this list with the header)
 SYMBOLS = [
     "icar_hip_ctx_create", "icar_hip_ctx_destroy", "icar_hip_set_stream", "icar_hip_synchronize",
+    "icar_hip_aux_fork", "icar_hip_aux_begin", "icar_hip_aux_end", "icar_hip_aux_join", "icar_hip_max_courant_device",
     "icar_hip_field_upload", "icar_hip_field_download", "icar_hip_field_fill", "icar_hip_field_device_ptr",
     "icar_hip_field_count", "icar_hip_field_elem_size", "icar_hip_setup_winds", "icar_hip_advect", "icar_hip_advect_occupancy",
     "icar_hip_mp_simple", "icar_hip_thompson_init", "icar_hip_thompson", "icar_hip_thompson_tiles", "icar_hip_thompson_table", "icar_hip_mp_tiles",

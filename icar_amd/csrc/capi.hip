@@ -174,7 +174,10 @@ k_max_courant(Dims d, const float *__restrict__ u, const float *__restrict__ v,
     }
 }
 
-int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out)
+// out != nullptr: the maximum is copied to the host (one stream synchronisation).  d_out != nullptr: it is left in device
+// memory at d_out (a REAL(4) the caller owns) and nothing waits -- the caller all-reduces it on the device (co_min of
+// time_step.f90:413 as max over images of the Courant sum: dt = factor / max is monotone, so min(dt) == factor / max).
+int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out, float *d_out)
 {
     const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V), *w = icar_field_f(c, ICAR_F_W);
     if (!u || !v || !w) return 1;
@@ -183,14 +186,17 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
         c->dzl_host.assign(dz_levels, dz_levels + c->d.nz);      // the copy source must outlive the async copy
         HIPCHK(hipMemcpyAsync(dzl, c->dzl_host.data(), sizeof(float) * c->d.nz, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(hipMemsetAsync(c->d_red, 0, sizeof(float), c->stream));
+    float *red = d_out ? d_out : c->d_red;
+    HIPCHK(hipMemsetAsync(red, 0, sizeof(float), c->stream));
     const int nlines = c->d.nz * c->d.ny;
     dim3 g(std::min((nlines + 3) / 4, 2048)), b(64, 4);
     ScopedTimer t(c, "cfl");
-    hipLaunchKernelGGL(k_max_courant, g, b, 0, c->stream, c->d, u, v, w, dzl, dx, (unsigned *)c->d_red);
+    hipLaunchKernelGGL(k_max_courant, g, b, 0, c->stream, c->d, u, v, w, dzl, dx, (unsigned *)red);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, c->d_red, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (out) {
+        HIPCHK(hipMemcpyAsync(out, red, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 
@@ -327,6 +333,10 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     icar_wsm3_free(c);
     icar_thompson_free(c);
     icar_linwinds_free(c);
+    if (c->on_aux) c->stream = c->main_saved;
+    if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -335,6 +345,8 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
 int icar_hip_set_stream(icar_hip_ctx *c, void *s)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    if (c->on_aux) { icar_set_error("set_stream: called between aux_begin and aux_end"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s) {
         if (c->own_stream) { hipStreamDestroy(c->stream); c->own_stream = false; }
@@ -349,6 +361,7 @@ int icar_hip_set_stream(icar_hip_ctx *c, void *s)
 int icar_hip_synchronize(icar_hip_ctx *c)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -368,6 +381,7 @@ int icar_hip_field_upload(icar_hip_ctx *c, int f, const void *host)
 int icar_hip_field_download(icar_hip_ctx *c, int f, void *host)
 {
     if (!c || !host) { icar_set_error("field_download: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     float *p = icar_field_f(c, f, true);
     if (!p) return 1;
     HIPCHK(hipMemcpyAsync(host, p, icar_field_count(c, f) * icar_hip_field_elem_size(f), hipMemcpyDeviceToHost, c->stream));
@@ -381,6 +395,7 @@ __global__ void k_fill_d(double *p, size_t n, double v) { size_t t = (size_t)blo
 int icar_hip_field_fill(icar_hip_ctx *c, int f, double value)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     float *p = icar_field_f(c, f, false);
     if (!p) return 1;
     const size_t n = icar_field_count(c, f);
@@ -393,6 +408,7 @@ int icar_hip_field_fill(icar_hip_ctx *c, int f, double value)
 int icar_hip_field_device_ptr(icar_hip_ctx *c, int f, void **dptr)
 {
     if (!c || !dptr) { icar_set_error("field_device_ptr: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     float *p = icar_field_f(c, f, false);
     if (!p) return 1;
     *dptr = p;
@@ -402,12 +418,14 @@ int icar_hip_field_device_ptr(icar_hip_ctx *c, int f, void **dptr)
 int icar_hip_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_advect_setup_winds(c, scheme, dt, dx, advect_density);
 }
 
 int icar_hip_advect(icar_hip_ctx *c, int scheme, int mpdata_order, int fct, int advect_density, const int *fields, int nfields)
 {
     if (!c || (!fields && nfields > 0)) { icar_set_error("advect: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_advect_run(c, scheme, mpdata_order, fct, advect_density, fields, nfields);
 }
 
@@ -421,12 +439,14 @@ int icar_hip_advect_occupancy(icar_hip_ctx *c, int nfields, float *frac_fluxes, 
 int icar_hip_mp_simple(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_count)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_mp_simple_run(c, dt, its, ite, jts, jte, kts, kte, err_count);
 }
 
 int icar_hip_thompson_init(icar_hip_ctx *c, const float params[18], const int flags[2])
 {
     if (!c || !params || !flags) { icar_set_error("thompson_init: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_thompson_init_run(c, params, flags);
 }
 
@@ -434,6 +454,7 @@ int icar_hip_thompson(icar_hip_ctx *c, float dt, int its, int ite, int jts, int 
                       int ids, int ide, int jds, int jde, int kds, int kde)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_thompson_run(c, dt, its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde);
 }
 
@@ -448,6 +469,7 @@ int icar_hip_thompson_tiles(icar_hip_ctx *c, float dt, int ntiles, const int til
 int icar_hip_thompson_table(icar_hip_ctx *c, const char *name, double *out, size_t capacity, size_t *count)
 {
     if (!c || !name) { icar_set_error("thompson_table: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_thompson_table_download(c, name, out, capacity, count);
 }
 
@@ -470,19 +492,30 @@ int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, 
 int icar_hip_max_courant(icar_hip_ctx *c, float dx, const float *dz_levels, float *out)
 {
     if (!c || !dz_levels || !out) { icar_set_error("max_courant: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     if (c->d.nz > 4096) { icar_set_error("max_courant: nz too large"); return 1; }
-    return icar_max_courant_run(c, dx, dz_levels, out);
+    return icar_max_courant_run(c, dx, dz_levels, out, nullptr);
+}
+
+int icar_hip_max_courant_device(icar_hip_ctx *c, float dx, const float *dz_levels, void *d_out)
+{
+    if (!c || !dz_levels || !d_out) { icar_set_error("max_courant_device: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d.nz > 4096) { icar_set_error("max_courant_device: nz too large"); return 1; }
+    return icar_max_courant_run(c, dx, dz_levels, nullptr, (float *)d_out);
 }
 
 int icar_hip_diagnostic_update(icar_hip_ctx *c)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_diagnostic_update_run(c);
 }
 
 int icar_hip_dqdt_upload(icar_hip_ctx *c, int f, const void *host)
 {
     if (!c || !host) { icar_set_error("dqdt_upload: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     if (f < 0 || f >= ICAR_N_FIELDS || field_is_2dd(f)) { icar_set_error("dqdt_upload: bad field"); return 1; }
     const size_t bytes = icar_field_count(c, f) * sizeof(float);
     if (!c->dqdt[f]) HIPCHK(hipMalloc(&c->dqdt[f], bytes));
@@ -494,60 +527,70 @@ int icar_hip_dqdt_upload(icar_hip_ctx *c, int f, const void *host)
 int icar_hip_apply_forcing(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn)
 {
     if (!c || (n > 0 && (!fields || !fb))) { icar_set_error("apply_forcing: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_apply_forcing_run(c, dt, fields, fb, n, w, e, s, nn);
 }
 
 int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
 {
     if (!c || (n > 0 && !fields)) { icar_set_error("enforce_limits: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_enforce_limits_run(c, fields, n);
 }
 
 int icar_hip_wsm3_init(icar_hip_ctx *c)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_wsm3_init_run(c);
 }
 
 int icar_hip_wsm3(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_wsm3_run(c, dt, its, ite, jts, jte, kts, kte);
 }
 
 int icar_hip_max_abs_winds(icar_hip_ctx *c, float *out3)
 {
     if (!c || !out3) { icar_set_error("max_abs_winds: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_max_abs_winds_run(c, out3);
 }
 
 int icar_hip_balance_uvw(icar_hip_ctx *c, float dx)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_balance_uvw_run(c, dx, 0);
 }
 
 int icar_hip_balance_uvw_update(icar_hip_ctx *c, float dx)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_balance_uvw_run(c, dx, 1);
 }
 
 int icar_hip_mass_conservative_acceleration(icar_hip_ctx *c, int update)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_mass_conservative_acceleration(c, update);
 }
 
 int icar_hip_iterative_winds_correct_w(icar_hip_ctx *c, int update)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_iterative_winds_correct_w(c, update);
 }
 
 int icar_hip_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int update)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     if (nsweeps < 0 || !(dx > 0)) { icar_set_error("iterative_winds_sweep: bad argument"); return 1; }
     return icar_iterative_winds_sweep(c, dx, nsweeps, update);
 }
@@ -555,18 +598,21 @@ int icar_hip_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int u
 int icar_hip_box_pack(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, void *dbuf)
 {
     if (!c || !dbuf) { icar_set_error("box_pack: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_box_copy(c, field, which, i0, ni, j0, nj, (float *)dbuf, false);
 }
 
 int icar_hip_box_unpack(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, const void *dbuf)
 {
     if (!c || !dbuf) { icar_set_error("box_unpack: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_box_copy(c, field, which, i0, ni, j0, nj, (float *)dbuf, true);
 }
 
 int icar_hip_dqdt_download(icar_hip_ctx *c, int f, void *host)
 {
     if (!c || !host) { icar_set_error("dqdt_download: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     if (f < 0 || f >= ICAR_N_FIELDS || field_is_2dd(f) || !c->dqdt[f]) { icar_set_error("dqdt_download: no dqdt mirror for this field"); return 1; }
     HIPCHK(hipMemcpyAsync(host, c->dqdt[f], icar_field_count(c, f) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -658,20 +704,78 @@ size_t icar_hip_halo_count(const icar_hip_ctx *c, int dir, int halo)
 int icar_hip_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int nfields, void *dbuf)
 {
     if (!c || !dbuf) { icar_set_error("halo_pack: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_halo_pack(c, dir, halo, fields, nfields, (float *)dbuf, false);
 }
 
 int icar_hip_halo_unpack(icar_hip_ctx *c, int dir, int halo, const int *fields, int nfields, const void *dbuf)
 {
     if (!c || !dbuf) { icar_set_error("halo_unpack: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
     return icar_halo_pack(c, dir, halo, fields, nfields, (float *)dbuf, true);
 }
 
-int icar_hip_timing_enable(icar_hip_ctx *c, int on) { if (!c) return 1; c->timing = on != 0; return 0; }
-int icar_hip_timing_reset(icar_hip_ctx *c) { if (!c) return 1; hipStreamSynchronize(c->stream); drain_timers(c); c->timers.clear(); return 0; }
+// ---- second stream -------------------------------------------------------------------------------------------------
+// aux_fork : the aux stream waits for everything issued on the main stream so far
+// aux_begin / aux_end : entry points called in between launch on the aux stream
+// aux_join : the main stream waits for everything issued on the aux stream so far
+static int ensure_aux(icar_hip_ctx *c)
+{
+    if (c->aux) return 0;
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo = lowest priority (numerically greatest)
+    HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, lo));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    return 0;
+}
+
+int icar_hip_aux_fork(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (c->on_aux) { icar_set_error("aux_fork: already on the aux stream"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    if (ensure_aux(c)) return 1;
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    return 0;
+}
+
+int icar_hip_aux_begin(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (c->on_aux) { icar_set_error("aux_begin: already on the aux stream"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    if (ensure_aux(c)) return 1;
+    c->main_saved = c->stream; c->stream = c->aux; c->on_aux = true;
+    return 0;
+}
+
+int icar_hip_aux_end(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (!c->on_aux) { icar_set_error("aux_end: not on the aux stream"); return 1; }
+    c->stream = c->main_saved; c->on_aux = false;
+    return 0;
+}
+
+int icar_hip_aux_join(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (c->on_aux) { icar_set_error("aux_join: call aux_end first"); return 1; }
+    if (!c->aux) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev_join, c->aux));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return 0;
+}
+
+int icar_hip_timing_enable(icar_hip_ctx *c, int on) { if (!c) return 1; hipSetDevice(c->device); c->timing = on != 0; return 0; }
+int icar_hip_timing_reset(icar_hip_ctx *c) { if (!c) return 1; hipSetDevice(c->device); hipStreamSynchronize(c->stream); drain_timers(c); c->timers.clear(); return 0; }
 int icar_hip_timing_read(icar_hip_ctx *c, const char *group, double *total_ms, int *launches)
 {
     if (!c || !group) return 1;
+    hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     drain_timers(c);
     auto it = c->timers.find(group);

@@ -30,8 +30,12 @@ struct icar_hip_ctx {
     int ims, ime, kms, kme, jms, jme;
     Dims d;
     size_t n3 = 0;                       // nx*nz*ny
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // the stream every entry point launches on (main, or aux between aux_begin/aux_end)
     bool own_stream = false;
+    // second HIP stream (north_star: halo strips + exchange on one stream, interior work beside them on the other)
+    hipStream_t aux = nullptr, main_saved = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool on_aux = false;
     void *field[ICAR_N_FIELDS] = {nullptr};
     float *dqdt[ICAR_N_FIELDS] = {nullptr};    // variable_t%dqdt_3d mirrors (apply_forcing)
     // advection scratch (A1-A5)
@@ -76,7 +80,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
 int icar_advect_occupancy(icar_hip_ctx *c, int n, float *frac_fluxes, float *frac_final);
 int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err);
 int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
-int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out);
+int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out, float *d_out);
 int icar_max_abs_winds_run(icar_hip_ctx *c, float *out3);
 int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update);
 int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update);

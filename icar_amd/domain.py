@@ -27,7 +27,9 @@ class domain_t:
         check(lib().icar_hip_ctx_create(ctypes.byref(self._ctx), int(device), grid.ims, grid.ime, grid.kms,
                                         grid.kme, grid.jms, grid.jme), "icar_hip_ctx_create")
         self.nx, self.nz, self.ny = grid.ime - grid.ims + 1, grid.kme - grid.kms + 1, grid.jme - grid.jms + 1
+        self.device = int(device)
         self.model_time_seconds = 0.0    # domain%model_time%seconds()
+        self.mp_state = dict(last_model_time=-999.0)   # mp_driver.f90's SAVE variables last_model_time / update_interval
         self.exchange_vars = []          # kVARS names with an associated exchangeable (halo_send order)
 
     # ---- plumbing -------------------------------------------------------------------------
@@ -119,6 +121,19 @@ class domain_t:
     def synchronize(self):
         check(lib().icar_hip_synchronize(self.ctx), "synchronize")
 
+    # second HIP stream (include/icar_hip.h: aux_fork / aux_begin / aux_end / aux_join)
+    def aux_fork(self):
+        check(lib().icar_hip_aux_fork(self.ctx), "aux_fork")
+
+    def aux_begin(self):
+        check(lib().icar_hip_aux_begin(self.ctx), "aux_begin")
+
+    def aux_end(self):
+        check(lib().icar_hip_aux_end(self.ctx), "aux_end")
+
+    def aux_join(self):
+        check(lib().icar_hip_aux_join(self.ctx), "aux_join")
+
     def set_stream(self, stream_ptr):
         """Run the context's kernels on the caller's HIP stream (0 / None = the context's own non-blocking stream)."""
         check(lib().icar_hip_set_stream(self.ctx, ctypes.c_void_p(stream_ptr)), "set_stream")
@@ -178,7 +193,7 @@ def _halo_count(self, direction, halo):
 
 def _new_buffer(self, n):
     import torch
-    return torch.empty(int(n), dtype=torch.float32, device=f"cuda:{torch.cuda.current_device()}")
+    return torch.empty(int(n), dtype=torch.float32, device=f"cuda:{self.device}")     # the context's device, not torch's current one
 
 
 def _halo_pack(self, direction, halo, field_ids, buf):

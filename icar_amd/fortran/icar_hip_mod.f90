@@ -15,7 +15,8 @@ module icar_hip
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
             hip_diagnostic_update, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
-            hip_halo_unpack, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3
+            hip_halo_unpack, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, &
+            hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
@@ -56,6 +57,21 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_synchronize(ctx) bind(C, name="icar_hip_synchronize")
        import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_aux_fork(ctx) bind(C, name="icar_hip_aux_fork")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_aux_begin(ctx) bind(C, name="icar_hip_aux_begin")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_aux_end(ctx) bind(C, name="icar_hip_aux_end")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_aux_join(ctx) bind(C, name="icar_hip_aux_join")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_max_courant_device(ctx, dx, dz_levels, d_out) bind(C, name="icar_hip_max_courant_device")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dx; real(c_float), intent(in) :: dz_levels(*); type(c_ptr), value :: d_out
      end function
      integer(c_int) function icar_hip_field_upload(ctx, field, host) bind(C, name="icar_hip_field_upload")
        import; type(c_ptr), value :: ctx; integer(c_int), value :: field; type(c_ptr), value :: host
@@ -181,6 +197,33 @@ contains
   subroutine hip_sync(ctx)
     type(hip_ctx_t), intent(in) :: ctx
     call check(icar_hip_synchronize(ctx%p), "synchronize")
+  end subroutine
+
+  !> second HIP stream: `call hip_aux_fork(ctx)` before mp(halo=1); the interior mp(subset=1) between
+  !! hip_aux_begin / hip_aux_end runs beside the strips + halo_send; hip_aux_join before halo_retrieve (time_step.f90:512-526)
+  subroutine hip_aux_fork(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_aux_fork(ctx%p), "aux_fork")
+  end subroutine
+  subroutine hip_aux_begin(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_aux_begin(ctx%p), "aux_begin")
+  end subroutine
+  subroutine hip_aux_end(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_aux_end(ctx%p), "aux_end")
+  end subroutine
+  subroutine hip_aux_join(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_aux_join(ctx%p), "aux_join")
+  end subroutine
+
+  !> compute_dt's strictness-3 reduction left on the device (d_out = device address of one REAL(4)), for a device-side co_min
+  subroutine hip_max_courant_device(ctx, dx, dz_levels, d_out)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dx, dz_levels(:)
+    type(c_ptr), intent(in) :: d_out
+    call check(icar_hip_max_courant_device(ctx%p, real(dx,c_float), dz_levels, d_out), "max_courant_device")
   end subroutine
 
   !> domain%X%data_3d -> device.  The reference allocates these whole-array, i.e. contiguous; the

@@ -22,7 +22,9 @@ _NAMES = {DIR_NORTH: "north", DIR_SOUTH: "south", DIR_EAST: "east", DIR_WEST: "w
 
 
 class HaloComm:
-    def __init__(self, grid, image, group=None, halo=None):
+    def __init__(self, grid, image, group=None, halo=None, loopback=False):
+        """loopback=True: edges WITHOUT a neighbouring image wrap around to the tile's own opposite edge (a periodic
+        domain; what src/tests/test_mpdata.f90 does by hand): same pack / unpack kernels, no transport."""
         self.grid = grid
         self.image = image                      # 1-based, = rank + 1
         self.group = group
@@ -30,6 +32,8 @@ class HaloComm:
         nb = grid.neighbors(image)
         # direction -> neighbour rank (0-based) ; boundaries have no entry
         self.peers = {d: nb[_NAMES[d]] - 1 for d in _NAMES if nb[_NAMES[d]] is not None}
+        self.loop = [d for d in _NAMES if loopback and d not in self.peers and _OPPOSITE[d] not in self.peers]
+        self._loopbuf = {}
         self._send = {}
         self._recv = {}
         self._hsend = {}
@@ -53,6 +57,12 @@ class HaloComm:
 
     def send(self, tile, field_ids):
         """exchangeable%send for every variable: pack my edge planes, post send+recv per neighbour."""
+        if self.loop and field_ids:
+            if self._loopbuf.get("nf") != len(field_ids):
+                self._loopbuf = {d: tile.new_buffer(tile.halo_count(d, self.halo) * len(field_ids)) for d in self.loop}
+                self._loopbuf["nf"] = len(field_ids)
+            for d in self.loop:
+                tile.halo_pack(d, self.halo, field_ids, self._loopbuf[d])
         if not self.peers or not field_ids:
             return
         self._buffers(tile, len(field_ids))
@@ -79,6 +89,9 @@ class HaloComm:
     def retrieve(self, tile, field_ids):
         """exchangeable%retrieve: `sync images(neighbors)` == wait for the posted transfers,
         then copy each inbox into the halo planes facing that neighbour."""
+        if self.loop and field_ids:
+            for d in self.loop:                              # my north edge is what arrives from the south, etc.
+                tile.halo_unpack(_OPPOSITE[d], self.halo, field_ids, self._loopbuf[d])
         if not self.peers or not field_ids:
             return
         for r in self._reqs:
@@ -172,6 +185,8 @@ def co_min(value, group=None, device=None):
     """time_step.f90:413 `call co_min(seconds)`: all-reduce(min) of one REAL(8)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    if device is None:                                  # RCCL reduces device memory only
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return float(t.item())

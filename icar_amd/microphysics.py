@@ -3,8 +3,6 @@ import ctypes
 from .capi import lib, check
 from .constants import kMP_THOMPSON, kMP_SB04, kMP_WSM3
 
-_state = {}     # per-domain replacement of the module SAVE variables last_model_time / update_interval
-
 
 def mp_var_request(options):
     """mp_driver.f90:200-229 (mp_simple.f90:104-126, mp_driver.f90:115-140 for Thompson)."""
@@ -47,7 +45,7 @@ def mp_init(options, domain=None):
             raise ValueError("mp_init(options, domain): the WSM3 constants live in the domain's device context")
         check(lib().icar_hip_wsm3_init(domain.ctx), "icar_hip_wsm3_init")
     if domain is not None:
-        _state[id(domain)] = dict(last_model_time=-999.0)
+        domain.mp_state = dict(last_model_time=-999.0)       # the module SAVE variables live on the domain object
 
 
 def mp_tiles(its, ite, jts, jte, halo=0, subset=0):
@@ -76,7 +74,7 @@ def mp(domain, options, dt_in, halo=None, subset=None):
     """mp_driver.f90:673-772 including the update_interval gating (:698-713)."""
     if options.physics.microphysics == 0:
         return
-    st = _state.setdefault(id(domain), dict(last_model_time=-999.0))
+    st = domain.mp_state
     upd = float(options.mp_options.update_interval)
     now = domain.model_time_seconds
     if st["last_model_time"] == -999.0:
@@ -94,7 +92,11 @@ def mp(domain, options, dt_in, halo=None, subset=None):
                 _process_subdomain(domain, options, mp_dt, a, b, c, d, g.kts, kte)
         if halo is not None:
             tiles = mp_tiles(g.its, g.ite, g.jts, g.jte, halo=halo)
-            if options.physics.microphysics == kMP_THOMPSON:
+            h = int(halo)
+            # a tile narrower than 2*halo makes the west/east (or south/north) strips overlap: the reference then runs
+            # those columns once per strip, one strip after the other -- a single batched launch would race on them
+            overlapping = (g.ite - g.its + 1 < 2 * h) or (g.jte - g.jts + 1 < 2 * h)
+            if options.physics.microphysics == kMP_THOMPSON and not overlapping:
                 # process_halo's four strips in one launch (icar_hip_thompson_tiles)
                 tiles = [t for t in tiles if t[1] >= t[0] and t[3] >= t[2]]
                 arr = ((ctypes.c_int * 4) * len(tiles))(*[(ctypes.c_int * 4)(*t) for t in tiles])
@@ -110,4 +112,4 @@ def mp(domain, options, dt_in, halo=None, subset=None):
 
 def mp_finish(options, domain=None):
     if domain is not None:
-        _state.pop(id(domain), None)
+        domain.mp_state = dict(last_model_time=-999.0)

@@ -42,10 +42,67 @@ def compute_dt(domain, options):
     return float(dt)
 
 
+def _world(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def update_dt(domain, options, group=None, device=None):
-    """time_step.f90:375-423: local CFL dt, co_min over images, cap at 120 s."""
+    """time_step.f90:375-423: local CFL dt, co_min over images, cap at 120 s.
+
+    With RCCL (several images, cfl_strictness 3 or 4) the reduction never leaves the device before the all-reduce:
+    k_max_courant writes the tile's maximum Courant sum into a 1-element device tensor, all_reduce(MAX) runs on it, and
+    one read brings the global value back -- dt = factor / max is monotone, so min over images of dt == factor / max
+    over images, bit for bit.  Other settings / backends combine on the host (compute_dt) and co_min the REAL(8)."""
+    strict = int(options.parameters.cfl_strictness)
+    if _world(group) > 1 and strict in (3, 4):
+        import torch
+        import torch.distributed as dist
+        if dist.get_backend(group) == "nccl":
+            f32 = np.float32
+            t = getattr(domain, "_cfl_dev", None)
+            if t is None:
+                t = domain._cfl_dev = torch.zeros(1, dtype=torch.float32, device=f"cuda:{domain.device}")
+            dzl = np.ascontiguousarray(options.parameters.dz_levels, np.float32)
+            check(lib().icar_hip_max_courant_device(domain.ctx, ctypes.c_float(domain.dx), dzl.ctypes.data_as(ctypes.c_void_p),
+                                                    ctypes.c_void_p(t.data_ptr())), "icar_hip_max_courant_device")
+            if domain.needs_host_sync():
+                domain.synchronize()                   # the reduction ran on a stream RCCL does not order itself against
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            maxwind3d = f32(t.item())
+            if strict == 4:
+                maxwind3d = f32(maxwind3d * f32(f32(np.sqrt(f32(3.0))) * f32(1.001)))
+            dt = f32(options.parameters.cfl_reduction_factor) / f32(maxwind3d)
+            if dt < 1e-1:
+                raise IcarHipError("ERROR time step too small")
+            return min(float(dt), 120.0)
     seconds = co_min(compute_dt(domain, options), group=group, device=device)
     return min(seconds, 120.0)
+
+
+def mp_and_halo(domain, options, dt, overlap=True):
+    """time_step.f90:512-526: mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve.
+
+    The strips, the pack kernels and the exchange stay on the context's main stream; the interior launch runs beside them
+    on the context's second (low-priority) stream -- a one-cell-wide strip launch cannot fill 256 CUs, and the interior
+    does not have to wait for it (disjoint columns).  An image without neighbours runs exactly the same launches (its
+    halo_send / halo_retrieve have nobody to talk to), so 1-image and N-image timings compare like with like."""
+    from .constants import kMP_THOMPSON, kMP_SB04
+    overlap = overlap and options.physics.microphysics in (kMP_THOMPSON, kMP_SB04)   # WSM3 re-zeroes whole-tile scratch per call
+    if overlap:
+        domain.aux_fork()
+    mp(domain, options, dt, halo=1)                            # :512
+    domain.halo_send()                                         # :515
+    if overlap:
+        domain.aux_begin()
+        try:
+            mp(domain, options, dt, subset=1)                  # :523
+        finally:
+            domain.aux_end()
+        domain.aux_join()
+    else:
+        mp(domain, options, dt, subset=1)
+    domain.halo_retrieve()                                     # :526
 
 
 def step(domain, end_time, options, group=None, device=None, forced=None, diagnostics=True):
@@ -62,16 +119,7 @@ def step(domain, end_time, options, group=None, device=None, forced=None, diagno
         if diagnostics:
             domain.diagnostic_update()                         # :474
         if dt > 1e-3:                                          # :483
-            if getattr(domain, "comm", None) is None or not domain.comm.peers:
-                # an image without neighbours has nothing to send between the strips and the interior: mp()'s own
-                # whole-tile form (mp_driver.f90:755-768) does the same columns in ONE launch -- a 1-cell-wide strip
-                # launch cannot fill 256 CUs.  Columns are independent, so the result is identical.
-                mp(domain, options, dt)
-            else:
-                mp(domain, options, dt, halo=1)                # :512
-                domain.halo_send()                             # :515
-                mp(domain, options, dt, subset=1)              # :523
-                domain.halo_retrieve()                         # :526
+            mp_and_halo(domain, options, dt)                   # :512-526
             advect(domain, options, dt)                        # :529
             if forced:
                 domain.apply_forcing(dt, forced)               # :534

@@ -92,6 +92,18 @@ int icar_hip_ctx_destroy(icar_hip_ctx *ctx);
 /* Run all kernels of this context on the caller's HIP stream (hipStream_t); NULL = own stream. */
 int icar_hip_set_stream(icar_hip_ctx *ctx, void *hip_stream);
 int icar_hip_synchronize(icar_hip_ctx *ctx);
+/* Second HIP stream of the context (created on first use, lowest priority).  time_step.f90:512-526 orders
+ *     mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
+ * so that the interior microphysics overlaps the coarray PUTs; here the strips, the pack kernels and the exchange stay
+ * on the main stream while the interior launch runs beside them on the aux stream:
+ *     aux_fork   aux waits for everything issued on the main stream so far
+ *     aux_begin  ... entry points called here launch on the aux stream ...  aux_end
+ *     aux_join   the main stream waits for everything issued on the aux stream so far
+ * Work issued between fork and join on the two streams must touch disjoint cells (strips vs interior columns). */
+int icar_hip_aux_fork(icar_hip_ctx *ctx);
+int icar_hip_aux_begin(icar_hip_ctx *ctx);
+int icar_hip_aux_end(icar_hip_ctx *ctx);
+int icar_hip_aux_join(icar_hip_ctx *ctx);
 /* Lazily allocates the device mirror of a field.  Host buffers are the domain_t arrays
  * (contiguous, Fortran order).  Element count: icar_hip_field_count(). */
 int icar_hip_field_upload(icar_hip_ctx *ctx, int field, const void *host);
@@ -166,6 +178,10 @@ int icar_hip_wsm3(icar_hip_ctx *ctx, float dt, int its, int ite, int jts, int jt
 /* ---- T2: CFL reduction for compute_dt (src/main/time_step.f90:217-330, cfl_strictness 3) -----
  * out = max over the tile of max(|u_i|,|u_i+1|)/dx + max(|v_j|,|v_j+1|)/dx + max(|w_k|,|w_k-1|)/dz_levels(k) */
 int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, float *out);
+/* Same reduction, result left in DEVICE memory at d_out (one REAL(4) owned by the caller), no host synchronisation:
+ * `call co_min(seconds)` (time_step.f90:413) becomes a 1-element all-reduce(max) of d_out over the images on the device
+ * (dt = cfl_reduction_factor / max is monotone, so the minimum dt is the quotient of the maximum). */
+int icar_hip_max_courant_device(icar_hip_ctx *ctx, float dx, const float *dz_levels, void *d_out);
 /* the other cfl_strictness settings (:238-259, :293-305) also need out[0..2] = maxval(abs(u)), maxval(abs(v)), maxval(abs(w)) */
 int icar_hip_max_abs_winds(icar_hip_ctx *ctx, float out[3]);
 

@@ -46,13 +46,18 @@ def _setup(case, g, opt, comm):
     return d
 
 
+TH_NAMES = NAMES + ["cloud_ice_mass", "graupel_mass", "cloud_ice_number", "rain_number"]
+
+
 def _options(adv, case):
     from icar_amd.options import options_t
-    from icar_amd.constants import kADV_UPWIND, kADV_MPDATA, kMP_SB04
+    from icar_amd.constants import kADV_UPWIND, kADV_MPDATA, kMP_SB04, kMP_THOMPSON
     from icar_amd.microphysics import mp_var_request
     opt = options_t()
+    thompson = adv.endswith("+thompson")
+    adv = adv.split("+")[0]
     opt.physics.advection = kADV_UPWIND if adv == "upwind" else kADV_MPDATA
-    opt.physics.microphysics = kMP_SB04
+    opt.physics.microphysics = kMP_THOMPSON if thompson else kMP_SB04
     opt.parameters.dz_levels = case["dz_levels"]; opt.parameters.dx = float(case["dx"])
     mp_var_request(opt)
     return opt
@@ -77,7 +82,8 @@ def _worker(rank, world, port, adv, q):
         d = _setup(case, g, opt, HaloComm(g, rank + 1))
         dt0 = update_dt(d, opt)                       # co_min over the tiles == the global CFL step
         n = step(d, NSTEPS * dt0 * 0.999, opt, diagnostics=False)
-        got = {k: d.get(k) for k in NAMES}
+        names = TH_NAMES if adv.endswith("+thompson") else NAMES
+        got = {k: d.get(k) for k in names}
         acc = d.get("accumulated_precipitation")
         d.close()
         ref = None
@@ -86,14 +92,15 @@ def _worker(rank, world, port, adv, q):
             d1 = _setup(case, g1, opt, None)
             dt1 = update_dt(d1, opt, group=solo)
             n1 = step(d1, NSTEPS * dt1 * 0.999, opt, group=solo, diagnostics=False)
-            ref = {k: d1.get(k) for k in NAMES}; ref["acc"] = d1.get("accumulated_precipitation"); ref["dt"] = dt1; ref["n"] = n1
+            ref = {k: d1.get(k) for k in names}; ref["acc"] = d1.get("accumulated_precipitation"); ref["dt"] = dt1; ref["n"] = n1
             d1.close()
         obj = [ref]; dist.broadcast_object_list(obj, src=0); ref = obj[0]
         assert n == ref["n"] and abs(dt0 - ref["dt"]) == 0.0, f"dt/steps differ: {dt0} {ref['dt']} {n} {ref['n']}"
         oj = slice(g.jts - g.jms, g.jte - g.jms + 1); oi = slice(g.its - g.ims, g.ite - g.ims + 1)
         gj = slice(g.jts - 1, g.jte); gi = slice(g.its - 1, g.ite)
         worst = 0.0
-        for k in NAMES:
+        adv = adv.split("+")[0]
+        for k in names:
             a, b = got[k][oj, :, oi], ref[k][gj, :, gi]
             if adv == "upwind":
                 assert np.array_equal(a, b), f"rank {rank} {k}: {(a != b).sum()} owned cells differ from the single-tile run"
@@ -252,7 +259,7 @@ def test_tiled_iterative_winds_equals_tiled_oracle():
     _run(_worker_iw, 4, "upwind")
 
 
-@pytest.mark.parametrize("world,adv", [(2, "upwind"), (4, "upwind"), (4, "mpdata")])
+@pytest.mark.parametrize("world,adv", [(2, "upwind"), (4, "upwind"), (4, "mpdata"), (2, "upwind+thompson"), (4, "upwind+thompson")])
 def test_tiled_step_equals_single_tile_on_device(world, adv):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
