@@ -12,11 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicar_hip.so")
-SOURCES = ["capi.hip", "advect.hip", "mp_simple.hip", "mp_thompson.hip", "thompson_tables.hip", "step.hip", "linear_winds.hip", "iterative_winds.hip", "mp_wsm3.hip"]
+SOURCES = ["capi.hip", "advect.hip", "mpdata.hip", "mp_simple.hip", "mp_thompson.hip", "thompson_tables.hip", "step.hip", "linear_winds.hip", "iterative_winds.hip", "mp_wsm3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # finite data only: drop the NaN-canonicalisation v_max x,x,x in front of every fmin/fmax (no effect on finite results)
-PER_FILE_FLAGS = {"advect.hip": ["-fno-honor-nans"]}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+PER_FILE_FLAGS = {"advect.hip": ["-fno-honor-nans"],
+                  # the fused MPDATA kernel is held to the 1e-5 tolerance, not to bit equality: fma contraction allowed
+                  "mpdata.hip": ["-fno-honor-nans", "-ffp-contract=fast"]}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",     # (a later -ffp-contract wins)
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

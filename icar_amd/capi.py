@@ -17,7 +17,7 @@ SYMBOLS = [
     "icar_hip_ctx_create", "icar_hip_ctx_destroy", "icar_hip_set_stream", "icar_hip_synchronize",
     "icar_hip_aux_fork", "icar_hip_aux_begin", "icar_hip_aux_end", "icar_hip_aux_join", "icar_hip_max_courant_device",
     "icar_hip_field_upload", "icar_hip_field_download", "icar_hip_field_fill", "icar_hip_field_device_ptr",
-    "icar_hip_field_count", "icar_hip_field_elem_size", "icar_hip_setup_winds", "icar_hip_advect", "icar_hip_advect_occupancy",
+    "icar_hip_field_count", "icar_hip_field_elem_size", "icar_hip_setup_winds", "icar_hip_advect",
     "icar_hip_mp_simple", "icar_hip_thompson_init", "icar_hip_thompson", "icar_hip_thompson_tiles", "icar_hip_thompson_table", "icar_hip_mp_tiles",
     "icar_hip_wsm3_init", "icar_hip_wsm3", "icar_hip_max_courant", "icar_hip_max_abs_winds", "icar_hip_balance_uvw", "icar_hip_balance_uvw_update", "icar_hip_mass_conservative_acceleration", "icar_hip_iterative_winds_correct_w", "icar_hip_iterative_winds_sweep", "icar_hip_box_pack", "icar_hip_box_unpack", "icar_hip_dqdt_download", "icar_hip_diagnostic_update", "icar_hip_dqdt_upload",
     "icar_hip_apply_forcing", "icar_hip_enforce_limits", "icar_hip_halo_count", "icar_hip_halo_pack",

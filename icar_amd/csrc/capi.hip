@@ -269,6 +269,7 @@ int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update)
     dim3 g((c->d.nx + 63) / 64, c->d.ny), b(64);
     hipLaunchKernelGGL(k_balance_uvw, g, b, 0, c->stream, c->d, u, v, w, ju, jv, jw, dz, dx);
     HIPCHK(hipGetLastError());
+    if (!update) c->winds_valid = false;                          // w changed: the Courant winds are stale
     return 0;
 }
 
@@ -324,11 +325,9 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->field[f]) hipFree(c->field[f]);
     for (int f = 0; f < ICAR_N_ADVECTABLE; ++f) if (c->alt[f]) hipFree(c->alt[f]);
     for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->dqdt[f]) hipFree(c->dqdt[f]);
-    float *scr[] = {c->U, c->V, c->W, c->Wdz, c->q2, c->u2, c->v2, c->w2, c->d_red};
+    float *scr[] = {c->U, c->V, c->W, c->Wdz, c->d_red};
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
-    if (c->occ) hipFree(c->occ);
-    if (c->needf) hipFree(c->needf);
     if (c->iw_adj) hipFree(c->iw_adj);
     icar_wsm3_free(c);
     icar_thompson_free(c);
@@ -427,13 +426,6 @@ int icar_hip_advect(icar_hip_ctx *c, int scheme, int mpdata_order, int fct, int 
     if (!c || (!fields && nfields > 0)) { icar_set_error("advect: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_advect_run(c, scheme, mpdata_order, fct, advect_density, fields, nfields);
-}
-
-int icar_hip_advect_occupancy(icar_hip_ctx *c, int nfields, float *frac_fluxes, float *frac_final)
-{
-    if (!c || !frac_fluxes || !frac_final || nfields < 1 || nfields > ICAR_MAX_ADV) { icar_set_error("advect_occupancy: bad argument"); return 1; }
-    HIPCHK(hipSetDevice(c->device));
-    return icar_advect_occupancy(c, nfields, frac_fluxes, frac_final);
 }
 
 int icar_hip_mp_simple(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_count)

@@ -41,9 +41,6 @@ struct icar_hip_ctx {
     // advection scratch (A1-A5)
     float *U = nullptr, *V = nullptr, *W = nullptr, *Wdz = nullptr;
     float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
-    float *q2 = nullptr, *u2 = nullptr, *v2 = nullptr, *w2 = nullptr;   // each holds batch_cap fields
-    int batch_cap = 0;
-    unsigned char *occ = nullptr, *needf = nullptr;   // MPDATA occupancy flags (advect.hip)
     bool winds_valid = false;
     float *iw_adj = nullptr;             // iterative_winds ADJ scratch (iterative_winds.hip)
     // reductions / flags
@@ -77,7 +74,6 @@ struct ScopedTimer {
 // kernels implemented in the .hip files
 int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density);
 int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_density, const int *fields, int n);
-int icar_advect_occupancy(icar_hip_ctx *c, int n, float *frac_fluxes, float *frac_final);
 int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err);
 int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out, float *d_out);

@@ -1,0 +1,500 @@
+// icar_amd/csrc/mpdata.hip -- MPDATA (order >= 2) with flux-corrected transport as ONE kernel per corrective iteration
+// (rows A2-A5 of SURVEY.md section 8: adv_mpdata.f90:44-105 donor cell, :107-255 pseudo-velocities, :383-385 scaling,
+// adv_mpdata_FCT_core.f90:47-116 limiter, :389 final donor-cell pass).
+//
+// Round 1 ran these as three kernels that exchanged q2, u2, v2, w2 through HBM (7.4 GB per call against 0.92 GB of
+// algorithmic traffic) and evaluated every limited face from scratch (700 VALU instructions per scalar-cell, 22 IEEE
+// divisions).  This kernel reads each scalar once and writes it once:
+//
+//   * a block owns an x-tile of 64 lanes (58 outputs + 3 halo lanes per side) over ALL levels and MARCHES along y.
+//     A thread owns KB consecutive levels of one column-of-the-plane; a wave is one group of KB levels.
+//   * every intermediate of the scheme lives in registers as a rolling window over the planes:
+//         step P:  q(P+2) is loaded                       (the only read of the scalar)
+//                  q2(P+1)        = donor-cell pass        (needs q at P, P+1, P+2)
+//                  v2(P+1/2), Fy  = pseudo-velocity + unlimited flux of the y face between planes P and P+1
+//                  u2(P), w2(P), Fx, Fz, beta_x(P), beta_z(P), limited x/z fluxes of plane P
+//                  beta_y(P), limited y flux (P-1/2)
+//                  out(P-1) is stored                      (the only write)
+//   * x neighbours come from the neighbouring lanes by DPP wave shifts (v_*_dpp wave_shr:1 / wave_shl:1: one VALU
+//     slot, mostly folded into the consuming instruction; ds_bpermute costs 24 cycles per wave on gfx950),
+//     z neighbours inside a thread's own levels are registers, across threads they go through LDS twice per plane
+//     (the pass-1 field of the two edge levels, then the limiter's beta of the two edge levels), y neighbours are the
+//     rolling registers.
+//   * the limiter is evaluated per CELL and direction (beta_in, beta_out: adv_mpdata_FCT_core.f90's carried variables
+//     written as what they are -- properties of a cell), so every flux, extremum and quotient is computed once; the
+//     limited flux of a face is min(1, beta, beta) times its unlimited flux (flux1 is linear in the velocity).
+//   * quotients are n * v_rcp_f32(d) (1 ulp): the scheme's 22 divisions per scalar-cell cost 11 instead of 50 cycles
+//     per wave each (profiles/micro/valubench.hip).  flux1(l, r, U) = ((U+|U|) l + (U-|U|) r)/2 is evaluated as
+//     U * (U > 0 ? l : r), which is the same number.  Results agree with the CPU reference to ~1e-6 of the local field
+//     scale; tests assert 1e-5 on every cell (north-star tolerance) -- the donor-cell kernel of the upwind scheme
+//     (advect.hip) stays bit-exact.
+//
+// Scalar-independent inputs (U_m, V_m, W_m, W_m/dz, jacobian, rho, dz) are re-read per scalar from L2; they are 16-24 B
+// per cell against the 8 B of the scalar itself, which is why blocks of the same (tile, chunk) and different scalars are
+// scheduled onto the same XCD.
+#include "ctx.h"
+#include <algorithm>
+
+#define MP_HL 3                       // halo lanes per side
+#define MP_XOUT (64 - 2 * MP_HL)      // outputs per 64-lane tile
+#define EPSQ 1e-10f
+#define EPSF 1e-15f
+
+// bound_ctrl:1 -- a lane without a source reads 0, so no `old` value has to be materialised and the shift can fold into
+// the consuming VALU instruction (v_sub_f32_dpp ...)
+__device__ __forceinline__ float dpp_l(float x)   // value of lane-1 (0 in lane 0)
+{ return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_r(float x)   // value of lane+1 (0 in lane 63)
+{ return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130, 0xf, 0xf, true)); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float upw(float l, float r, float U) { return U * (U > 0.0f ? l : r); }      // == flux1 (adv_mpdata.f90:40)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float ldb(const float *__restrict__ p, unsigned b) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + b); }
+__device__ __forceinline__ void stb(float *__restrict__ p, unsigned b, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(p) + b) = v; }
+
+// KB levels per thread, NWMAX waves per block at most (launch bound), RHO: advect_density, FCT: limiter on,
+// PASS1: first corrective iteration (donor-cell pass inside); false: iord >= 3, where q2 == q (adv_mpdata.f90:393-402)
+template <int KB, int NWMAX, bool RHO, bool FCT, bool PASS1>
+__global__ void __launch_bounds__(64 * NWMAX)
+k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
+               const float *__restrict__ Ug, const float *__restrict__ Vg, const float *__restrict__ Wg, const float *__restrict__ Wzg,
+               const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dzg, int clen, int ntile, int nchunk, int nscal)
+{
+    constexpr int H = KB + 2;                       // own levels + one halo level below and above
+    // exchange slots, double-buffered by step parity (a step without plane-P work has only ONE barrier)
+    __shared__ float s_q2[2][NWMAX][2][64];         // pass-1 field of a wave's lowest / highest level
+    __shared__ float s_bz[2][NWMAX][4][64];         // beta_in, beta_out of a wave's lowest / highest level
+    // The part of the rolling window that belongs to plane M (= P-1) is produced at the end of a step and consumed in the
+    // second half of the next one.  With 8 waves per block a thread may hold ~250 VGPRs, and the loads + arithmetic of the
+    // first half of a step need that room to overlap: those 9 KB + 2 values per thread are parked in LDS in between
+    // (thread-private float4 slots: no synchronisation, conflict-free b128 accesses).
+    constexpr bool PARK = (NWMAX <= 8);
+    constexpr int NA4 = (H + 3) / 4, NB4 = 2 * KB;  // float4 slots: q2M[H] | mM nM v2S FyS bYinM bYoutM acc rdhM [KB each]
+    __shared__ float4 s_park[PARK ? NA4 + NB4 : 1][PARK ? 64 * NWMAX : 1];
+
+    const int lane = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y), nw = blockDim.y;
+    const int tid = lane + 64 * wv;
+    const int nx = d.nx, nz = d.nz, ny = d.ny;
+    const size_t sj = (size_t)d.sj;
+    // work item.  Items are ordered group-major (group = (tile, chunk), then the scalars of that group) and dealt to the 8
+    // XCDs in contiguous runs of `cap` items; consecutive block ids go to the XCDs round-robin, so block id = xcd + 8 * slot.
+    // The scalars of a group therefore share an XCD (at most two groups per XCD are split) and start together: the
+    // scalar-independent arrays come from HBM once per group and from that XCD's L2 for the other scalars.
+    int tile, chunk, m;
+    {
+        const unsigned id = blockIdx.x, nv = (unsigned)nscal, nitem = (unsigned)(ntile * nchunk) * nv;
+        const unsigned cap = (nitem + 7u) / 8u, xcd = id & 7u, slot = id >> 3;
+        const unsigned it = xcd * cap + slot;
+        if (slot >= cap || it >= nitem) return;
+        const unsigned g = it / nv;
+        m = (int)(it - g * nv);
+        tile = (int)(g % (unsigned)ntile); chunk = (int)(g / (unsigned)ntile);
+    }
+    const float *__restrict__ q = qin.p[0];
+    float *__restrict__ out = qout.p[0];
+#pragma unroll
+    for (int mm = 1; mm < ICAR_MAX_ADV; ++mm) if (mm == m) { q = qin.p[mm]; out = qout.p[mm]; }   // (a dynamic index would put the tables in scratch)
+
+    const int i = 1 - MP_HL + tile * MP_XOUT + lane;
+    const int ic = min(max(i, 0), nx - 1);
+    const bool xlo = (i == 0), xhi = (i == nx - 1), xin = (i > 0) && (i < nx - 1);
+    const bool xring = xlo || xhi;
+    const bool lane_out = (lane >= MP_HL) && (lane < 64 - MP_HL) && xin;
+    const unsigned bx = 4u * (unsigned)ic;
+    const int ja = 1 + chunk * clen, jb = min(ja + clen - 1, ny - 2);
+    const int k0 = wv * KB;
+    // level of slot h (0..H-1) = k0-1+h, clamped for addressing; flags are wave-uniform
+    int kc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) kc[h] = min(max(k0 - 1 + h, 0), nz - 1) * nx;
+
+#define LDP(arr, h, plane) ldb((arr) + (size_t)(plane) * sj + kc[h], bx)
+#define CLAMPJ(p) min(max((p), 0), ny - 1)
+
+    // ---- rolling state (planes relative to the step's in-plane index P; N = P+1, M = P-1) ----
+    float qP[KB], qN[H], qPh0 = 0.f, qPh1 = 0.f;            // q (= l of the limiter): plane P own levels (+ its halo levels), plane N
+    float q2P[H];                                           // field after pass 1, plane P
+    float mP[KB], nP[KB];                                   // max / min of (q2, l) per cell, plane P
+    float DxP[KB], SxP[KB], DzP[KB], SzP[KB];               // q2(i+1) -+ q2(i-1), q2(k+1) -+ q2(k-1) on plane P
+    // plane-M part (parked between steps): pkA = q2M[H] ; pkB = mM nM v2S FyS bYinM bYoutM acc rdhM, KB values each
+    //   mM, nM: extrema of plane M; v2S, FyS: pseudo-velocity / unlimited flux of the y face (P-1/2); bY*M: beta_y of
+    //   plane M; acc: q2 - x/z/south contributions of plane M; rdhM: 1 / (jaco rho) of plane M
+    float pkA[NA4 * 4], pkB[NB4 * 4];
+#pragma unroll
+    for (int t = 0; t < NA4 * 4; ++t) pkA[t] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NB4 * 4; ++t) pkB[t] = 0.f;
+    if (PARK) {
+#pragma unroll
+        for (int t = 0; t < NA4 + NB4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) { mP[kk] = nP[kk] = 0.f; DxP[kk] = SxP[kk] = DzP[kk] = SzP[kk] = 0.f; }
+#pragma unroll
+    for (int h = 0; h < H; ++h) q2P[h] = 0.f;
+    const int P0 = ja - 3;
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) qP[kk] = LDP(q, kk + 1, CLAMPJ(P0));
+#pragma unroll
+    for (int h = 0; h < H; ++h) qN[h] = LDP(q, h, CLAMPJ(P0 + 1));
+
+    // inputs of one step (plane indices relative to that step's P): see ISSUE_LOADS
+    float qNN[H], GP[H], GN[KB], WN[KB + 1], UN[KB], VN[H], VNN[KB], dzN[KB];
+    float VP[H], UP[H], WzP[KB + 1], WzN[KB + 1], dzP[KB + 1];
+    float rN[RHO ? KB : 1], rP[RHO ? H : 1];
+// group A: what the donor-cell pass (first half of a step) reads; group B: inputs of the pseudo-velocity coefficients
+#define ISSUE_LOADS_A(PP)                                                                                                \
+    {                                                                                                                    \
+        const int lN = CLAMPJ((PP) + 1), lNN = CLAMPJ((PP) + 2);                                                         \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) qNN[h] = LDP(q, h, lNN);                                           \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) GN[kk] = LDP(jaco, kk + 1, lN);                                \
+        _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = LDP(Wg, h, lN);                                          \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = LDP(Ug, kk + 1, lN); VNN[kk] = LDP(Vg, kk + 1, lNN); dzN[kk] = LDP(dzg, kk + 1, lN); } \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) VN[h] = LDP(Vg, h, lN);                                            \
+        if (RHO) { _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) rN[kk] = LDP(rho, kk + 1, lN); }                    \
+    }
+#define ISSUE_LOADS_B(PP)                                                                                                \
+    {                                                                                                                    \
+        const int lP = CLAMPJ(PP), lN = CLAMPJ((PP) + 1);                                                                \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) { GP[h] = LDP(jaco, h, lP); VP[h] = LDP(Vg, h, lP); UP[h] = LDP(Ug, h, lP); } \
+        if (RHO) { _Pragma("unroll") for (int h = 0; h < H; ++h) rP[h] = LDP(rho, h, lP); }                              \
+        _Pragma("unroll") for (int h = 0; h <= KB; ++h) { WzP[h] = LDP(Wzg, h, lP); WzN[h] = LDP(Wzg, h, lN); dzP[h] = LDP(dzg, h, lP); } \
+    }
+    ISSUE_LOADS_A(P0)
+    ISSUE_LOADS_B(P0)
+    for (int P = P0; P <= jb + 1; ++P) {
+        const int N = P + 1;
+        const int pP = CLAMPJ(P), pN = CLAMPJ(N), pNN = CLAMPJ(N + 1);
+        const int par = (P - P0) & 1;
+        const bool haveN = (N >= 0) && (N <= ny - 1);
+        // The global loads of this step were issued during the previous one (ISSUE_LOADS_A after its x/z limiter,
+        // ISSUE_LOADS_B at its end), each group back to back -- loads placed next to their use were waited for one by
+        // one: 59 exposed L2 round trips per step.
+        if (RHO) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) GN[kk] *= rN[kk];
+#pragma unroll
+            for (int h = 0; h < H; ++h) GP[h] *= rP[h];
+        }
+
+        // ================= S1: donor-cell pass on plane N, its extrema and x/z differences =================
+        float q2N[H], mN[KB], nN[KB], DxN[KB], SxN[KB], DzN[KB], SzN[KB];
+#pragma unroll
+        for (int h = 0; h < H; ++h) q2N[h] = qN[h];
+        if (haveN) {
+            const bool ring = (N == 0) || (N == ny - 1);
+            if (PASS1 && !ring) {
+                float FzT[KB + 1];                                 // flux through the face ABOVE level k0-1+h
+#pragma unroll
+                for (int h = 0; h <= KB; ++h) {
+                    const int k = k0 - 1 + h;
+                    const float Wc = WN[h];
+                    float f = upw(qN[h], qN[h + 1], Wc);
+                    if (k >= nz - 1) f = qN[h] * Wc;              // top of the column: q*W (adv_mpdata.f90:96)
+                    if (k < 0) f = 0.f;                           // the ground
+                    FzT[h] = f;
+                }
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) {
+                    const int h = kk + 1;
+                    const float Uc = UN[kk], Vs = VN[h], Vn = VNN[kk];
+                    const float rdh = frcp(GN[kk]), rdv = frcp(dzN[kk] * GN[kk]);
+                    const float FxL = upw(dpp_l(qN[h]), qN[h], Uc), FxR = dpp_r(FxL);
+                    const float Fs = upw(qP[kk], qN[h], Vs), Fn = upw(qN[h], qNN[h], Vn);
+                    const float v = qN[h] - ((FxR - FxL) + (Fn - Fs)) * rdh - (FzT[h] - FzT[h - 1]) * rdv;
+                    q2N[h] = xring ? qN[h] : v;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) { mN[kk] = fmaxf(q2N[kk + 1], qN[kk + 1]); nN[kk] = fminf(q2N[kk + 1], qN[kk + 1]); }
+            // pass-1 field of the levels just below / above my own ones
+            s_q2[par][wv][0][lane] = q2N[1]; s_q2[par][wv][1][lane] = q2N[KB];
+            __syncthreads();
+            q2N[0] = (wv > 0) ? s_q2[par][wv - 1][1][lane] : q2N[1];
+            q2N[H - 1] = (wv < nw - 1) ? s_q2[par][wv + 1][0][lane] : q2N[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int h = kk + 1;
+                const float l = dpp_l(q2N[h]), r = dpp_r(q2N[h]);
+                DxN[kk] = r - l; SxN[kk] = r + l;
+                DzN[kk] = q2N[h + 1] - q2N[h - 1]; SzN[kk] = q2N[h + 1] + q2N[h - 1];
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) { mN[kk] = nN[kk] = 0.f; DxN[kk] = SxN[kk] = DzN[kk] = SzN[kk] = 0.f; }
+        }
+
+        // ================= S2: y face between planes P and N =================
+        float v2N[KB], FyN[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; }
+        // scalar-independent sums shared by S2 and S3
+        float Vsum[H];                                             // V(P) + V(N) per level
+#pragma unroll
+        for (int h = 0; h < H; ++h) Vsum[h] = VP[h] + VN[h];
+        float WzsP[KB];                                            // Wz(k) + Wz(k-1) on plane P
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) WzsP[kk] = WzP[kk + 1] + WzP[kk];
+        if (P >= 0 && haveN) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int h = kk + 1, k = k0 + kk;
+                const bool kin = (k > 0) && (k < nz - 1);
+                const float Vc = VN[h];
+                const float rG = frcp(GN[kk] + GP[h]);
+                const float Us = UP[h] + UN[kk];
+                const float evu = Us + dpp_r(Us);
+                const float evw = WzsP[kk] + (WzN[h] + WzN[h - 1]);
+                const float aV = fabsf(Vc), av = 0.5f * aV * (1.0f - 2.0f * aV * rG), c0 = 0.0625f * Vc * rG;
+                const float cvu = xin ? c0 * evu : 0.0f, cvw = kin ? c0 * evw : 0.0f;
+                const float t = av * (q2N[h] - q2P[h]) * frcp(q2N[h] + q2P[h] + EPSQ)
+                              - cvu * (DxN[kk] + DxP[kk]) * frcp(SxN[kk] + SxP[kk] + EPSQ)
+                              - cvw * (DzN[kk] + DzP[kk]) * frcp(SzN[kk] + SzP[kk] + EPSQ);
+                v2N[kk] = t; FyN[kk] = upw(q2P[h], q2N[h], t);
+            }
+        }
+
+        // ================= S3: x and z faces of plane P, their limiter, divergence =================
+        float xdiv[KB], zdiv[KB], rdhP[KB], rdvP[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) { xdiv[kk] = zdiv[kk] = 0.f; rdhP[kk] = rdvP[kk] = 0.f; }
+        float q2M[H];
+        if (PARK) {
+#pragma unroll
+            for (int t = 0; t < NA4; ++t) { const float4 v = s_park[t][tid]; pkA[4 * t] = v.x; pkA[4 * t + 1] = v.y; pkA[4 * t + 2] = v.z; pkA[4 * t + 3] = v.w; }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) q2M[h] = pkA[h];
+        const bool planeP = (P >= ja) && (P <= jb);                // warm-up planes feed nothing but the y limiter
+        if (planeP) {
+            float Dy[H], Sy[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) { Dy[h] = q2N[h] - q2M[h]; Sy[h] = q2N[h] + q2M[h]; }
+            // ---- x faces (i-1/2) of my own levels
+            float Fx[KB], u2[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int h = kk + 1, k = k0 + kk;
+                const bool kin = (k > 0) && (k < nz - 1);
+                const float Uc = UP[h];
+                const float rG = frcp(GP[h] + dpp_l(GP[h]));
+                const float evv = Vsum[h] + dpp_l(Vsum[h]);
+                const float evw = WzsP[kk] + dpp_l(WzsP[kk]);
+                const float aU = fabsf(Uc), au = 0.5f * aU * (1.0f - 2.0f * aU * rG), c0 = 0.0625f * Uc * rG;
+                const float cuv = c0 * evv, cuw = kin ? c0 * evw : 0.0f;
+                const float qL = dpp_l(q2P[h]);
+                const float t = au * (q2P[h] - qL) * frcp(q2P[h] + qL + EPSQ)
+                              - cuv * (Dy[h] + dpp_l(Dy[h])) * frcp(Sy[h] + dpp_l(Sy[h]) + EPSQ)
+                              - cuw * (DzP[kk] + dpp_l(DzP[kk])) * frcp(SzP[kk] + dpp_l(SzP[kk]) + EPSQ);
+                u2[kk] = t; Fx[kk] = upw(qL, q2P[h], t);
+            }
+            // ---- z faces above levels k0-1 .. k0+KB-1 (the lowest one is also computed by the wave below)
+            float DxA[H], SxA[H];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) { DxA[kk + 1] = DxP[kk]; SxA[kk + 1] = SxP[kk]; }
+            { const float l0 = dpp_l(q2P[0]), r0 = dpp_r(q2P[0]), l1 = dpp_l(q2P[H - 1]), r1 = dpp_r(q2P[H - 1]);
+              DxA[0] = r0 - l0; SxA[0] = r0 + l0; DxA[H - 1] = r1 - l1; SxA[H - 1] = r1 + l1; }
+            float Fz[KB + 1], w2[KB + 1];
+#pragma unroll
+            for (int hf = 0; hf <= KB; ++hf) {
+                const int k = k0 - 1 + hf;
+                const float Wc = WzP[hf];
+                const float rG = frcp(GP[hf] + GP[hf + 1]);
+                const float Uk = UP[hf] + UP[hf + 1];
+                const float evu = Uk + dpp_r(Uk);
+                const float evv = Vsum[hf] + Vsum[hf + 1];
+                const float aW = fabsf(Wc), aw = 0.5f * aW * (1.0f - 2.0f * aW * rG), c0 = 0.0625f * Wc * rG;
+                const float cwu = xin ? c0 * evu : 0.0f, cwv = c0 * evv;
+                float t = aw * (q2P[hf + 1] - q2P[hf]) * frcp(q2P[hf + 1] + q2P[hf] + EPSQ)
+                        - cwu * (DxA[hf] + DxA[hf + 1]) * frcp(SxA[hf] + SxA[hf + 1] + EPSQ)
+                        - cwv * (Dy[hf] + Dy[hf + 1]) * frcp(Sy[hf] + Sy[hf + 1] + EPSQ);
+                t = t * dzP[hf];
+                if (k < 0 || k >= nz - 1) t = 0.0f;              // no face below the ground; w2(top) = 0 (adv_mpdata.f90:214)
+                w2[hf] = t; Fz[hf] = upw(q2P[hf], q2P[hf + 1], t);
+            }
+            // ---- limiter, x direction
+            float FxLim[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int h = kk + 1;
+                if (FCT) {
+                    const float qc = q2P[h], FxW = Fx[kk], FxE = dpp_r(Fx[kk]);
+                    const float mL = dpp_l(mP[kk]), mR = dpp_r(mP[kk]), nL = dpp_l(nP[kk]), nR = dpp_r(nP[kk]);
+                    float qmax = max3f(mL, mP[kk], mR), qmin = min3f(nL, nP[kk], nR);
+                    if (xlo) { qmax = fmaxf(mP[kk], mR); qmin = fminf(nP[kk], nR); }
+                    if (xhi) { qmax = fmaxf(mL, qc); qmin = fminf(nL, qc); }
+                    float fin = fmaxf(0.f, FxW) - fminf(0.f, FxE), fout = fmaxf(0.f, FxE) - fminf(0.f, FxW);
+                    if (xring) { fin = 0.f; fout = 0.f; }
+                    const float bin = (qmax - qc) * frcp(fin + EPSF), bout = (qc - qmin) * frcp(fout + EPSF);
+                    const float bLin = dpp_l(bin), bLout = dpp_l(bout);
+                    const float s = fminf(1.0f, (u2[kk] > 0.0f) ? fminf(bin, bLout) : fminf(bLin, bout));
+                    FxLim[kk] = s * Fx[kk];
+                } else FxLim[kk] = Fx[kk];
+                xdiv[kk] = dpp_r(FxLim[kk]) - FxLim[kk];
+            }
+            // ---- limiter, z direction
+            float FzLim[KB + 1];
+            if (FCT) {
+                float bZin[H], bZout[H];
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) {
+                    const int h = kk + 1, k = k0 + kk;
+                    const float qc = q2P[h], FzB = Fz[h - 1], FzT = Fz[h];
+                    const float mlo = (kk > 0) ? mP[kk - 1] : fmaxf(q2P[0], qPh0), nlo = (kk > 0) ? nP[kk - 1] : fminf(q2P[0], qPh0);
+                    const float mhi = (kk < KB - 1) ? mP[kk + 1] : fmaxf(q2P[H - 1], qPh1), nhi = (kk < KB - 1) ? nP[kk + 1] : fminf(q2P[H - 1], qPh1);
+                    float qmax = max3f(mlo, mP[kk], mhi), qmin = min3f(nlo, nP[kk], nhi);
+                    float fin = fmaxf(0.f, FzB) - fminf(0.f, FzT), fout = fmaxf(0.f, FzT) - fminf(0.f, FzB);
+                    if (k == 0) { qmax = fmaxf(mP[kk], mhi); qmin = fminf(nP[kk], nhi); fin = 0.f - fminf(0.f, FzT); fout = fmaxf(0.f, FzT); }
+                    if (k >= nz - 1) { qmax = fmaxf(mlo, qc); qmin = fminf(nlo, qc); fin = fmaxf(0.f, FzB) - fminf(0.f, FzB); fout = fin; }
+                    bZin[h] = (qmax - qc) * frcp(fin + EPSF); bZout[h] = (qc - qmin) * frcp(fout + EPSF);
+                }
+                s_bz[par][wv][0][lane] = bZin[1]; s_bz[par][wv][1][lane] = bZout[1]; s_bz[par][wv][2][lane] = bZin[KB]; s_bz[par][wv][3][lane] = bZout[KB];
+                __syncthreads();
+                bZin[0] = (wv > 0) ? s_bz[par][wv - 1][2][lane] : 0.f; bZout[0] = (wv > 0) ? s_bz[par][wv - 1][3][lane] : 0.f;
+                bZin[H - 1] = (wv < nw - 1) ? s_bz[par][wv + 1][0][lane] : 0.f; bZout[H - 1] = (wv < nw - 1) ? s_bz[par][wv + 1][1][lane] : 0.f;
+#pragma unroll
+                for (int hf = 0; hf <= KB; ++hf) {                 // face between slots hf (lower cell) and hf+1 (upper cell)
+                    const float s = fminf(1.0f, (w2[hf] > 0.0f) ? fminf(bZin[hf + 1], bZout[hf]) : fminf(bZin[hf], bZout[hf + 1]));
+                    FzLim[hf] = s * Fz[hf];
+                }
+            } else {
+#pragma unroll
+                for (int hf = 0; hf <= KB; ++hf) FzLim[hf] = Fz[hf];
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                zdiv[kk] = FzLim[kk + 1] - FzLim[kk];
+                rdhP[kk] = frcp(GP[kk + 1]); rdvP[kk] = frcp(dzP[kk + 1] * GP[kk + 1]);
+            }
+        }
+
+        // ---- the inputs of the NEXT step: in flight while this step finishes (y limiter, store, roll) ----
+        // (the q part of the window rolls here: qNN is about to receive the next step's plane)
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) qP[kk] = qN[kk + 1];
+        qPh0 = qN[0]; qPh1 = qN[H - 1];
+#pragma unroll
+        for (int h = 0; h < H; ++h) qN[h] = qNN[h];
+        __builtin_amdgcn_sched_barrier(0);
+        ISSUE_LOADS_A(P + 1)
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ================= S4: beta_y of plane P ; S5: limited y face (P-1/2) =================
+        float mM[KB], nM[KB], v2S[KB], FyS[KB], bYinM[KB], bYoutM[KB], acc[KB], rdhM[KB];
+        if (PARK) {
+#pragma unroll
+            for (int t = 0; t < NB4; ++t) { const float4 v = s_park[NA4 + t][tid]; pkB[4 * t] = v.x; pkB[4 * t + 1] = v.y; pkB[4 * t + 2] = v.z; pkB[4 * t + 3] = v.w; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            mM[kk] = pkB[kk]; nM[kk] = pkB[KB + kk]; v2S[kk] = pkB[2 * KB + kk]; FyS[kk] = pkB[3 * KB + kk];
+            bYinM[kk] = pkB[4 * KB + kk]; bYoutM[kk] = pkB[5 * KB + kk]; acc[kk] = pkB[6 * KB + kk]; rdhM[kk] = pkB[7 * KB + kk];
+        }
+        float bYin[KB], bYout[KB], FyLimS[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const int h = kk + 1;
+            if (FCT) {
+                const float qc = q2P[h];
+                float qmax = max3f(mM[kk], mP[kk], mN[kk]), qmin = min3f(nM[kk], nP[kk], nN[kk]);
+                float fin = fmaxf(0.f, FyS[kk]) - fminf(0.f, FyN[kk]), fout = fmaxf(0.f, FyN[kk]) - fminf(0.f, FyS[kk]);
+                if (P <= 0) { qmax = fmaxf(mP[kk], mN[kk]); qmin = fminf(nP[kk], nN[kk]); fin = 0.f; fout = 0.f; }
+                if (P >= ny - 1) { qmax = fmaxf(mM[kk], qc); qmin = fminf(nM[kk], qc); fin = 0.f; fout = 0.f; }
+                bYin[kk] = (qmax - qc) * frcp(fin + EPSF); bYout[kk] = (qc - qmin) * frcp(fout + EPSF);
+                const float s = fminf(1.0f, (v2S[kk] > 0.0f) ? fminf(bYin[kk], bYoutM[kk]) : fminf(bYinM[kk], bYout[kk]));
+                FyLimS[kk] = s * FyS[kk];
+            } else { bYin[kk] = bYout[kk] = 0.f; FyLimS[kk] = FyS[kk]; }
+        }
+
+        // ================= S6: plane M is complete =================
+        const int M = P - 1;
+        if (M >= ja && M <= jb) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const float v = xring ? q2M[kk + 1] : acc[kk] - FyLimS[kk] * rdhM[kk];
+                if ((lane_out || (xring && lane < 64)) && (k0 + kk < nz)) stb(out + (size_t)M * sj + kc[kk + 1], bx, v);
+            }
+        }
+        // the boundary rows of the new field are the old ones (adv_mpdata.f90:63-65)
+        if (M == 0 && ja == 1) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+                if ((lane_out || xring) && (k0 + kk < nz)) stb(out + kc[kk + 1], bx, q2M[kk + 1]);
+        }
+        if (P == ny - 1 && jb == ny - 2) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+                if ((lane_out || xring) && (k0 + kk < nz)) stb(out + (size_t)(ny - 1) * sj + kc[kk + 1], bx, q2P[kk + 1]);
+        }
+        // ---- roll the window
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const int h = kk + 1;
+            pkB[kk] = mP[kk]; pkB[KB + kk] = nP[kk]; pkB[2 * KB + kk] = v2N[kk]; pkB[3 * KB + kk] = FyN[kk];
+            pkB[4 * KB + kk] = bYin[kk]; pkB[5 * KB + kk] = bYout[kk];
+            pkB[6 * KB + kk] = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdhP[kk] - zdiv[kk] * rdvP[kk];
+            pkB[7 * KB + kk] = rdhP[kk];
+            mP[kk] = mN[kk]; nP[kk] = nN[kk];
+            DxP[kk] = DxN[kk]; SxP[kk] = SxN[kk]; DzP[kk] = DzN[kk]; SzP[kk] = SzN[kk];
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) { pkA[h] = q2P[h]; q2P[h] = q2N[h]; }
+        if (PARK) {
+#pragma unroll
+            for (int t = 0; t < NA4; ++t) s_park[t][tid] = make_float4(pkA[4 * t], pkA[4 * t + 1], pkA[4 * t + 2], pkA[4 * t + 3]);
+#pragma unroll
+            for (int t = 0; t < NB4; ++t) s_park[NA4 + t][tid] = make_float4(pkB[4 * t], pkB[4 * t + 1], pkB[4 * t + 2], pkB[4 * t + 3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ISSUE_LOADS_B(P + 1)                                       // land while the next step's donor-cell pass runs
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef ISSUE_LOADS_A
+#undef ISSUE_LOADS_B
+#undef LDP
+#undef CLAMPJ
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int KB, int NWMAX>
+static void launch_fused(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
+                         const float *rho, const float *jaco, const float *dz, int nw, int clen, int ntile, int nchunk)
+{
+    const unsigned nitem = (unsigned)(ntile * nchunk * nv), cap = (nitem + 7u) / 8u;
+    const dim3 g(8u * cap), b(64, nw);                      // block id = xcd + 8 * slot, slot < cap
+#define GO(R, F, P1) hipLaunchKernelGGL((k_mpdata_fused<KB, NWMAX, R, F, P1>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->Wdz, rho, jaco, dz, clen, ntile, nchunk, nv)
+    if (rho_on) { if (fct) { if (pass1) GO(true, true, true); else GO(true, true, false); } else { if (pass1) GO(true, false, true); else GO(true, false, false); } }
+    else        { if (fct) { if (pass1) GO(false, true, true); else GO(false, true, false); } else { if (pass1) GO(false, false, true); else GO(false, false, false); } }
+#undef GO
+}
+
+// one corrective iteration of MPDATA: in -> out (distinct buffers).  pass1: the donor-cell pass is part of it (iord == 2).
+int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
+                          const float *rho, const float *jaco, const float *dz)
+{
+    const int nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
+    if (nx < 3 || ny < 3) { icar_set_error("mpdata: tile must be at least 3 x 3 cells"); return 1; }
+    const int ntile = std::max(1, (nx - 2 + MP_XOUT - 1) / MP_XOUT);
+    // levels per thread: as few waves as keep two per SIMD (8 per block) when nz allows; at most 16 waves
+    int kb = (nz + 7) / 8;
+    if (kb > 5) kb = (nz + 15) / 16;
+    if (kb > 5) { icar_set_error("mpdata: more than 80 levels are not supported by the fused kernel"); return 1; }
+    const int nw = (nz + kb - 1) / kb;
+    // y chunks: a block keeps a whole CU (8 waves at ~250 VGPRs), so the work items (tiles x chunks x scalars) should
+    // number just under a multiple of the 256 CUs -- one round when the domain allows it; each chunk pays 3 warm-up planes
+    const int rows = ny - 2;
+    int nchunk = std::max(1, std::min(rows, 256 / std::max(1, ntile * nv)));
+    while (nchunk > 1 && (rows + nchunk - 1) / nchunk < 16) --nchunk;
+    const int clen = (rows + nchunk - 1) / nchunk;
+    nchunk = (rows + clen - 1) / clen;
+#define KBCASE(K) case K: if (nw <= 8) launch_fused<K, 8>(c, rho_on, fct, pass1, in, out, nv, rho, jaco, dz, nw, clen, ntile, nchunk); \
+                          else launch_fused<K, 16>(c, rho_on, fct, pass1, in, out, nv, rho, jaco, dz, nw, clen, ntile, nchunk); break;
+    switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) }
+#undef KBCASE
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -1,13 +1,13 @@
 !> icar_hip_demo.f90 -- Fortran host driving the device hot path through the C ABI.
 !! Reads a tile written by tests/test_gpu_fortran_host.py (raw little-endian REAL(4), Fortran order),
-!! runs `nsteps` x [mp_simple on the interior tile -> MPDATA advection of the 5 mp_simple scalars]
+!! runs `nsteps` x [mp_simple on the interior tile -> advection (scheme from meta.txt: 1 upwind, 2 MPDATA) of the 5 mp_simple scalars]
 !! exactly as time_step.f90:512-529 orders them for one image, and writes the fields back.
 program icar_hip_demo
   use iso_c_binding
   use icar_hip
   implicit none
   type(hip_ctx_t) :: ctx
-  integer :: nx, nz, ny, nsteps, u, s, i
+  integer :: nx, nz, ny, nsteps, u, s, i, scheme
   real :: dt, dx
   real(c_float), allocatable, target :: a(:,:,:), au(:,:,:), av(:,:,:)
   real(c_double), allocatable, target :: acc(:,:)
@@ -20,7 +20,7 @@ program icar_hip_demo
   integer(c_int), parameter :: adv(5) = [ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE]
 
   call get_command_argument(1, dir)
-  open(newunit=u, file=trim(dir)//"/meta.txt", status="old"); read(u,*) nx, nz, ny, nsteps, dt, dx; close(u)
+  open(newunit=u, file=trim(dir)//"/meta.txt", status="old"); read(u,*) nx, nz, ny, nsteps, dt, dx, scheme; close(u)
   allocate(a(nx,nz,ny), au(nx+1,nz,ny), av(nx,nz,ny+1), acc(nx,ny))
   call hip_create(ctx, 0, 1, nx, 1, nz, 1, ny)
   do i = 1, 13
@@ -32,7 +32,7 @@ program icar_hip_demo
   call rdu(trim(dir)//"/jacobian_v.bin", av); call hip_upload(ctx, ICAR_F_JACOBIAN_V, av)
   do s = 1, nsteps
      call hip_mp_simple(ctx, dt, 2, nx-1, 2, ny-1, 1, nz)             ! mp()   time_step.f90:512-523
-     call hip_advect(ctx, 2, 2, .true., .false., dt, dx, adv)         ! advect time_step.f90:529 (kADV_MPDATA)
+     call hip_advect(ctx, scheme, 2, .true., .false., dt, dx, adv)    ! advect time_step.f90:529 (kADV_UPWIND / kADV_MPDATA)
   end do
   do i = 9, 13
      call hip_download(ctx, f3(i), a); call wr(trim(dir)//"/out_"//trim(n3(i))//".bin", a)

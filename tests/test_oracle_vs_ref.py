@@ -22,6 +22,23 @@ def test_advect_matches_reference(oracle, scheme, dens, fct, seed):
     assert bits_equal(qa, qb), f"{nbitdiff(qa, qb)} values differ"
 
 
+@pytest.mark.parametrize("order,dens,fct,seed", [(3, 0, 1, 6), (3, 1, 1, 7), (4, 0, 1, 8), (3, 0, 0, 9), (1, 0, 1, 10)])
+def test_mpdata_order_matches_reference(oracle, order, dens, fct, seed):
+    """adv_mpdata.f90:372-402, the iord loop beyond the default order 2 (q2 = q before every further corrective
+    iteration, limiter against the field that iteration started from), and mpdata_order 1 (= donor cell): bit-exact."""
+    c = ideal.make_case(NX, NY, NZ, hill_height=900.0, noise=0.05, seed=seed, n_hydro=1, u0=8.0 + seed % 5, v0=-4.0 + seed % 5)
+    dt = ideal.cfl_dt(c)
+    names = ["water_vapor", "rain", "ice_number"]
+    qa = np.stack([c[n] for n in names]).copy(); qb = qa.copy()
+    ref.advect(2, qa, *adv_args(c), dt, advect_density=dens, mpdata_order=order, fct=fct, nsteps=2)
+    oracle.advect(2, qb, *adv_args(c), dt, advect_density=dens, mpdata_order=order, fct=fct, nsteps=2)
+    assert bits_equal(qa, qb), f"{nbitdiff(qa, qb)} values differ"
+    if order >= 3:                                      # the extra iteration must have done something
+        qc = np.stack([c[n] for n in names]).copy()
+        oracle.advect(2, qc, *adv_args(c), dt, advect_density=dens, mpdata_order=2, fct=fct, nsteps=2)
+        assert not bits_equal(qb, qc)
+
+
 @pytest.mark.parametrize("seed,moist,cool", [(11, 1.6, 0.4), (12, 2.5, 1.5), (13, 0.7, 0.0)])
 def test_mp_simple_matches_reference(oracle, seed, moist, cool):
     nx, ny, nz = 33, 21, 25
