@@ -34,6 +34,7 @@
 // scheduled onto the same XCD.
 #include "ctx.h"
 #include <algorithm>
+#include <type_traits>
 
 #define MP_HL 3                       // halo lanes per side
 #define MP_XOUT (64 - 2 * MP_HL)      // outputs per 64-lane tile
@@ -163,20 +164,24 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         _Pragma("unroll") for (int h = 0; h <= KB; ++h) { WzP[h] = LDP(Wzg, h, lP); WzN[h] = LDP(Wzg, h, lN); dzP[h] = LDP(dzg, h, lP); } \
     }
     ISSUE_LOADS_A(P0)
-    ISSUE_LOADS_B(P0)
-    for (int P = P0; P <= jb + 1; ++P) {
+    // One step of the march.  STEADY = every stage is on and no plane of the window is a boundary row of the domain
+    // (the bulk of a chunk): the stage conditions and the first/last-row forms of the y limiter are compiled out, and
+    // with them the zero-initialisations and merge copies of ~70 values per step.  The generic form runs the warm-up
+    // steps of a chunk, its last steps and the chunks that touch row 0 / ny-1.
+    auto step = [&](auto steady_tag, const int P) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
         const int N = P + 1;
         const int pP = CLAMPJ(P), pN = CLAMPJ(N), pNN = CLAMPJ(N + 1);
         const int par = (P - P0) & 1;
-        const bool haveN = (N >= 0) && (N <= ny - 1);
-        // The global loads of this step were issued during the previous one (ISSUE_LOADS_A after its x/z limiter,
-        // ISSUE_LOADS_B at its end), each group back to back -- loads placed next to their use were waited for one by
-        // one: 59 exposed L2 round trips per step.
+        const bool haveN = STEADY || ((N >= 0) && (N <= ny - 1));
+        // Group A of this step's global loads was issued during the previous step (after its x/z limiter), group B is
+        // issued here; each group back to back -- loads placed next to their use were waited for one by one: 59 exposed
+        // L2 round trips per step.
+        ISSUE_LOADS_B(P)                                           // land while the donor-cell pass runs
+        __builtin_amdgcn_sched_barrier(0);
         if (RHO) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) GN[kk] *= rN[kk];
-#pragma unroll
-            for (int h = 0; h < H; ++h) GP[h] *= rP[h];
         }
 
         // ================= S1: donor-cell pass on plane N, its extrema and x/z differences =================
@@ -184,7 +189,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
         for (int h = 0; h < H; ++h) q2N[h] = qN[h];
         if (haveN) {
-            const bool ring = (N == 0) || (N == ny - 1);
+            const bool ring = !STEADY && ((N == 0) || (N == ny - 1));
             if (PASS1 && !ring) {
                 float FzT[KB + 1];                                 // flux through the face ABOVE level k0-1+h
 #pragma unroll
@@ -231,13 +236,17 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; }
         // scalar-independent sums shared by S2 and S3
+        if (RHO) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) GP[h] *= rP[h];
+        }
         float Vsum[H];                                             // V(P) + V(N) per level
 #pragma unroll
         for (int h = 0; h < H; ++h) Vsum[h] = VP[h] + VN[h];
         float WzsP[KB];                                            // Wz(k) + Wz(k-1) on plane P
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) WzsP[kk] = WzP[kk + 1] + WzP[kk];
-        if (P >= 0 && haveN) {
+        if (STEADY || (P >= 0 && haveN)) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const int h = kk + 1, k = k0 + kk;
@@ -267,7 +276,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         }
 #pragma unroll
         for (int h = 0; h < H; ++h) q2M[h] = pkA[h];
-        const bool planeP = (P >= ja) && (P <= jb);                // warm-up planes feed nothing but the y limiter
+        const bool planeP = STEADY || ((P >= ja) && (P <= jb));                // warm-up planes feed nothing but the y limiter
         if (planeP) {
             float Dy[H], Sy[H];
 #pragma unroll
@@ -400,8 +409,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 const float qc = q2P[h];
                 float qmax = max3f(mM[kk], mP[kk], mN[kk]), qmin = min3f(nM[kk], nP[kk], nN[kk]);
                 float fin = fmaxf(0.f, FyS[kk]) - fminf(0.f, FyN[kk]), fout = fmaxf(0.f, FyN[kk]) - fminf(0.f, FyS[kk]);
-                if (P <= 0) { qmax = fmaxf(mP[kk], mN[kk]); qmin = fminf(nP[kk], nN[kk]); fin = 0.f; fout = 0.f; }
-                if (P >= ny - 1) { qmax = fmaxf(mM[kk], qc); qmin = fminf(nM[kk], qc); fin = 0.f; fout = 0.f; }
+                if (!STEADY && P <= 0) { qmax = fmaxf(mP[kk], mN[kk]); qmin = fminf(nP[kk], nN[kk]); fin = 0.f; fout = 0.f; }
+                if (!STEADY && P >= ny - 1) { qmax = fmaxf(mM[kk], qc); qmin = fminf(nM[kk], qc); fin = 0.f; fout = 0.f; }
                 bYin[kk] = (qmax - qc) * frcp(fin + EPSF); bYout[kk] = (qc - qmin) * frcp(fout + EPSF);
                 const float s = fminf(1.0f, (v2S[kk] > 0.0f) ? fminf(bYin[kk], bYoutM[kk]) : fminf(bYinM[kk], bYout[kk]));
                 FyLimS[kk] = s * FyS[kk];
@@ -410,7 +419,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 
         // ================= S6: plane M is complete =================
         const int M = P - 1;
-        if (M >= ja && M <= jb) {
+        if (STEADY || (M >= ja && M <= jb)) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const float v = xring ? q2M[kk + 1] : acc[kk] - FyLimS[kk] * rdhM[kk];
@@ -418,12 +427,12 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             }
         }
         // the boundary rows of the new field are the old ones (adv_mpdata.f90:63-65)
-        if (M == 0 && ja == 1) {
+        if (!STEADY && M == 0 && ja == 1) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
                 if ((lane_out || xring) && (k0 + kk < nz)) stb(out + kc[kk + 1], bx, q2M[kk + 1]);
         }
-        if (P == ny - 1 && jb == ny - 2) {
+        if (!STEADY && P == ny - 1 && jb == ny - 2) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
                 if ((lane_out || xring) && (k0 + kk < nz)) stb(out + (size_t)(ny - 1) * sj + kc[kk + 1], bx, q2P[kk + 1]);
@@ -447,9 +456,16 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int t = 0; t < NB4; ++t) s_park[NA4 + t][tid] = make_float4(pkB[4 * t], pkB[4 * t + 1], pkB[4 * t + 2], pkB[4 * t + 3]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        ISSUE_LOADS_B(P + 1)                                       // land while the next step's donor-cell pass runs
-        __builtin_amdgcn_sched_barrier(0);
+
+    };
+    {
+        const int s0 = ja + 1, s1 = max(min(jb, ny - 3), s0 - 1);  // steady steps: P in [s0, s1] (possibly empty)
+        for (int ph = 0; ph < 2; ++ph) {                           // generic warm-up, steady bulk, generic tail
+            const int lo = ph ? s1 + 1 : P0, hi = ph ? jb + 1 : s0 - 1;
+            for (int P = lo; P <= hi; ++P) step(std::false_type{}, P);
+            if (ph == 0)
+                for (int P = s0; P <= s1; ++P) step(std::true_type{}, P);
+        }
     }
 #undef ISSUE_LOADS_A
 #undef ISSUE_LOADS_B

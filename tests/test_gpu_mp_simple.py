@@ -8,8 +8,8 @@ the same as the flang/glibc reference is exp(): the device evaluates it in FP64 
   * oracle math-mode 0 (bit-identical to the compiled reference, tests/test_oracle_vs_ref.py):
     rtol 1e-5 (the north-star tolerance).  A 1-ulp change of e_s can flip the
     `abs(lastqv-qv) > 1e-4` convergence test of the saturation adjustment (mp_simple.f90:217) in
-    rare cells, moving qv/qc there by < 1e-4/2 -- so up to 1 % of cells may exceed rtol, bounded by
-    the scheme's own 1e-4 threshold.  tests/test_oracle_modes.py shows the CPU oracle has the same
+    rare cells, moving qv/qc there by < 1e-4/2 -- measured <= 1.2e-3 of the cells exceed rtol (bound asserted:
+    2.5e-3), every difference bounded by the scheme's own 1e-4 threshold and by 2e-4 of the field maximum.  tests/test_oracle_modes.py shows the CPU oracle has the same
     sensitivity between its two modes."""
 import numpy as np
 import pytest
@@ -17,17 +17,21 @@ from icar_amd import ideal
 from icar_amd.options import options_t
 from icar_amd.microphysics import mp, mp_init, mp_tiles
 from icar_amd.constants import kMP_SB04
-from util import single_image_domain
+from util import single_image_domain, parity_record, field_stats
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
-def compare(name, a, b, frac_allowed=1e-2, abs_bound=1e-4):
+def compare(name, a, b, frac_allowed=1e-2, abs_bound=1e-4, label=None, rel_bound=None):
+    if label:
+        parity_record("mp_simple", label, {name: field_stats(a, b, RTOL)})
     a = a.astype(np.float64); b = b.astype(np.float64)
     scale = max(np.abs(b).max(), 1e-30)
     bad = np.abs(a - b) > RTOL * np.maximum(np.abs(b), 1e-3 * scale)
     assert bad.mean() <= frac_allowed, f"{name}: {bad.mean():.2e} of cells beyond rtol {RTOL}"
+    if rel_bound is not None:
+        assert np.abs(a - b).max() <= rel_bound * scale, f"{name}: max|d|/max = {np.abs(a - b).max() / scale:.2e}"
     if name in ("water_vapor", "cloud_water_mass", "rain_mass", "snow_mass"):
         assert np.abs(a - b).max() <= abs_bound, f"{name}: max|d|={np.abs(a-b).max()}"
 
@@ -70,6 +74,10 @@ def _run(oracle, nx, ny, nz, steps, dt, moist, cool, hill):
     return out, ref
 
 
+# bounds of the reference-math (mode 0) comparisons: <= 2x the values measured on MI355X (profiles/r02_parity.json)
+#   measured: <= 1.2e-3 of the cells beyond rtol 1e-5 (config1_size), max |d| <= 9.3e-5 of the field maximum (warm_rain)
+BOUNDS_MODE0 = dict(frac_allowed=2.5e-3, abs_bound=1e-4, rel_bound=2e-4)
+
 CASES = {"warm_rain": dict(nx=70, ny=36, nz=20, steps=6, dt=40.0),
          "snow": dict(nx=66, ny=20, nz=30, steps=8, dt=60.0, moist=2.5, cool=1.5),
          "config1_size": dict(nx=100, ny=100, nz=30, steps=3, dt=30.0)}
@@ -90,7 +98,7 @@ def test_mp_simple_bit_exact_vs_oracle_fp64exp(oracle, case):
 def test_mp_simple_within_tolerance_of_reference_math(oracle, case):
     out, ref = run(oracle, mode=0, **CASES[case])
     for k in ref:
-        compare(k, out[k], ref[k])
+        compare(k, out[k], ref[k], label=case + "/mode0", **BOUNDS_MODE0)
 
 
 def test_halo_plus_subset_equals_full(oracle):
@@ -140,9 +148,11 @@ def test_mp_simple_layouts_bit_identical(nz):
         assert np.array_equal(outs[None][k], outs["lane"][k]), f"{k}: {(outs[None][k] != outs['lane'][k]).sum()} cells differ"
 
 
-def test_mp_simple_full_size_column_subset_vs_oracle(oracle):
+@pytest.mark.parametrize("mode", [1, 0])
+def test_mp_simple_full_size_column_subset_vs_oracle(oracle, mode):
     """BASELINE size (512x512x40): 4000 random columns, re-run by the CPU oracle as a small domain of their own (the scheme
-    is column-local), must be BIT-identical to the device (oracle math-mode 1); all fields stay finite and non-negative."""
+    is column-local): BIT-identical to the device in oracle math-mode 1 (the device's definition of expf), within the
+    recorded tolerance in mode 0 (the reference's libm); all fields stay finite and non-negative."""
     nx = ny = 512; nz = 40; dt = 45.0; steps = 3
     c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01)
     c["water_vapor"] = (c["water_vapor"] * np.float32(1.7)).astype(np.float32)
@@ -154,7 +164,7 @@ def test_mp_simple_full_size_column_subset_vs_oracle(oracle):
     names = ["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water", "rain", "snow", "dz_mass"]
     sub = {k: np.ascontiguousarray(np.pad(np.stack([c[k][jj, :, ii].T] * 3, axis=0), ((0, 0), (0, 0), (1, 1)), mode="edge")) for k in names}
     n = sub["pressure"].shape[2]
-    oracle.set_math_mode(1)
+    oracle.set_math_mode(mode)
     try:
         for _ in range(steps):
             mp(d, opt, dt); d.model_time_seconds += dt
@@ -171,7 +181,10 @@ def test_mp_simple_full_size_column_subset_vs_oracle(oracle):
         a = d.get(m)
         assert np.isfinite(a).all() and (k == "potential_temperature" or a.min() >= 0), k
         got = a[jj, :, ii].T; ref = sub[k][1, :, 1:-1]
-        assert np.array_equal(got, ref), f"{k}: {(got != ref).sum()} of {got.size} subset cells differ"
+        if mode == 1:
+            assert np.array_equal(got, ref), f"{k}: {(got != ref).sum()} of {got.size} subset cells differ"
+        else:
+            compare(m, got, ref, label="full_size_subset/mode0", **BOUNDS_MODE0)
     assert d.get("rain_mass").max() > 1e-5
     d.close()
 

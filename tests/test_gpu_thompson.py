@@ -4,10 +4,11 @@
   bit-identical to the compiled reference, tests/test_oracle_vs_ref.py): the O(1e10)-term FP64
   collection integrals run on the GPU in the reference's summation order without FMA contraction.
 * column physics: compared with the oracle in math-mode 1 (float pow/exp/log10 evaluated in FP64 and
-  rounded once -- the device's definition; the remaining difference is the last bit of FP64
-  pow/exp/log between ocml and glibc, ~1e-16 relative) and in mode 0 (the reference's libm).
-  Tolerance: rtol 1e-5 relative to each field's column-scale (north-star tolerance); table indices
-  and category switches are integer-exact, so differences stay at rounding level."""
+  rounded once -- the device's definition): BIT-IDENTICAL, every field, every case (asserted: bounds 0);
+  and in mode 0 (the reference's libm, bit-identical to the compiled reference): rtol 1e-5 (north-star
+  tolerance) on all but a measured <= 2.1e-3 of the cells -- a 1-ulp difference of expf / powf flips one of
+  the scheme's category thresholds there -- with max |d| <= 1.3e-5 of the field maximum.  The measured values are
+  recorded by every run (gpurun_out/parity -> profiles/r02_parity.json); the asserted bounds are <= 2.5x them."""
 import ctypes
 import numpy as np
 import pytest
@@ -16,7 +17,7 @@ from icar_amd.capi import lib, check
 from icar_amd.options import options_t
 from icar_amd.microphysics import mp, mp_init
 from icar_amd.constants import kMP_THOMPSON
-from util import single_image_domain
+from util import single_image_domain, parity_record, field_stats
 
 pytestmark = pytest.mark.gpu
 TABLES = ["tcg_racg", "tmr_racg", "tcr_gacr", "tmg_gacr", "tnr_racg", "tnr_gacr", "tcs_racs1", "tmr_racs1", "tcs_racs2",
@@ -87,17 +88,28 @@ def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, 
     return out, ref
 
 
-def check_close(out, ref, rtol, frac_allowed, label):
-    report = []
+def check_close(out, ref, rtol, frac_allowed, label, abs_allowed=None):
+    """Per field: the fraction of cells beyond rtol must not exceed frac_allowed and max |d| / max|field| must not exceed
+    abs_allowed; the measured values go to gpurun_out/parity/ (-> profiles/r02_parity.json), the bounds are <= 2x them."""
+    report = []; stats = {}
     for k in list(FIELDS) + ["acc_rain", "acc_snow", "acc_graupel"]:
-        a = out[k].astype(np.float64); b = ref[k].astype(np.float64)
-        scale = max(np.abs(b).max(), 1e-300)
-        bad = np.abs(a - b) > rtol * np.maximum(np.abs(b), 1e-3 * scale)
-        nb = int((out[k] != ref[k].astype(out[k].dtype)).sum())
-        report.append(f"{k}: bitdiff {nb}/{a.size}, beyond-rtol {bad.mean():.2e}, max|d|/max {np.abs(a-b).max()/scale:.2e}")
-        assert bad.mean() <= frac_allowed, f"[{label}] " + report[-1]
+        st = field_stats(out[k], ref[k], rtol); stats[k] = st
+        report.append(f"{k}: bitdiff {st['bitdiff_frac']:.2e}, beyond-rtol {st['beyond_rtol_frac']:.2e}, max|d|/max {st['max_abs_over_max']:.2e}")
+    parity_record("thompson", label, stats)
     print(f"[{label}]\n  " + "\n  ".join(report))
+    for k, st in stats.items():
+        assert st["beyond_rtol_frac"] <= frac_allowed, f"[{label}] {k}: {st}"
+        if abs_allowed is not None:
+            assert st["max_abs_over_max"] <= abs_allowed, f"[{label}] {k}: {st}"
 
+
+# (frac_allowed, abs_allowed) per oracle math mode: <= 2x the values measured on MI355X (profiles/r02_parity.json)
+#   mode 1 (the device's definition of the float transcendentals): measured 0 differing bits in every case -> asserted exact
+#   mode 0 (the reference's libm): measured <= 2.1e-3 of the cells beyond rtol 1e-5 (long_dt; 5e-5 / 6e-5 in the other cases),
+#           max |d| <= 1.3e-5 of the field maximum; full-size subset: no cell beyond rtol, max |d| 5.6e-6 of the maximum
+FULL_SIZE_BOUNDS = {1: (0.0, 0.0), 0: (1e-4, 1.2e-5)}
+MODE1_BOUNDS = dict(frac_allowed=0.0, abs_allowed=0.0)
+MODE0_BOUNDS = dict(frac_allowed=5e-3, abs_allowed=3e-5)
 
 CASES = {"warm_mixed": dict(nx=70, ny=20, nz=30, steps=10, cool=1.0, moist=1.6, dt=40.0),
          "cold_graupel": dict(nx=66, ny=18, nz=40, steps=20, cool=2.0, moist=2.0, dt=60.0),
@@ -110,13 +122,13 @@ def test_thompson_vs_oracle_device_math(th_oracle, case):
     if case == "cold_graupel":
         assert ref["snow"].max() > 1e-4 and ref["graupel"].max() > 1e-5 and ref["cloud_ice"].max() > 1e-6
     assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
-    check_close(out, ref, rtol=1e-5, frac_allowed=1e-4, label=case + "/mode1")
+    check_close(out, ref, rtol=1e-5, label=case + "/mode1", **MODE1_BOUNDS)
 
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_thompson_vs_oracle_reference_math(th_oracle, case):
     out, ref = run_case(th_oracle, mode=0, **CASES[case])
-    check_close(out, ref, rtol=1e-5, frac_allowed=2e-2, label=case + "/mode0")
+    check_close(out, ref, rtol=1e-5, label=case + "/mode0", **MODE0_BOUNDS)
 
 
 def test_thompson_excludes_last_global_row_and_column(th_oracle):
@@ -178,7 +190,7 @@ def test_thompson_other_level_counts_vs_oracle(th_oracle, nz):
     out, ref = run_case(th_oracle, mode=1, nx=30, ny=10, nz=nz, steps=8, cool=2.0, moist=2.0, dt=60.0,
                         uniform_dz=150.0 if nz == 100 else None)
     assert ref["rain"].max() > 1e-6
-    check_close(out, ref, rtol=1e-5, frac_allowed=1e-4, label=f"nz{nz}/mode1")
+    check_close(out, ref, rtol=1e-5, label=f"nz{nz}/mode1", **MODE1_BOUNDS)
 
 
 def test_halo_strips_in_one_launch_equal_four_launches():
@@ -213,7 +225,8 @@ def test_halo_strips_in_one_launch_equal_four_launches():
     assert inner.max() == 0.0, "only the halo ring is processed"
 
 
-def test_thompson_full_size_budget_and_column_subset_vs_oracle(th_oracle):
+@pytest.mark.parametrize("mode", [1, 0])
+def test_thompson_full_size_budget_and_column_subset_vs_oracle(th_oracle, mode):
     """BASELINE size (512x512x40): (a) every species stays non-negative and finite, (b) the column water budget closes to within
     1 % (microphysics only moves water between species / levels / the surface), (c) 3000 random columns, re-run by the CPU
     oracle as a small domain of their own (the scheme is column-local), agree with the device to the usual tolerance."""
@@ -240,7 +253,7 @@ def test_thompson_full_size_budget_and_column_subset_vs_oracle(th_oracle):
         q = sum(f[k].astype(np.float64) for k in ("water_vapor", "cloud_water", "rain", "cloud_ice", "snow", "graupel"))
         return (q * rho0 * c["dz_mass"]).sum(axis=1)
     before = water_path(c)
-    th_oracle.set_math_mode(1)
+    th_oracle.set_math_mode(mode)
     try:
         for _ in range(steps):
             mp(d, opt, dt); d.model_time_seconds += dt
@@ -268,11 +281,11 @@ def test_thompson_full_size_budget_and_column_subset_vs_oracle(th_oracle):
     assert resid.max() <= 0.01 * before[inner].max(), f"column water budget residual {resid.max():.3e} of {before[inner].max():.3e}"
     got = {k: out[k][jj, :, ii].T for k in keys}                                          # (nz, 3000)
     ref = {k: sub[k][1, :, 1:-1] for k in keys}
-    for k in keys:
-        a = got[k].astype(np.float64); b = ref[k].astype(np.float64)
-        scale = max(np.abs(b).max(), 1e-300)
-        bad = np.abs(a - b) > 1e-5 * np.maximum(np.abs(b), 1e-3 * scale)
-        assert bad.mean() <= 1e-4, f"{k}: {bad.mean():.2e} of the subset beyond rtol 1e-5 (bit-different: {(got[k] != ref[k]).mean():.2e})"
+    stats = {k: field_stats(got[k], ref[k], 1e-5) for k in keys}
+    parity_record("thompson", f"full_size_subset/mode{mode}", stats)
+    frac_allowed, abs_allowed = FULL_SIZE_BOUNDS[mode]
+    for k, st in stats.items():
+        assert st["beyond_rtol_frac"] <= frac_allowed and st["max_abs_over_max"] <= abs_allowed, f"mode {mode} {k}: {st}"
 
 
 def test_table_cache_files_byte_identical_to_the_reference(tmp_path):
@@ -317,7 +330,7 @@ def test_non_default_mp_options(oracle):
         d.close()
         out, ref = run_case(oracle, mode=1, mp_options=mpo, **CASES["cold_graupel"])
         assert ref["snow"].max() > 1e-4 and ref["graupel"].max() > 1e-5
-        check_close(out, ref, rtol=1e-5, frac_allowed=1e-4, label="alt/mode1")
+        check_close(out, ref, rtol=1e-5, label="alt/mode1", **MODE1_BOUNDS)
     finally:
         po, fo = options_t().mp_options.as_arrays()
         oracle.thompson_init(po, fo)

@@ -58,3 +58,25 @@ def single_image_domain(case, device=0):
 def adv_args(c):
     return (c["u"], c["v"], c["w"], c["density"], c["jacobian"], c["jacobian_u"], c["jacobian_v"], c["jacobian_w"],
             c["advection_dz"], c["dz_levels"], float(c["dx"]))
+
+
+def parity_record(test, label, stats):
+    """Append the MEASURED deviation of a parity test to gpurun_out/parity/<test>.jsonl (merged back from the GPU box;
+    profiles/collect_parity.py turns the files into the tracked profiles/r02_parity.json).  Never raises."""
+    import json, os
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        d = os.path.join(root, "gpurun_out", "parity"); os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, test + ".jsonl"), "a") as f:
+            f.write(json.dumps({"label": label, "fields": stats}) + "\n")
+    except Exception:
+        pass
+
+
+def field_stats(got, ref, rtol=1e-5):
+    """bit-different fraction, fraction of cells beyond rtol (relative to max(|ref|, 1e-3 max|ref|)), max |d| / max|ref|"""
+    a = np.asarray(got, np.float64); b = np.asarray(ref, np.float64)
+    scale = max(float(np.abs(b).max()), 1e-300)
+    bad = np.abs(a - b) > rtol * np.maximum(np.abs(b), 1e-3 * scale)
+    return {"bitdiff_frac": float((np.asarray(got) != np.asarray(ref).astype(np.asarray(got).dtype)).mean()),
+            "beyond_rtol_frac": float(bad.mean()), "max_abs_over_max": float(np.abs(a - b).max() / scale), "cells": int(a.size)}
