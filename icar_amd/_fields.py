@@ -9,7 +9,8 @@ PRESSURE_INTERFACE, TEMPERATURE, TEMPERATURE_INTERFACE, U_MASS, V_MASS, W_REAL, 
 Z, NSQUARED = 35, 36
 IVT, IWV, IWL, IWI = 37, 38, 39, 40
 ZR_U, ZR_V = 41, 42
-N_FIELDS = 43
+SINTHETA, COSTHETA = 43, 44
+N_FIELDS = 45
 
 NAMES = {
     "water_vapor": WATER_VAPOR, "cloud_water_mass": CLOUD_WATER, "rain_mass": RAIN, "snow_mass": SNOW,
@@ -20,7 +21,7 @@ NAMES = {
     "jacobian_v": JACOBIAN_V, "jacobian_w": JACOBIAN_W, "advection_dz": ADVECTION_DZ,
     "pressure_interface": PRESSURE_INTERFACE, "temperature": TEMPERATURE, "temperature_interface": TEMPERATURE_INTERFACE,
     "u_mass": U_MASS, "v_mass": V_MASS, "w_real": W_REAL, "dzdx": DZDX, "dzdy": DZDY, "surface_pressure": SURFACE_PRESSURE,
-    "z": Z, "nsquared": NSQUARED, "ivt": IVT, "iwv": IWV, "iwl": IWL, "iwi": IWI, "zr_u": ZR_U, "zr_v": ZR_V,
+    "z": Z, "nsquared": NSQUARED, "ivt": IVT, "iwv": IWV, "iwl": IWL, "iwi": IWI, "zr_u": ZR_U, "zr_v": ZR_V, "sintheta": SINTHETA, "costheta": COSTHETA,
     "accumulated_precipitation": PRECIPITATION, "accumulated_snowfall": SNOWFALL, "graupel": GRAUPEL_ACC,
 }
-IS_2DD = {PRECIPITATION, SNOWFALL, GRAUPEL_ACC}
+IS_2DD = {PRECIPITATION, SNOWFALL, GRAUPEL_ACC, SINTHETA, COSTHETA}

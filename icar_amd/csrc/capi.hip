@@ -18,7 +18,7 @@ int icar_hip_check(hipError_t e, const char *what)
 // ------------------------------------------------------------------------------------------------
 // field registry
 // ------------------------------------------------------------------------------------------------
-static bool field_is_2dd(int f) { return f == ICAR_F_PRECIPITATION || f == ICAR_F_SNOWFALL || f == ICAR_F_GRAUPEL_ACC; }
+static bool field_is_2dd(int f) { return f == ICAR_F_PRECIPITATION || f == ICAR_F_SNOWFALL || f == ICAR_F_GRAUPEL_ACC || f == ICAR_F_SINTHETA || f == ICAR_F_COSTHETA; }
 
 size_t icar_field_count(const icar_hip_ctx *c, int f)
 {
@@ -329,6 +329,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
     if (c->iw_adj) hipFree(c->iw_adj);
+    if (c->wgr_tmp) hipFree(c->wgr_tmp);
     icar_wsm3_free(c);
     icar_thompson_free(c);
     icar_linwinds_free(c);
@@ -563,6 +564,13 @@ int icar_hip_balance_uvw_update(icar_hip_ctx *c, float dx)
     if (!c) { icar_set_error("null ctx"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_balance_uvw_run(c, dx, 1);
+}
+
+int icar_hip_make_winds_grid_relative(icar_hip_ctx *c, int update)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_make_winds_grid_relative(c, update);
 }
 
 int icar_hip_mass_conservative_acceleration(icar_hip_ctx *c, int update)

@@ -43,6 +43,7 @@ struct icar_hip_ctx {
     float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
     bool winds_valid = false;
     float *iw_adj = nullptr;             // iterative_winds ADJ scratch (iterative_winds.hip)
+    float *wgr_tmp = nullptr;            // make_winds_grid_relative: rotated mass-grid u | v (2 x n3)
     // reductions / flags
     float *d_red = nullptr;              // small device scratch for reductions
     std::vector<float> dzl_host;         // dz_levels last uploaded behind d_red (compute_dt re-sends them only when they change)
@@ -82,6 +83,7 @@ int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update);
 int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update);
 int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update);
 int icar_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int update);
+int icar_make_winds_grid_relative(icar_hip_ctx *c, int update);
 int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, float *buf, bool unpack);
 int icar_diagnostic_update_run(icar_hip_ctx *c);
 int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);

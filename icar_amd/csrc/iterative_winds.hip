@@ -119,6 +119,62 @@ int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// make_winds_grid_relative (wind.f90:236-287).  The reference works in place with whole-array statements; here the
+// rotated mass-grid winds go to a scratch pair and a second pass restaggers from it.  Same operations, same order:
+// REAL (a+b)/2, the REAL*DOUBLE products in double rounded once on assignment.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_wgr_rotate(Dims d, const float *__restrict__ u, const float *__restrict__ v, const double *__restrict__ st,
+                             const double *__restrict__ ct, float *__restrict__ ur, float *__restrict__ vr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y, j = blockIdx.z;
+    if (i >= d.nx) return;
+    const size_t cu = (size_t)i + (size_t)(d.nx + 1) * (k + (size_t)d.nz * j), c = (size_t)d.idx(i, k, j);
+    const float uc = (u[cu] + u[cu + 1]) / 2, vc = (v[c] + v[c + d.sj]) / 2;              // :254-255
+    const double cs = ct[i + (size_t)d.nx * j], sn = st[i + (size_t)d.nx * j];
+    ur[c] = (float)((double)uc * cs - (double)vc * sn);                                    // :260
+    vr[c] = (float)((double)vc * cs + (double)uc * sn);                                    // :261
+}
+__global__ void k_wgr_restagger(Dims d, const float *__restrict__ ur, const float *__restrict__ vr, float *__restrict__ u, float *__restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y, j = blockIdx.z;      // i in 0..nx, j in 0..ny
+    const int nx = d.nx, ny = d.ny;
+    if (i <= nx && j < ny) {                                                                 // u (nx+1, nz, ny): :270-272
+        const float *r = ur + (size_t)nx * (k + (size_t)d.nz * j);
+        float val;
+        if (i == 0) val = 2 * r[0] - (r[0] + r[1]) / 2;
+        else if (i == nx) val = 2 * ((r[nx - 2] + r[nx - 1]) / 2) - ((nx - 2 >= 1) ? (r[nx - 3] + r[nx - 2]) / 2 : 2 * r[0] - (r[0] + r[1]) / 2);
+        else val = (r[i - 1] + r[i]) / 2;
+        u[(size_t)i + (size_t)(nx + 1) * (k + (size_t)d.nz * j)] = val;
+    }
+    if (i < nx && j <= ny) {                                                                 // v (nx, nz, ny+1): :274-276
+        const size_t sj = (size_t)d.sj; const float *r = vr + (size_t)i + (size_t)nx * k;
+        float val;
+        if (j == 0) val = 2 * r[0] - (r[0] + r[sj]) / 2;
+        else if (j == ny) val = 2 * ((r[(ny - 2) * sj] + r[(ny - 1) * sj]) / 2) - ((ny - 2 >= 1) ? (r[(ny - 3) * sj] + r[(ny - 2) * sj]) / 2 : 2 * r[0] - (r[0] + r[sj]) / 2);
+        else val = (r[(j - 1) * sj] + r[j * sj]) / 2;
+        v[(size_t)i + (size_t)nx * (k + (size_t)d.nz * j)] = val;
+    }
+}
+}  // namespace
+
+int icar_make_winds_grid_relative(icar_hip_ctx *c, int update)
+{
+    float *u = update ? c->dqdt[ICAR_F_U] : icar_field_f(c, ICAR_F_U), *v = update ? c->dqdt[ICAR_F_V] : icar_field_f(c, ICAR_F_V);
+    if (!u || !v) { if (update) icar_set_error("make_winds_grid_relative(update): upload the u and v dqdt_3d first"); return 1; }
+    const double *st = (const double *)icar_field_f(c, ICAR_F_SINTHETA), *ct = (const double *)icar_field_f(c, ICAR_F_COSTHETA);
+    if (!st || !ct) return 1;
+    if (c->d.nx < 2 || c->d.ny < 2) { icar_set_error("make_winds_grid_relative: tile too small"); return 1; }
+    if (!c->wgr_tmp) HIPCHK(hipMalloc(&c->wgr_tmp, 2 * c->n3 * sizeof(float)));
+    float *ur = c->wgr_tmp, *vr = c->wgr_tmp + c->n3;
+    hipLaunchKernelGGL(k_wgr_rotate, dim3((c->d.nx + 63) / 64, c->d.nz, c->d.ny), dim3(64), 0, c->stream, c->d, u, v, st, ct, ur, vr);
+    hipLaunchKernelGGL(k_wgr_restagger, dim3((c->d.nx + 1 + 63) / 64, c->d.nz, c->d.ny + 1), dim3(64), 0, c->stream, c->d, ur, vr, u, v);
+    HIPCHK(hipGetLastError());
+    if (!update) c->winds_valid = false;
+    return 0;
+}
+
 int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update)
 {
     Winds q;

@@ -8,7 +8,7 @@
 //   W2  spatial_winds             :840-1127  (N^2 field, smoothing, bracket search, 8-corner LUT interpolation)
 //
 // MI355X design.
-//  * FFTs: hipFFT Z2Z (FP64 complex like the reference's FFTW plans), batched.  The reference runs one pair of
+//  * FFTs: rocFFT, FP64 complex (like the reference's FFTW plans), batched.  The reference runs one pair of
 //    inverse FFTs per (combo, level, sub-layer); the inverse transform is linear, so here the sub-layer sum is
 //    taken in spectral space (each term still rounded through the reference's single-precision ifftshift temp,
 //    fftshift.f90:221) and ONE pair of FFTs per (combo, level) is done, all levels of a combo in one batched
@@ -24,11 +24,29 @@
 //  * W2 is per forcing step, bandwidth/gather bound; running sums of smooth_array are kept sequential (one
 //    thread per line) so that the result is bit-identical to the reference's FP64 running sums.
 #include "ctx.h"
-#include <hipfft/hipfft.h>
+#include <rocfft/rocfft.h>
 #include <cmath>
 #include <vector>
 #include <algorithm>
 #include <cstring>
+
+// One batched 2-D FP64 complex transform of the (fftnx, fftny) planes, rocFFT called directly (north star: "the linear-wind
+// FFT uses rocFFT"; round 1 went through the hipFFT front end).  A rocFFT plan fixes direction and placement, so a slot
+// keeps one plan per use: inverse in place (every LUT entry / perturbation) and forward out of place (the terrain spectrum).
+struct RocPlan {
+    rocfft_plan inv = nullptr, fwd = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *work = nullptr; size_t work_bytes = 0;
+    int batch = 0;
+    void destroy()
+    {
+        if (inv) rocfft_plan_destroy(inv);
+        if (fwd) rocfft_plan_destroy(fwd);
+        if (info) rocfft_execution_info_destroy(info);
+        if (work) hipFree(work);
+        inv = fwd = nullptr; info = nullptr; work = nullptr; work_bytes = 0; batch = 0;
+    }
+};
 
 struct LinWinds {
     icar_hip_lt_options o;
@@ -39,7 +57,7 @@ struct LinWinds {
     float *k1 = nullptr, *l1 = nullptr;                        // lt_data%k(:,1), lt_data%l(1,:)
     std::vector<float> dirv, spdv, nsqv;
     float *d_vals = nullptr;                                   // dir | spd | nsq values on the device
-    hipfftHandle plan[2] = {0, 0}; int plan_batch[2] = {0, 0};
+    RocPlan plan[2];                                           // slot 0: single transforms (either direction); slot 1: the LUT build's batch
     double2 *spec = nullptr; size_t spec_cap = 0;              // [comp][level][fftny][fftnx]
     float *d_z = nullptr; int *d_nsteps = nullptr; int max_steps = 0, nlev = 0;
     float *lut[2] = {nullptr, nullptr}; bool lut_ready = false;
@@ -47,10 +65,10 @@ struct LinWinds {
     double *rowmeans = nullptr; float *u1d = nullptr, *v1d = nullptr; int4 *brk = nullptr; float2 *brw = nullptr;
 };
 
-static int fftchk(hipfftResult r, const char *what)
+static int fftchk(rocfft_status r, const char *what)
 {
-    if (r == HIPFFT_SUCCESS) return 0;
-    char b[128]; snprintf(b, sizeof b, "hipFFT error %d in %s", (int)r, what);
+    if (r == rocfft_status_success) return 0;
+    char b[128]; snprintf(b, sizeof b, "rocFFT error %d in %s", (int)r, what);
     icar_set_error(b); return 1;
 }
 #define FFTCHK(x) do { if (fftchk((x), #x)) return 1; } while (0)
@@ -59,7 +77,7 @@ void icar_linwinds_free(icar_hip_ctx *c)
 {
     LinWinds *w = c->linwinds;
     if (!w) return;
-    for (int i = 0; i < 2; ++i) { if (w->plan_batch[i]) hipfftDestroy(w->plan[i]); if (w->lut[i]) hipFree(w->lut[i]); if (w->pert[i]) hipFree(w->pert[i]); }
+    for (int i = 0; i < 2; ++i) { w->plan[i].destroy(); if (w->lut[i]) hipFree(w->lut[i]); if (w->pert[i]) hipFree(w->pert[i]); }
     void *p[] = {w->hhat, w->k1, w->l1, w->d_vals, w->spec, w->d_z, w->d_nsteps, w->rowmeans, w->u1d, w->v1d, w->brk, w->brw};
     for (void *q : p) if (q) hipFree(q);
     delete w; c->linwinds = nullptr;
@@ -285,14 +303,37 @@ __global__ void k_lut_transpose(float *__restrict__ dev, float *__restrict__ ref
 // ------------------------------------------------------------------------------------------------ W3 host
 static int ensure_plan(LinWinds *w, int slot, int batch, hipStream_t s)
 {
-    if (w->plan_batch[slot] == batch) return 0;
-    if (w->plan_batch[slot]) { hipfftDestroy(w->plan[slot]); w->plan_batch[slot] = 0; }
-    int n[2] = {w->fftny, w->fftnx};
-    const int dist = w->fftnx * w->fftny;
-    FFTCHK(hipfftPlanMany(&w->plan[slot], 2, n, nullptr, 1, dist, nullptr, 1, dist, HIPFFT_Z2Z, batch));
-    FFTCHK(hipfftSetStream(w->plan[slot], s));
-    w->plan_batch[slot] = batch;
+    static bool setup_done = false;
+    if (!setup_done) { FFTCHK(rocfft_setup()); setup_done = true; }
+    RocPlan &P = w->plan[slot];
+    if (P.batch != batch) {
+        P.destroy();
+        const size_t len[2] = {(size_t)w->fftnx, (size_t)w->fftny};          // fastest dimension first
+        FFTCHK(rocfft_plan_create(&P.inv, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, 2, len, (size_t)batch, nullptr));
+        FFTCHK(rocfft_plan_create(&P.fwd, rocfft_placement_notinplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 2, len, (size_t)batch, nullptr));
+        FFTCHK(rocfft_execution_info_create(&P.info));
+        size_t wi = 0, wf = 0;
+        FFTCHK(rocfft_plan_get_work_buffer_size(P.inv, &wi));
+        FFTCHK(rocfft_plan_get_work_buffer_size(P.fwd, &wf));
+        P.work_bytes = wi > wf ? wi : wf;
+        if (P.work_bytes) {
+            HIPCHK(hipMalloc(&P.work, P.work_bytes));
+            FFTCHK(rocfft_execution_info_set_work_buffer(P.info, P.work, P.work_bytes));
+        }
+        P.batch = batch;
+    }
+    FFTCHK(rocfft_execution_info_set_stream(P.info, s));
     return 0;
+}
+static int fft_inverse_inplace(LinWinds *w, int slot, double2 *buf)
+{
+    void *io[1] = {buf};
+    return fftchk(rocfft_execute(w->plan[slot].inv, io, nullptr, w->plan[slot].info), "rocfft_execute(inverse)");
+}
+static int fft_forward(LinWinds *w, int slot, double2 *in, double2 *out)
+{
+    void *i_[1] = {in}, *o_[1] = {out};
+    return fftchk(rocfft_execute(w->plan[slot].fwd, i_, o_, w->plan[slot].info), "rocfft_execute(forward)");
 }
 
 static int ensure_spec(LinWinds *w, size_t elems)
@@ -329,7 +370,7 @@ int icar_linwinds_setup_run(icar_hip_ctx *c, const icar_hip_lt_options *o, const
     if (ensure_spec(w, plane * 2)) return 1;
     HIPCHK(hipMemcpyAsync(w->spec, cplx.data(), plane * sizeof(double2), hipMemcpyHostToDevice, c->stream));
     if (ensure_plan(w, 0, 1, c->stream)) return 1;
-    FFTCHK(hipfftExecZ2Z(w->plan[0], (hipfftDoubleComplex *)w->spec, (hipfftDoubleComplex *)(w->spec + plane), HIPFFT_FORWARD));   // :1216-1218
+    if (fft_forward(w, 0, w->spec, w->spec + plane)) return 1;   // :1216-1218
     k_lt_norm_shift<<<dim3((nx2 + 63) / 64, ny2), 64, 0, c->stream>>>(w->spec + plane, w->hhat, nx2, ny2);
     HIPCHK(hipGetLastError());
     // wavenumber axes :447-462
@@ -401,7 +442,7 @@ int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, f
     k_lt_spectral<<<dim3((w->fftnx + 63) / 64, w->fftny), 64, 0, c->stream>>>(w->hhat, w->k1, w->l1, w->fftnx, w->fftny, U, V, Nsq,
                                                                                    w->d_z, w->d_nsteps, w->max_steps, 0, 1, w->spec, 1);
     HIPCHK(hipGetLastError());
-    FFTCHK(hipfftExecZ2Z(w->plan[0], (hipfftDoubleComplex *)w->spec, (hipfftDoubleComplex *)w->spec, HIPFFT_BACKWARD));
+    if (fft_inverse_inplace(w, 0, w->spec)) return 1;
     double *du = (double *)(w->spec + 2 * plane), *dv = du + plane;
     int ns1 = 0;
     HIPCHK(hipMemcpy(&ns1, w->d_nsteps, sizeof(int), hipMemcpyDeviceToHost));
@@ -457,7 +498,7 @@ int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *z
             if (ensure_plan(w, slot, 2 * nl, c->stream)) return 1;
             k_lt_spectral<<<dim3((w->fftnx + 63) / 64, w->fftny), 64, 0, c->stream>>>(w->hhat, w->k1, w->l1, w->fftnx, w->fftny, u, v, nsq,
                                                                                            w->d_z, w->d_nsteps, w->max_steps, lev0, nl, w->spec, nl);
-            FFTCHK(hipfftExecZ2Z(w->plan[slot], (hipfftDoubleComplex *)w->spec, (hipfftDoubleComplex *)w->spec, HIPFFT_BACKWARD));
+            if (fft_inverse_inplace(w, slot, w->spec)) return 1;
             k_lt_destagger<<<dim3((nx + 1 + 63) / 64, ny + 1, nl), 64, 0, c->stream>>>(w->spec, w->fftnx, w->fftny, nl, lev0, w->d_nsteps, w->buffer,
                                                                                         w->a0, w->b0, nx, nz, ny,
                                                                                         w->lut[0] + combo * ucells, w->lut[1] + combo * vcells);
@@ -530,7 +571,7 @@ int icar_linwinds_build_lut_varying_run(icar_hip_ctx *c, const float *zb3, const
                 // u planes at [0, nsub), v planes at [maxsub, maxsub+nsub): call the spectral kernel once per component block
                 k_lt_spectral<<<dim3((w->fftnx + 63) / 64, w->fftny), 64, 0, c->stream>>>(w->hhat, w->k1, w->l1, w->fftnx, w->fftny, u, v, nsq,
                                                                                                w->d_z, w->d_nsteps, 1, off[z], nsub, w->spec, (int)maxsub);
-                if (fftchk(hipfftExecZ2Z(w->plan[0], (hipfftDoubleComplex *)w->spec, (hipfftDoubleComplex *)w->spec, HIPFFT_BACKWARD), "hipfftExecZ2Z")) { rc = 1; break; }
+                if (fft_inverse_inplace(w, 0, w->spec)) { rc = 1; break; }
                 VaryZ vz{dzb, dzt, nxg, nlev, nyg, z, start_z[z], end_z[z], step[z], w->d_z + off[z], nsub};
                 k_lt_destagger_varying<<<dim3((nx + 1 + 63) / 64, ny + 1), 64, 0, c->stream>>>(w->spec, w->fftnx, w->fftny, (int)maxsub, vz, w->buffer,
                                                                                                 w->a0, w->b0, nx, nz, ny,

@@ -7,8 +7,8 @@
 // evaporation sweep after every fall sub-step -- coupled only by the fall fluxes: flux(k+1) of the level above is read
 // through LDS once per sub-step (mp_simple.f90:437-459 only ever uses the not-yet-modified q(k+1), so all levels of a
 // sub-step are independent), and the column-wide "any rain / snow" and CFL numbers are LDS reductions.  State lives in
-// registers; 16 waves per CU instead of the 3 the first version (k_mp_simple: one column per lane, 51 kB of LDS per
-// 64 columns) could keep resident.  FP32 throughout like the reference;
+// registers; 16 waves per CU instead of the 3 a one-column-per-lane layout (51 kB of LDS per 64 columns) could keep
+// resident.  FP32 throughout like the reference;
 // exp() is evaluated in FP64 and rounded once so that it agrees with the host libm's correctly
 // rounded expf in all but ~1e-3 of evaluations (documented tolerance in tests/).
 #include "ctx.h"
@@ -17,8 +17,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-
-#define MPS_LANES 64
 
 namespace {
 constexpr float LH_vapor = 2.26E6f, dLHvdt = 2400.0f, LH_liquid = 3.34E5f, heat_capacity = 1006.0f;
@@ -116,112 +114,6 @@ __device__ void mp_conversions(float pressure, float &temperature, float &qv, fl
             if (qs > SMALL_VALUE) phase_change(temperature, qs, qvsat, qv, L_subl, cloud2snow / 2, err);
         }
     }
-}
-
-// one explicit-upwind fall sub-step of species column q (LDS), :437-459 with the flux array fused
-// away: flux(i) only ever sees the not-yet-modified q(i+1).
-__device__ __forceinline__ float sediment(float *q, int ls, float vfall, const float *__restrict__ rho,
-                                          const float *__restrict__ dz, int gs, int nz, int kts, int kte)
-{
-    const float sed = vfall * q[kts * ls] * rho[kts * gs];
-    q[kts * ls] = q[kts * ls] - (sed / dz[kts * gs] / rho[kts * gs]);
-    const int top = (kte < nz - 2) ? kte : nz - 2;
-    for (int i = kts; i <= top; ++i) {
-        const float flux = vfall * q[(i + 1) * ls] * rho[(i + 1) * gs];
-        q[i * ls] = q[i * ls] + flux / (rho[i * gs] * dz[i * gs]);
-        q[(i + 1) * ls] = q[(i + 1) * ls] - flux / (rho[(i + 1) * gs] * dz[(i + 1) * gs]);
-    }
-    return sed;
-}
-
-__global__ void __launch_bounds__(MPS_LANES)
-k_mp_simple(Dims d, const float *__restrict__ pressure, float *__restrict__ th, const float *__restrict__ pii,
-            const float *__restrict__ rho, float *__restrict__ qv_g, float *__restrict__ qc_g,
-            float *__restrict__ qr_g, float *__restrict__ qs_g, const float *__restrict__ dz,
-            double *__restrict__ precip_acc, double *__restrict__ snow_acc,
-            float dt, float cloud2rain, float cloud2snow,
-            int i0, int i1, int j0, int kts, int kte, int *__restrict__ err_count)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x;
-    const int i = i0 + blockIdx.x * MPS_LANES + lane;
-    const int j = j0 + blockIdx.y;
-    if (i > i1) return;
-    const int nz = d.nz, gs = d.sk, ls = MPS_LANES;
-    float *T = lds + lane, *qv = T + nz * ls, *qc = qv + nz * ls, *qr = qc + nz * ls, *qs = qr + nz * ls;
-    const int c0 = d.idx(i, 0, j);
-    const float *p = pressure + c0, *rh = rho + c0, *dzc = dz + c0, *pi_c = pii + c0;
-    for (int k = 0; k < nz; ++k) {
-        const int g = c0 + k * gs;
-        T[k * ls] = th[g] * pi_c[k * gs];
-        qv[k * ls] = qv_g[g]; qc[k * ls] = qc_g[g]; qr[k * ls] = qr_g[g]; qs[k * ls] = qs_g[g];
-    }
-    int err = 0;
-    float rain = 0.0f, snow = 0.0f;
-    const float L_melt = -1 * LH_liquid;
-    float qr_max = -INFINITY, qs_max = -INFINITY;
-    for (int k = kts; k <= kte; ++k) {
-        float t = T[k * ls], v = qv[k * ls], cc = qc[k * ls], r = qr[k * ls], s = qs[k * ls];
-        mp_conversions(p[k * gs], t, v, cc, r, s, cloud2rain, cloud2snow, err);
-        T[k * ls] = t; qv[k * ls] = v; qc[k * ls] = cc; qr[k * ls] = r; qs[k * ls] = s;
-    }
-    for (int k = 0; k < nz; ++k) qr_max = fmaxf(qr_max, qr[k * ls]);
-    if (qr_max > SMALL_VALUE) {
-        float m = dt / dzc[0] * rain_fall_rate;
-        for (int k = 1; k < nz; ++k) m = fmaxf(m, dt / dzc[k * gs] * rain_fall_rate);
-        const float cfl = ceilf(m);
-        const float vfall = dt * rain_fall_rate / cfl;
-        const int ncfl = (int)lroundf(cfl);
-        const float rate = cloud2rain / (2 * ncfl);
-        for (int s = 1; s <= ncfl; ++s) {
-            rain = rain + sediment(qr, ls, vfall, rh, dzc, gs, nz, kts, kte);
-            for (int k = kts; k <= kte; ++k) {
-                float t = T[k * ls];
-                const float L_evap = -1 * (LH_vapor + (373.15f - t) * dLHvdt);
-                const float qvsat = sat_mr(t, p[k * gs]);
-                float v = qv[k * ls], r = qr[k * ls];
-                if (v < qvsat && r > SMALL_VALUE) {
-                    phase_change(t, r, qvsat, v, L_evap, rate, err);
-                    T[k * ls] = t; qv[k * ls] = v; qr[k * ls] = r;
-                }
-            }
-        }
-    }
-    for (int k = 0; k < nz; ++k) qs_max = fmaxf(qs_max, qs[k * ls]);
-    if (qs_max > SMALL_VALUE) {
-        float m = dt / dzc[0] * snow_fall_rate;
-        for (int k = 1; k < nz; ++k) m = fmaxf(m, dt / dzc[k * gs] * snow_fall_rate);
-        const float cfl = ceilf(m);
-        const float vfall = dt * snow_fall_rate / cfl;
-        const int ncfl = (int)lroundf(cfl);
-        const float rate = cloud2snow / (2 * ncfl);
-        for (int s = 1; s <= ncfl; ++s) {
-            const float snowfall = sediment(qs, ls, vfall, rh, dzc, gs, nz, kts, kte);
-            snow = snow + snowfall;
-            rain = rain + snowfall;
-            for (int k = kts; k <= kte; ++k) {
-                float t = T[k * ls];
-                const float L_evap = -1 * (LH_vapor + (373.15f - t) * dLHvdt);
-                const float L_subl = L_melt + L_evap;
-                const float qvsat = sat_mr(t, p[k * gs]);
-                float v = qv[k * ls], sn = qs[k * ls];
-                if (v < qvsat && sn > SMALL_VALUE) {
-                    phase_change(t, sn, qvsat, v, L_subl, rate, err);
-                    T[k * ls] = t; qv[k * ls] = v; qs[k * ls] = sn;
-                }
-            }
-        }
-    }
-    for (int k = 0; k < nz; ++k) {
-        const int g = c0 + k * gs;
-        th[g] = T[k * ls] / pi_c[k * gs];
-        qv_g[g] = qv[k * ls]; qc_g[g] = qc[k * ls]; qr_g[g] = qr[k * ls]; qs_g[g] = qs[k * ls];
-    }
-    // process_subdomain, mp_driver.f90:587-595: REAL(8) accumulators += REAL(4) tile fluxes
-    const int c2 = i + d.nx * j;
-    precip_acc[c2] = precip_acc[c2] + rain;
-    snow_acc[c2] = snow_acc[c2] + snow;
-    if (err) atomicAdd(err_count, 1);
 }
 
 // one level of one column per thread; see the header comment.  All threads of the block run the same sub-step loops.
@@ -326,23 +218,15 @@ int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int
     const float cloud2rain = std::exp(-1.0f * (1 / 500.0f) * dt);
     HIPCHK(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
     ScopedTimer t(c, "mp");
-    const char *mode = getenv("ICAR_HIP_MP_SIMPLE");              // A/B switch: "lane" = one column per lane (first version)
     const int nz = c->d.nz;
     int nt = 0, cpb = 0;
-    if (!(mode && !strcmp(mode, "lane")) && block_comm_geometry(nz, nt, cpb) > 0.0f) {
+    if (!(block_comm_geometry(nz, nt, cpb) > 0.0f)) { icar_set_error("mp_simple: more than 1024 levels are not supported"); return 1; }
+    {
         // whole columns packed into blocks of 256 threads (512 / 1024 when nz needs it), thread = level*cpb + column
         const int i0 = its - c->ims, i1 = ite - c->ims, ib0 = i0 / cpb, nb = i1 / cpb - ib0 + 1;
         hipLaunchKernelGGL(k_mp_simple_pack, dim3(nb, jte - jts + 1), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d,
                            p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa, dt, cloud2rain, cloud2snow,
                            i0, i1, jts - c->jms, kts - c->kms, kte - c->kms, cpb, ib0, c->d_flag);
-    } else {
-        const size_t lds_bytes = (size_t)5 * nz * MPS_LANES * sizeof(float);
-        if (lds_bytes > 160 * 1024) { icar_set_error("mp_simple: nz too large for the LDS column staging"); return 1; }
-        HIPCHK(hipFuncSetAttribute((const void *)k_mp_simple, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        const int ncol = ite - its + 1;
-        dim3 g((ncol + MPS_LANES - 1) / MPS_LANES, jte - jts + 1), b(MPS_LANES);
-        hipLaunchKernelGGL(k_mp_simple, g, b, lds_bytes, c->stream, c->d, p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa,
-                           dt, cloud2rain, cloud2snow, its - c->ims, ite - c->ims, jts - c->jms, kts - c->kms, kte - c->kms, c->d_flag);
     }
     HIPCHK(hipGetLastError());
     if (err_out) {

@@ -383,8 +383,7 @@ int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     for (int loop = 1; loop <= loops; ++loop) {
         if (loop == 1) hipLaunchKernelGGL((k_wsm3_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, i0, i1, j0, k0, km);
         else           hipLaunchKernelGGL((k_wsm3_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qci, qrs, den, p, i0, i1, j0, k0, km);
-        static const bool serial_fall = getenv("ICAR_HIP_WSM3_FALL") && !strcmp(getenv("ICAR_HIP_WSM3_FALL"), "serial");   // A/B switch
-        if (km + 1 <= 64 && !serial_fall) {
+        if (km + 1 <= 64) {                                   // lane = level; more levels: one thread per column
             const int ncol_x = ite - its + 1;
             hipLaunchKernelGGL(k_wsm3_fall_tile, dim3((ncol_x + W3_TC - 1) / W3_TC, nyt, 2), dim3(256), 7 * (size_t)km * (W3_TC + 1) * sizeof(float),
                                c->stream, c->d, S->c, W, qci, qrs, den, dz, S->delq, dtcld, i0, i1, j0, k0, km);

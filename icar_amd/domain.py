@@ -71,6 +71,8 @@ class domain_t:
         if a.shape != self.shape(fid):
             raise ValueError(f"{name}: shape {a.shape} != {self.shape(fid)}")
         check(lib().icar_hip_field_upload(self.ctx, fid, a.ctypes.data_as(ctypes.c_void_p)), f"upload {name}")
+        if fid in (F.SINTHETA, F.COSTHETA):
+            self._has_theta = True
 
     def get(self, name):
         fid = self.fid(name)

@@ -16,14 +16,14 @@ module icar_hip
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
             hip_diagnostic_update, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
             hip_halo_unpack, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, &
-            hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device
+            hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
             ICAR_F_JACOBIAN_V, ICAR_F_JACOBIAN_W, ICAR_F_ADVECTION_DZ, ICAR_F_PRECIPITATION, ICAR_F_SNOWFALL, ICAR_F_GRAUPEL_ACC, &
             ICAR_F_Z, ICAR_F_NSQUARED, ICAR_F_PRESSURE_INTERFACE, ICAR_F_TEMPERATURE, ICAR_F_TEMPERATURE_INTERFACE, &
             ICAR_F_U_MASS, ICAR_F_V_MASS, ICAR_F_W_REAL, ICAR_F_DZDX, ICAR_F_DZDY, ICAR_F_SURFACE_PRESSURE, &
-            ICAR_F_IVT, ICAR_F_IWV, ICAR_F_IWL, ICAR_F_IWI, ICAR_F_ZR_U, ICAR_F_ZR_V
+            ICAR_F_IVT, ICAR_F_IWV, ICAR_F_IWL, ICAR_F_IWI, ICAR_F_ZR_U, ICAR_F_ZR_V, ICAR_F_SINTHETA, ICAR_F_COSTHETA
 
   ! enum icar_hip_field (include/icar_hip.h)
   integer(c_int), parameter :: ICAR_F_WATER_VAPOR=0, ICAR_F_CLOUD_WATER=1, ICAR_F_RAIN=2, ICAR_F_SNOW=3, &
@@ -33,7 +33,7 @@ module icar_hip
        ICAR_F_PRECIPITATION=23, ICAR_F_SNOWFALL=24, ICAR_F_GRAUPEL_ACC=25, ICAR_F_PRESSURE_INTERFACE=26, ICAR_F_TEMPERATURE=27, &
        ICAR_F_TEMPERATURE_INTERFACE=28, ICAR_F_U_MASS=29, ICAR_F_V_MASS=30, ICAR_F_W_REAL=31, ICAR_F_DZDX=32, ICAR_F_DZDY=33, &
        ICAR_F_SURFACE_PRESSURE=34, ICAR_F_Z=35, ICAR_F_NSQUARED=36, ICAR_F_IVT=37, ICAR_F_IWV=38, ICAR_F_IWL=39, ICAR_F_IWI=40, &
-       ICAR_F_ZR_U=41, ICAR_F_ZR_V=42
+       ICAR_F_ZR_U=41, ICAR_F_ZR_V=42, ICAR_F_SINTHETA=43, ICAR_F_COSTHETA=44
 
   !> struct icar_hip_lt_options == the members of options%lt_options the linear-wind path reads
   type, bind(C) :: hip_lt_options_t
@@ -57,6 +57,9 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_synchronize(ctx) bind(C, name="icar_hip_synchronize")
        import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_make_winds_grid_relative(ctx, update) bind(C, name="icar_hip_make_winds_grid_relative")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: update
      end function
      integer(c_int) function icar_hip_aux_fork(ctx) bind(C, name="icar_hip_aux_fork")
        import; type(c_ptr), value :: ctx
@@ -197,6 +200,14 @@ contains
   subroutine hip_sync(ctx)
     type(hip_ctx_t), intent(in) :: ctx
     call check(icar_hip_synchronize(ctx%p), "synchronize")
+  end subroutine
+
+  !> make_winds_grid_relative(u, v, w, sintheta, costheta) of wind.f90:236-287 on the device u, v (update: their dqdt_3d);
+  !! upload domain%sintheta / costheta with hip_upload_2dd(ctx, ICAR_F_SINTHETA / ICAR_F_COSTHETA, ...) once after init_winds
+  subroutine hip_make_winds_grid_relative(ctx, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    logical, intent(in) :: update
+    call check(icar_hip_make_winds_grid_relative(ctx%p, merge(1_c_int,0_c_int,update)), "make_winds_grid_relative")
   end subroutine
 
   !> second HIP stream: `call hip_aux_fork(ctx)` before mp(halo=1); the interior mp(subset=1) between

@@ -17,6 +17,16 @@ def balance_uvw(domain, update=False):
     check(fn(domain.ctx, ctypes.c_float(domain.dx)), "balance_uvw")
 
 
+def make_winds_grid_relative(domain, update=False):
+    """wind.f90:236-287 on domain%u / domain%v (their dqdt_3d when update).  domain%sintheta / costheta are what init_winds
+    (wind.f90:512-590) derives from the lat / lon grid; a domain that has none is an unrotated grid (sin 0, cos 1)."""
+    if not getattr(domain, "_has_theta", False):
+        import numpy as np
+        domain.set("sintheta", np.zeros((domain.ny, domain.nx), np.float64))
+        domain.set("costheta", np.ones((domain.ny, domain.nx), np.float64))
+    check(lib().icar_hip_make_winds_grid_relative(domain.ctx, int(update)), "make_winds_grid_relative")
+
+
 def exchange_uv(domain, update=False):
     """domain%u%exchange_u(); domain%v%exchange_v() (on the dqdt_3d arrays when iterative_winds swapped them in)."""
     if getattr(domain, "comm", None) is not None:
@@ -41,13 +51,14 @@ def iterative_winds(domain, options, update=False):
 
 def update_winds(domain, options):
     """wind.f90:289-360 for every windtype: 0, kWIND_LINEAR, kCONSERVE_MASS, kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS.  First call: linear_perturb on u, v then balance_uvw on the
-    winds; every later call (a new forcing step has put the next winds into dqdt_3d) the same on the tendencies.
-    make_winds_grid_relative (rotation by sintheta / costheta) belongs to the forcing reader and is not on this path;
+    winds; every later call (a new forcing step has put the next winds into dqdt_3d) the same on the tendencies.  Both
+    branches start with make_winds_grid_relative (:300, :338).
     setup_linwinds(domain, options, global_terrain) must have been called when windtype == kWIND_LINEAR."""
     wt = options.physics.windtype
     if wt not in (0, kWIND_LINEAR, kCONSERVE_MASS, kITERATIVE_WINDS, kLINEAR_ITERATIVE_WINDS):
         raise IcarHipError(f"update_winds: unknown windtype {wt}")
     first = not getattr(domain, "_winds_initialised", False)
+    make_winds_grid_relative(domain, update=not first)                                   # wind.f90:300 / :338
     if wt in (kWIND_LINEAR, kLINEAR_ITERATIVE_WINDS):
         linear_perturb(domain, options, options.lt_options.vert_smooth, False, options.parameters.advect_density, update=not first)
     if wt == kCONSERVE_MASS:

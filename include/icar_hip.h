@@ -80,7 +80,10 @@ enum icar_hip_field {
      * zfr_u / zfr_v when options%parameters%use_terrain_difference */
     ICAR_F_ZR_U = 41,              /* (nx+1, nz, ny)                        */
     ICAR_F_ZR_V = 42,              /* (nx, nz, ny+1)                        */
-    ICAR_N_FIELDS = 43
+    /* make_winds_grid_relative (src/physics/wind.f90:236-287): domain%sintheta / costheta, REAL(8) (nx,ny) */
+    ICAR_F_SINTHETA = 43,
+    ICAR_F_COSTHETA = 44,
+    ICAR_N_FIELDS = 45
 };
 
 enum { ICAR_ADV_UPWIND = 1, ICAR_ADV_MPDATA = 2 };   /* kADV_UPWIND / kADV_MPDATA, icar_constants.f90:341 */
@@ -207,6 +210,12 @@ int icar_hip_balance_uvw(icar_hip_ctx *ctx, float dx);
 /* same on u/v/w%meta_data%dqdt_3d -- the form update_winds uses at every forcing step after the first
  * (src/physics/wind.f90:341-360); the w tendency mirror is created if needed. */
 int icar_hip_balance_uvw_update(icar_hip_ctx *ctx, float dx);
+
+/* ---- make_winds_grid_relative (src/physics/wind.f90:236-287): rotate the forcing winds from E-W / N-S to the grid's
+ * orientation -- destagger u, v to the mass grid, rotate by ICAR_F_SINTHETA / ICAR_F_COSTHETA (REAL(8), (nx,ny)),
+ * restagger, extrapolate the two lost edge cells.  update_winds calls it on both of its branches (:300 on u, v; :338 on
+ * their dqdt_3d when update != 0).  Not the identity even for an unrotated grid (the double averaging smooths). */
+int icar_hip_make_winds_grid_relative(icar_hip_ctx *ctx, int update);
 
 /* ---- iterative_winds (src/physics/wind.f90:371-498), SURVEY 8(f) rank 4 -----------------------
  * The host keeps the reference's control flow: [exchange_u, exchange_v], balance_uvw, correct_w, then

@@ -161,6 +161,13 @@ def balance_uvw(u, v, ju, jv, jw, dz, dx):
     return w
 
 
+def make_winds_grid_relative(u, v, sintheta, costheta):
+    """wind.f90:236-287 in place on u (ny,nz,nx+1), v (ny+1,nz,nx); sintheta / costheta float64 (ny,nx)."""
+    nyp, nz, nx = v.shape
+    st = np.ascontiguousarray(sintheta, np.float64); ct = np.ascontiguousarray(costheta, np.float64)
+    lib().orc_make_winds_grid_relative(_i(nx), _i(nz), _i(nyp - 1), _p(u), _p(v), st.ctypes.data_as(ctypes.c_void_p), ct.ctypes.data_as(ctypes.c_void_p))
+
+
 def calc_divergence(u, v, w, ju, jv, jw, dz, jaco, dx):
     ny, nz, nx = jw.shape
     div = np.zeros((ny, nz, nx), np.float32)

@@ -14,6 +14,7 @@
  */
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 #define IDX(i,k,j) ((size_t)(i) + (size_t)nx*((size_t)(k) + (size_t)nz*(size_t)(j)))
 #define IDXU(i,k,j) ((size_t)(i) + (size_t)(nx+1)*((size_t)(k) + (size_t)nz*(size_t)(j)))
 
@@ -113,6 +114,48 @@ void orc_balance_uvw(int nx, int nz, int ny, const float *u, const float *v, flo
             w[c] = wk; wprev = wk; jwprev = jw[c];
         }
     }
+}
+
+/* make_winds_grid_relative (wind.f90:236-287), PARITY UNPINNED (wind.f90 needs FFTW3 through linear_winds; restated statement
+ * by statement with Fortran's whole-array semantics: every right-hand side is evaluated before its assignment).
+ * u (nx+1,nz,ny), v (nx,nz,ny+1) REAL(4) in place; sintheta, costheta REAL(8) (nx,ny).  The mixed REAL*DOUBLE products are
+ * formed in double and rounded once on assignment to the REAL u_local / v_local. */
+void orc_make_winds_grid_relative(int nx, int nz, int ny, float *u, float *v, const double *sintheta, const double *costheta)
+{
+    float *ul = (float *)malloc(sizeof(float) * (size_t)(nx + 1)), *vl = (float *)malloc(sizeof(float) * (size_t)nx);
+    /* :254 u(:ime,:,:) = (u(:ime,:,:) + u(ims+1:,:,:))/2 ; :255 v(:,:,:jme) = (v(:,:,:jme) + v(:,:,jms+1:))/2 */
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) for (int i = 0; i < nx; ++i)
+        u[IDXU(i, k, j)] = (u[IDXU(i, k, j)] + u[IDXU(i + 1, k, j)]) / 2;
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) for (int i = 0; i < nx; ++i)
+        v[IDX(i, k, j)] = (v[IDX(i, k, j)] + v[IDX(i, k, j + 1)]) / 2;
+    /* :257-265 rotate */
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) {
+        for (int i = 0; i < nx; ++i) {
+            const double c = costheta[i + (size_t)nx * j], s = sintheta[i + (size_t)nx * j];
+            ul[i] = (float)((double)u[IDXU(i, k, j)] * c - (double)v[IDX(i, k, j)] * s);
+            vl[i] = (float)((double)v[IDX(i, k, j)] * c + (double)u[IDXU(i, k, j)] * s);
+        }
+        for (int i = 0; i < nx; ++i) { u[IDXU(i, k, j)] = ul[i]; v[IDX(i, k, j)] = vl[i]; }
+    }
+    /* :270-272: back onto the staggered grid; the two lost cells are extrapolated */
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) {
+        for (int i = 0; i < nx; ++i) ul[i] = u[IDXU(i, k, j)];
+        for (int i = 1; i < nx; ++i) u[IDXU(i, k, j)] = (ul[i - 1] + ul[i]) / 2;
+        u[IDXU(0, k, j)] = 2 * u[IDXU(0, k, j)] - u[IDXU(1, k, j)];
+        u[IDXU(nx, k, j)] = 2 * u[IDXU(nx - 1, k, j)] - u[IDXU(nx - 2, k, j)];
+    }
+    /* :274-276 */
+    {
+        float *col = (float *)malloc(sizeof(float) * (size_t)ny);
+        for (int k = 0; k < nz; ++k) for (int i = 0; i < nx; ++i) {
+            for (int j = 0; j < ny; ++j) col[j] = v[IDX(i, k, j)];
+            for (int j = 1; j < ny; ++j) v[IDX(i, k, j)] = (col[j - 1] + col[j]) / 2;
+            v[IDX(i, k, 0)] = 2 * v[IDX(i, k, 0)] - v[IDX(i, k, 1)];
+            v[IDX(i, k, ny)] = 2 * v[IDX(i, k, ny - 1)] - v[IDX(i, k, ny - 2)];
+        }
+        free(col);
+    }
+    free(ul); free(vl);
 }
 
 /* calc_divergence, full form (wind.f90:203-226): horizontal + vertical metric divergence, then / jaco */

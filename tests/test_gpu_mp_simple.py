@@ -116,38 +116,6 @@ def test_halo_plus_subset_equals_full(oracle):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("nz", [30, 57, 120])
-def test_mp_simple_layouts_bit_identical(nz):
-    """k_mp_simple_pack (one level per thread, columns packed into 256/512-thread blocks) vs k_mp_simple (one column per
-    lane): same arithmetic, different level coupling.  nz=57 -> 4 columns per 256 threads, nz=120 -> 4 per 512."""
-    import os
-    kw = dict(hill_height=900.0, noise=0.01, uniform_dz=120.0 if nz > 60 else None)
-    outs = {}
-    for layout in (None, "lane"):
-        c = ideal.make_case(44, 13, nz, **kw)
-        c["water_vapor"] = (c["water_vapor"] * np.float32(2.2)).astype(np.float32)
-        d = single_image_domain(c)
-        opt = options_t(); opt.physics.microphysics = kMP_SB04
-        mp_init(opt, d)
-        old = os.environ.pop("ICAR_HIP_MP_SIMPLE", None)
-        if layout:
-            os.environ["ICAR_HIP_MP_SIMPLE"] = layout
-        try:
-            for _ in range(6):
-                mp(d, opt, 50.0); d.model_time_seconds += 50.0
-                d.set("potential_temperature", d.get("potential_temperature") - np.float32(1.0))
-            outs[layout] = {k: d.get(k) for k in ("potential_temperature", "water_vapor", "cloud_water_mass", "rain_mass", "snow_mass",
-                                                  "accumulated_precipitation", "accumulated_snowfall")}
-        finally:
-            os.environ.pop("ICAR_HIP_MP_SIMPLE", None)
-            if old is not None:
-                os.environ["ICAR_HIP_MP_SIMPLE"] = old
-            d.close()
-    assert outs[None]["rain_mass"].max() > 1e-6 and outs[None]["accumulated_precipitation"].max() > 0
-    for k in outs[None]:
-        assert np.array_equal(outs[None][k], outs["lane"][k]), f"{k}: {(outs[None][k] != outs['lane'][k]).sum()} cells differ"
-
-
 @pytest.mark.parametrize("mode", [1, 0])
 def test_mp_simple_full_size_column_subset_vs_oracle(oracle, mode):
     """BASELINE size (512x512x40): 4000 random columns, re-run by the CPU oracle as a small domain of their own (the scheme

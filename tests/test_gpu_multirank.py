@@ -219,6 +219,7 @@ def _worker_iw(rank, world, port, adv, q):
             update_winds(d, opt)
             got = (d.get_dqdt("u"), d.get_dqdt("v"), d.get_dqdt("w")) if which else (d.get("u"), d.get("v"), d.get("w"))
             u_l, v_l = cut(ug), cut(vg)
+            orc.make_winds_grid_relative(u_l, v_l, np.zeros((g.jme - g.jms + 1, g.ime - g.ims + 1)), np.ones((g.jme - g.jms + 1, g.ime - g.ims + 1)))   # wind.f90:300/:338, per image
             store = {11: u_l, 12: v_l}
             tile = HostTile(g, {} if which else store, store if which else None); hc = HaloComm(g, rank + 1)
             hc.exchange_uv(tile, 11, 12, which=which)

@@ -45,9 +45,12 @@ def test_schaer_advection_scenario(oracle):
     d = single_image_domain(c)
     d.exchange_vars = ["water_vapor"]
     adv_init(d, opt)
-    update_winds(d, opt)                                                      # iterative_winds + balance_uvw on the device
+    update_winds(d, opt)                                                      # make_winds_grid_relative + iterative_winds + balance_uvw on the device
     geo = (c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], c["jacobian"], DX)
-    u, v, _ = oracle.iterative_winds(c["u"], c["v"], *geo, 100)
+    u0, v0 = c["u"].copy(), c["v"].copy()
+    ny_, nx_ = c["jacobian"].shape[0], c["jacobian"].shape[2]
+    oracle.make_winds_grid_relative(u0, v0, np.zeros((ny_, nx_)), np.ones((ny_, nx_)))     # unrotated grid (wind.f90:300)
+    u, v, _ = oracle.iterative_winds(u0, v0, *geo, 100)
     w = oracle.balance_uvw(u, v, *geo[:4], DX)
     assert bits_equal(d.get("u"), u) and bits_equal(d.get("v"), v) and bits_equal(d.get("w"), w)
     div = oracle.calc_divergence(u, v, w, *geo)

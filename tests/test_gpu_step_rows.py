@@ -146,6 +146,15 @@ def test_compute_dt_every_cfl_strictness(oracle, strict):
     d.close()
 
 
+def gridrel(oracle, u, v):
+    """update_winds starts with make_winds_grid_relative (wind.f90:300 / :338); these domains carry no sintheta / costheta,
+    i.e. an unrotated grid -- which still destaggers / restaggers the winds.  Returns the oracle's result on copies."""
+    u, v = u.copy(), v.copy()
+    ny, nz, nx = v.shape[0] - 1, v.shape[1], v.shape[2]
+    oracle.make_winds_grid_relative(u, v, np.zeros((ny, nx)), np.ones((ny, nx)))
+    return u, v
+
+
 def test_update_winds_first_and_later_calls(oracle):
     """update_winds (wind.f90:289-360), windtype 0: first call balances w from u, v; later calls balance the forcing
     tendencies u/v/w%dqdt_3d.  Same kernel, same oracle routine on the other arrays."""
@@ -154,12 +163,14 @@ def test_update_winds_first_and_later_calls(oracle):
     d = single_image_domain(c)
     opt = options_t()
     update_winds(d, opt)
-    want = oracle.balance_uvw(c["u"], c["v"], c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], float(c["dx"]))
-    assert bits_equal(d.get("w"), want)
+    ur, vr = gridrel(oracle, c["u"], c["v"])
+    want = oracle.balance_uvw(ur, vr, c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], float(c["dx"]))
+    assert bits_equal(d.get("w"), want) and bits_equal(d.get("u"), ur) and bits_equal(d.get("v"), vr)
     rng = np.random.default_rng(3)
     du = (0.01 * rng.standard_normal(c["u"].shape)).astype(np.float32); dv = (0.01 * rng.standard_normal(c["v"].shape)).astype(np.float32)
     d.set_dqdt("u", du); d.set_dqdt("v", dv)
     update_winds(d, opt)
+    du, dv = gridrel(oracle, du, dv)
     want2 = oracle.balance_uvw(du, dv, c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], float(c["dx"]))
     assert bits_equal(d.get_dqdt("w"), want2) and np.abs(want2).max() > 0
     assert bits_equal(d.get("w"), want)                          # the winds themselves are untouched by the later call
@@ -177,6 +188,7 @@ def test_iterative_winds_single_image(oracle, iters):
     d = single_image_domain(c)
     opt = options_t(); opt.physics.windtype = kITERATIVE_WINDS; opt.parameters.wind_iterations = iters
     update_winds(d, opt)
+    c = dict(c); c["u"], c["v"] = gridrel(oracle, c["u"], c["v"])                # what iterative_winds starts from (wind.f90:300)
     u, v, _ = oracle.iterative_winds(c["u"], c["v"], *geo, iters)
     w = oracle.balance_uvw(u, v, *geo[:4], geo[5])
     assert bits_equal(d.get("u"), u) and bits_equal(d.get("v"), v) and bits_equal(d.get("w"), w)
@@ -192,6 +204,7 @@ def test_iterative_winds_single_image(oracle, iters):
     du = (0.01 * rng.standard_normal(c["u"].shape)).astype(np.float32); dv = (0.01 * rng.standard_normal(c["v"].shape)).astype(np.float32)
     d.set_dqdt("u", du); d.set_dqdt("v", dv)
     update_winds(d, opt)
+    du, dv = gridrel(oracle, du, dv)
     u2, v2, _ = oracle.iterative_winds(du, dv, *geo, iters)
     w2 = oracle.balance_uvw(u2, v2, *geo[:4], geo[5])
     assert bits_equal(d.get_dqdt("u"), u2) and bits_equal(d.get_dqdt("v"), v2) and bits_equal(d.get_dqdt("w"), w2)
@@ -210,12 +223,14 @@ def test_update_winds_conserve_mass(oracle):
     d.set("zr_u", zr_u); d.set("zr_v", zr_v)
     opt = options_t(); opt.physics.windtype = kCONSERVE_MASS
     update_winds(d, opt)
-    u, v = c["u"] / zr_u, c["v"] / zr_v
+    ur, vr = gridrel(oracle, c["u"], c["v"])
+    u, v = ur / zr_u, vr / zr_v
     geo = (c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], float(c["dx"]))
     assert bits_equal(d.get("u"), u) and bits_equal(d.get("v"), v) and bits_equal(d.get("w"), oracle.balance_uvw(u, v, *geo))
     du = (0.01 * rng.standard_normal(c["u"].shape)).astype(np.float32); dv = (0.01 * rng.standard_normal(c["v"].shape)).astype(np.float32)
     d.set_dqdt("u", du); d.set_dqdt("v", dv)
     update_winds(d, opt)
+    du, dv = gridrel(oracle, du, dv)
     assert bits_equal(d.get_dqdt("u"), du / zr_u) and bits_equal(d.get_dqdt("v"), dv / zr_v)
     assert bits_equal(d.get_dqdt("w"), oracle.balance_uvw(du / zr_u, dv / zr_v, *geo)) and bits_equal(d.get("u"), u)
     d.close()

@@ -145,45 +145,6 @@ def test_thompson_excludes_last_global_row_and_column(th_oracle):
     assert qc[:-1, :, :-1].max() > 0 and qc[-1].max() == 0 and qc[:, :, -1].max() == 0
 
 
-def _gpu_only(nx, ny, nz, steps, cool, moist, dt, layout):
-    """Same inputs through one of the kernel layouts (icar_thompson_run: packed blocks | column per wave | column per lane)."""
-    import os
-    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01)
-    c["water_vapor"] = (c["water_vapor"] * np.float32(moist)).astype(np.float32)
-    d = single_image_domain(c)
-    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
-    mp_init(opt, d)
-    old = os.environ.pop("ICAR_HIP_THOMPSON", None)
-    if layout:
-        os.environ["ICAR_HIP_THOMPSON"] = layout
-    try:
-        for _ in range(steps):
-            mp(d, opt, dt)
-            d.model_time_seconds += dt
-            d.set("potential_temperature", d.get("potential_temperature") - np.float32(cool))
-        out = {k: d.get(m) for k, m in FIELDS.items()}
-        out["acc_rain"] = d.get("accumulated_precipitation"); out["acc_snow"] = d.get("accumulated_snowfall"); out["acc_graupel"] = d.get("graupel")
-    finally:
-        os.environ.pop("ICAR_HIP_THOMPSON", None)
-        if old is not None:
-            os.environ["ICAR_HIP_THOMPSON"] = old
-        d.close()
-    return out
-
-
-@pytest.mark.parametrize("nz", [40, 23])
-def test_thompson_kernel_layouts_bit_identical(nz):
-    """Packed-block, column-per-wave and column-per-lane kernels run the same arithmetic; only the cross-level
-    communication differs (LDS / wave shuffles / private arrays), so every output bit must agree."""
-    kw = dict(nx=45, ny=14, nz=nz, steps=12, cool=2.0, moist=2.0, dt=60.0)
-    base = _gpu_only(layout=None, **kw)
-    assert base["snow"].max() > 1e-5 and base["acc_rain"].max() > 0
-    for layout in ("wave", "lane"):
-        other = _gpu_only(layout=layout, **kw)
-        for k in base:
-            assert np.array_equal(base[k], other[k]), f"{layout}/{k}: {(base[k] != other[k]).sum()} values differ"
-
-
 @pytest.mark.parametrize("nz", [12, 56, 100])
 def test_thompson_other_level_counts_vs_oracle(th_oracle, nz):
     """nz=12: 21 columns per 256-thread block; nz=56: one column per wave; nz=100: 5 columns per 512-thread block."""

@@ -219,8 +219,8 @@ def test_lut_interpolation_of_constant_and_no_lut_error(oracle):
 @pytest.mark.parametrize("windtype", [1, 5])
 def test_update_winds_linear_chain(oracle, windtype):
     """update_winds end to end (wind.f90:289-360) with windtype kWIND_LINEAR (1) and kLINEAR_ITERATIVE_WINDS (5):
-    linear_perturb -> [iterative_winds] -> balance_uvw, first call on the winds, second call on dqdt_3d.
-    Bit-exact against the oracle chain in device-math mode."""
+    make_winds_grid_relative (non-trivial sintheta / costheta) -> linear_perturb -> [iterative_winds] -> balance_uvw, first
+    call on the winds, second call on dqdt_3d.  Bit-exact against the oracle chain in device-math mode."""
     from icar_amd.wind import update_winds
     nx, ny, nz, dx, iters = 48, 29, 10, 1000.0, 3
     a = atmosphere(nx, ny, nz, seed=21, moist=True)
@@ -253,7 +253,14 @@ def test_update_winds_linear_chain(oracle, windtype):
     du = (0.05 * rng.standard_normal(a["u"].shape)).astype(np.float32) + a["u"]
     dv = (0.05 * rng.standard_normal(a["v"].shape)).astype(np.float32) + a["v"]
 
+    # a grid rotated by up to ~17 degrees against E-W / N-S, varying over the tile (make_winds_grid_relative, wind.f90:300/:338)
+    jj, ii = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    theta = 0.3 * np.sin(0.11 * ii + 0.3) * np.cos(0.07 * jj)
+    sint, cost = np.sin(theta), np.cos(theta)
+    d.set("sintheta", sint); d.set("costheta", cost)
+
     def chain(u, v, up, vp):
+        oracle.make_winds_grid_relative(u, v, sint, cost)
         oracle.spatial_winds(u, v, a["potential_temperature"], a["exner"], a["z"], a["water_vapor"], hyd, ulut, vlut,
                              up, vp, o, dirv, spdv, nsqv, lt.vert_smooth, lt.stability_window_size)
         if windtype == 5:
@@ -278,3 +285,31 @@ def test_update_winds_linear_chain(oracle, windtype):
         assert bits_equal(g, w), f"second call {n}: {(g != w).sum()} of {g.size} differ, max {abs(g - w).max()}"
     assert bits_equal(d.get("u"), u1) and abs(u1 - a["u"]).max() > 0.05
     d.close()
+
+
+@pytest.mark.parametrize("update", [False, True])
+def test_make_winds_grid_relative_vs_oracle(oracle, update):
+    """wind.f90:236-287 alone, with a rotation field that changes sign over the tile, on the winds and on their dqdt_3d;
+    bit-exact against the restatement (parity unpinned: wind.f90 needs FFTW3).  An unrotated grid is NOT a no-op: the
+    destagger / restagger pair is a 1-2-1 smoother, which the second half checks."""
+    nx, ny, nz = 37, 22, 7
+    rng = np.random.default_rng(5)
+    u = (8 + 3 * rng.standard_normal((ny, nz, nx + 1))).astype(np.float32); v = (-2 + 3 * rng.standard_normal((ny + 1, nz, nx))).astype(np.float32)
+    jj, ii = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    theta = 0.6 * np.sin(0.2 * ii) * np.cos(0.15 * jj) - 0.1
+    for st, ct in ((np.sin(theta), np.cos(theta)), (np.zeros((ny, nx)), np.ones((ny, nx)))):
+        d = make_domain(nx, ny, nz, 1000.0)
+        d.set("sintheta", st); d.set("costheta", ct)
+        from icar_amd.wind import make_winds_grid_relative
+        if update:
+            d.set("u", np.zeros_like(u)); d.set("v", np.zeros_like(v)); d.set_dqdt("u", u); d.set_dqdt("v", v)
+        else:
+            d.set("u", u); d.set("v", v)
+        make_winds_grid_relative(d, update=update)
+        gu, gv = (d.get_dqdt("u"), d.get_dqdt("v")) if update else (d.get("u"), d.get("v"))
+        d.close()
+        ou, ov = u.copy(), v.copy()
+        oracle.make_winds_grid_relative(ou, ov, st, ct)
+        assert bits_equal(gu, ou), f"u: {(gu != ou).sum()} differ"
+        assert bits_equal(gv, ov), f"v: {(gv != ov).sum()} differ"
+        assert np.abs(ou - u).max() > 0.1               # also for the unrotated grid
