@@ -68,7 +68,7 @@ def build_tile(args, rank, world, device):
 
 
 # the kernels one advect() call launches, per scheme (the roofline's `kernel` label; also the key of profiles/advect_traffic.json)
-ADVECT_KERNELS = {"mpdata": "k_upwind_pass + k_mpdata_fluxes_pipe + k_mpdata_final2", "upwind": "k_upwind_pass"}
+ADVECT_KERNELS = {"mpdata": "k_mpdata_fused", "upwind": "k_upwind_pass"}
 
 FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
 
@@ -394,11 +394,7 @@ def main():
                          # streaming-copy bandwidth of this box beside the spec peak that `frac` uses
                          "advect_scalar_cell_updates_per_s": (mem_cells * nscal / (adv_ms * 1e-3)) if adv_ms > 0 else None,
                          "measured_copy_GBps": stream_gbs,
-                         "frac_of_measured_copy": (achieved / stream_gbs) if stream_gbs else None,
-                         # informational: the instruction-issue floor of the same launch.  700 VALU
-                         # instructions per scalar-cell is the PMC count of profiles/r01_pmc.md for MPDATA order 2 + FCT;
-                         # 1024 SIMDs x 16 lanes x 2.4 GHz lane-instructions per second.
-                         "valu_floor_ms": (mem_cells * nscal * 700 / (1024 * 16 * 2.4e9) * 1e3) if args.adv == "mpdata" else None},
+                         "frac_of_measured_copy": (achieved / stream_gbs) if stream_gbs else None},
             # informational: the microphysics is VALU-bound, its share of the step and its algorithmic traffic
             "microphysics": {"kernel": {"thompson": "k_thompson_pack", "simple": "k_mp_simple_pack", "wsm3": "k_wsm3"}.get(args.mp, "none"), "bound": "valu",
                              "ms_per_step": mp_ms_step,

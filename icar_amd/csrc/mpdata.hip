@@ -34,10 +34,14 @@
 // scheduled onto the same XCD.
 #include "ctx.h"
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 
 #define MP_HL 3                       // halo lanes per side
 #define MP_XOUT (64 - 2 * MP_HL)      // outputs per 64-lane tile
+#define MP_NW 8                       // waves per block at most: two per SIMD, ~250 VGPRs each
+#define MP_KB 5                       // levels per thread at most
+#define MP_ZH 2                       // halo levels of a level range: a fake edge corrupts the outputs of the 2 levels next to it
 #define EPSQ 1e-10f
 #define EPSF 1e-15f
 
@@ -54,25 +58,25 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf
 __device__ __forceinline__ float ldb(const float *__restrict__ p, unsigned b) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + b); }
 __device__ __forceinline__ void stb(float *__restrict__ p, unsigned b, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(p) + b) = v; }
 
-// KB levels per thread, NWMAX waves per block at most (launch bound), RHO: advect_density, FCT: limiter on,
+// KB levels per thread (at most MP_NW waves per block), RHO: advect_density, FCT: limiter on,
 // PASS1: first corrective iteration (donor-cell pass inside); false: iord >= 3, where q2 == q (adv_mpdata.f90:393-402)
-template <int KB, int NWMAX, bool RHO, bool FCT, bool PASS1>
-__global__ void __launch_bounds__(64 * NWMAX)
+template <int KB, bool RHO, bool FCT, bool PASS1>
+__global__ void __launch_bounds__(64 * MP_NW)
 k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                const float *__restrict__ Ug, const float *__restrict__ Vg, const float *__restrict__ Wg, const float *__restrict__ Wzg,
-               const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dzg, int clen, int ntile, int nchunk, int nscal)
+               const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dzg, int clen, int ntile, int nchunk, int nscal, int nkr, int kstore)
 {
     constexpr int H = KB + 2;                       // own levels + one halo level below and above
     // exchange slots, double-buffered by step parity (a step without plane-P work has only ONE barrier)
-    __shared__ float s_q2[2][NWMAX][2][64];         // pass-1 field of a wave's lowest / highest level
-    __shared__ float s_bz[2][NWMAX][4][64];         // beta_in, beta_out of a wave's lowest / highest level
+    __shared__ float s_q2[2][MP_NW][2][64];         // pass-1 field of a wave's lowest / highest level
+    __shared__ float s_bz[2][MP_NW][4][64];         // beta_in, beta_out of a wave's lowest / highest level
     // The part of the rolling window that belongs to plane M (= P-1) is produced at the end of a step and consumed in the
     // second half of the next one.  With 8 waves per block a thread may hold ~250 VGPRs, and the loads + arithmetic of the
     // first half of a step need that room to overlap: those 9 KB + 2 values per thread are parked in LDS in between
     // (thread-private float4 slots: no synchronisation, conflict-free b128 accesses).
-    constexpr bool PARK = (NWMAX <= 8);
+    constexpr bool PARK = true;
     constexpr int NA4 = (H + 3) / 4, NB4 = 2 * KB;  // float4 slots: q2M[H] | mM nM v2S FyS bYinM bYoutM acc rdhM [KB each]
-    __shared__ float4 s_park[PARK ? NA4 + NB4 : 1][PARK ? 64 * NWMAX : 1];
+    __shared__ float4 s_park[PARK ? NA4 + NB4 : 1][PARK ? 64 * MP_NW : 1];
 
     const int lane = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y), nw = blockDim.y;
@@ -83,16 +87,20 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     // XCDs in contiguous runs of `cap` items; consecutive block ids go to the XCDs round-robin, so block id = xcd + 8 * slot.
     // The scalars of a group therefore share an XCD (at most two groups per XCD are split) and start together: the
     // scalar-independent arrays come from HBM once per group and from that XCD's L2 for the other scalars.
-    int tile, chunk, m;
+    int tile, chunk, m, kr;
     {
-        const unsigned id = blockIdx.x, nv = (unsigned)nscal, nitem = (unsigned)(ntile * nchunk) * nv;
+        const unsigned id = blockIdx.x, nv = (unsigned)nscal, nitem = (unsigned)(ntile * nchunk * nkr) * nv;
         const unsigned cap = (nitem + 7u) / 8u, xcd = id & 7u, slot = id >> 3;
         const unsigned it = xcd * cap + slot;
         if (slot >= cap || it >= nitem) return;
         const unsigned g = it / nv;
         m = (int)(it - g * nv);
-        tile = (int)(g % (unsigned)ntile); chunk = (int)(g / (unsigned)ntile);
+        tile = (int)(g % (unsigned)ntile); chunk = (int)((g / (unsigned)ntile) % (unsigned)nchunk); kr = (int)(g / (unsigned)(ntile * nchunk));
     }
+    // More levels than 8 waves x 5 can hold are split into level ranges, each its own work item: a range stores `kstore`
+    // levels [ka, kb] and computes MP_ZH more on either side (whatever a fake edge corrupts stays inside those halo levels);
+    // the flags of the real bottom / top are those of the global level index, so a range edge is not a boundary.
+    const int ka = kr * kstore, kb = min(ka + kstore - 1, nz - 1), kbase = max(ka - MP_ZH, 0);
     const float *__restrict__ q = qin.p[0];
     float *__restrict__ out = qout.p[0];
 #pragma unroll
@@ -105,7 +113,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     const bool lane_out = (lane >= MP_HL) && (lane < 64 - MP_HL) && xin;
     const unsigned bx = 4u * (unsigned)ic;
     const int ja = 1 + chunk * clen, jb = min(ja + clen - 1, ny - 2);
-    const int k0 = wv * KB;
+    const int k0 = kbase + wv * KB;
     // level of slot h (0..H-1) = k0-1+h, clamped for addressing; flags are wave-uniform
     int kc[H];
 #pragma unroll
@@ -423,19 +431,19 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const float v = xring ? q2M[kk + 1] : acc[kk] - FyLimS[kk] * rdhM[kk];
-                if ((lane_out || (xring && lane < 64)) && (k0 + kk < nz)) stb(out + (size_t)M * sj + kc[kk + 1], bx, v);
+                if ((lane_out || (xring && lane < 64)) && (k0 + kk >= ka && k0 + kk <= kb)) stb(out + (size_t)M * sj + kc[kk + 1], bx, v);
             }
         }
         // the boundary rows of the new field are the old ones (adv_mpdata.f90:63-65)
         if (!STEADY && M == 0 && ja == 1) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (k0 + kk < nz)) stb(out + kc[kk + 1], bx, q2M[kk + 1]);
+                if ((lane_out || xring) && (k0 + kk >= ka && k0 + kk <= kb)) stb(out + kc[kk + 1], bx, q2M[kk + 1]);
         }
         if (!STEADY && P == ny - 1 && jb == ny - 2) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (k0 + kk < nz)) stb(out + (size_t)(ny - 1) * sj + kc[kk + 1], bx, q2P[kk + 1]);
+                if ((lane_out || xring) && (k0 + kk >= ka && k0 + kk <= kb)) stb(out + (size_t)(ny - 1) * sj + kc[kk + 1], bx, q2P[kk + 1]);
         }
         // ---- roll the window
 #pragma unroll
@@ -476,13 +484,13 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int KB, int NWMAX>
+template <int KB>
 static void launch_fused(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
-                         const float *rho, const float *jaco, const float *dz, int nw, int clen, int ntile, int nchunk)
+                         const float *rho, const float *jaco, const float *dz, int nw, int clen, int ntile, int nchunk, int nkr, int kstore)
 {
-    const unsigned nitem = (unsigned)(ntile * nchunk * nv), cap = (nitem + 7u) / 8u;
+    const unsigned nitem = (unsigned)(ntile * nchunk * nkr * nv), cap = (nitem + 7u) / 8u;
     const dim3 g(8u * cap), b(64, nw);                      // block id = xcd + 8 * slot, slot < cap
-#define GO(R, F, P1) hipLaunchKernelGGL((k_mpdata_fused<KB, NWMAX, R, F, P1>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->Wdz, rho, jaco, dz, clen, ntile, nchunk, nv)
+#define GO(R, F, P1) hipLaunchKernelGGL((k_mpdata_fused<KB, R, F, P1>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->Wdz, rho, jaco, dz, clen, ntile, nchunk, nv, nkr, kstore)
     if (rho_on) { if (fct) { if (pass1) GO(true, true, true); else GO(true, true, false); } else { if (pass1) GO(true, false, true); else GO(true, false, false); } }
     else        { if (fct) { if (pass1) GO(false, true, true); else GO(false, true, false); } else { if (pass1) GO(false, false, true); else GO(false, false, false); } }
 #undef GO
@@ -495,21 +503,27 @@ int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, co
     const int nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
     if (nx < 3 || ny < 3) { icar_set_error("mpdata: tile must be at least 3 x 3 cells"); return 1; }
     const int ntile = std::max(1, (nx - 2 + MP_XOUT - 1) / MP_XOUT);
-    // levels per thread: as few waves as keep two per SIMD (8 per block) when nz allows; at most 16 waves
-    int kb = (nz + 7) / 8;
-    if (kb > 5) kb = (nz + 15) / 16;
-    if (kb > 5) { icar_set_error("mpdata: more than 80 levels are not supported by the fused kernel"); return 1; }
-    const int nw = (nz + kb - 1) / kb;
-    // y chunks: a block keeps a whole CU (8 waves at ~250 VGPRs), so the work items (tiles x chunks x scalars) should
-    // number just under a multiple of the 256 CUs -- one round when the domain allows it; each chunk pays 3 warm-up planes
-    const int rows = ny - 2;
-    int nchunk = std::max(1, std::min(rows, 256 / std::max(1, ntile * nv)));
-    while (nchunk > 1 && (rows + nchunk - 1) / nchunk < 16) --nchunk;
+    // levels: one block holds at most MP_NW x MP_KB = 40; taller columns are cut into level ranges with MP_ZH halo levels
+    const int cap_lv = MP_NW * MP_KB;
+    int nkr = 1;
+    while (nkr * cap_lv - 2 * MP_ZH * (nkr - 1) < nz) ++nkr;
+    const int kstore = (nz + nkr - 1) / nkr;
+    const int blk_lv = std::min(nz, kstore + (nkr > 1 ? 2 * MP_ZH : 0));       // levels a block computes
+    const int kb = (blk_lv + MP_NW - 1) / MP_NW, nw = (blk_lv + kb - 1) / kb;
+    // y chunks: a block keeps a whole CU, so the work items (tiles x chunks x ranges x scalars) should fill a whole number of
+    // rounds of the 256 CUs; each chunk pays ~3.5 warm-up planes.  Pick the chunk count with the best product of the two.
+    const int rows = ny - 2, per = ntile * nkr * nv;
+    int nchunk = 1; double best = -1.0;
+    for (int n = 1; n <= std::max(1, rows / 16); ++n) {
+        const int cl = (rows + n - 1) / n, nn = (rows + cl - 1) / cl;
+        const double items = (double)per * nn, rounds = std::ceil(items / 256.0);
+        const double eff = items / (256.0 * rounds) * cl / (cl + 3.5);
+        if (eff > best + 1e-9) { best = eff; nchunk = nn; }
+    }
     const int clen = (rows + nchunk - 1) / nchunk;
     nchunk = (rows + clen - 1) / clen;
-#define KBCASE(K) case K: if (nw <= 8) launch_fused<K, 8>(c, rho_on, fct, pass1, in, out, nv, rho, jaco, dz, nw, clen, ntile, nchunk); \
-                          else launch_fused<K, 16>(c, rho_on, fct, pass1, in, out, nv, rho, jaco, dz, nw, clen, ntile, nchunk); break;
-    switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) }
+#define KBCASE(K) case K: launch_fused<K>(c, rho_on, fct, pass1, in, out, nv, rho, jaco, dz, nw, clen, ntile, nchunk, nkr, kstore); break;
+    switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) default: icar_set_error("mpdata: internal level-range error"); return 1; }
 #undef KBCASE
     HIPCHK(hipGetLastError());
     return 0;

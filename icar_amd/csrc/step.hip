@@ -11,8 +11,12 @@ constexpr float Rd = 287.058f, cp = 1012.0f;     // src/constants/icar_constants
 // (p/po)**(Rd/cp) evaluated in FP64 and rounded once ("Arithmetic")
 __device__ __forceinline__ float exner_function(float pressure)
 {   // atm_utilities.f90:682-691 ; po = 100000 (integer in the reference => p/100000.)
-    // (p/1e5)**(Rd/cp), p > 0: exp(y log x) in FP64 (|y log x| < 1 => relative error 2^-52), a third of ocml's pow()
-    return (float)d_exp((double)(Rd / cp) * d_log((double)(pressure / 100000.0f)));
+    // (p/1e5)**(Rd/cp), p > 0: exp(y log x) in FP64 (|y log x| < 1 => relative error 2^-52), a third of ocml's pow().
+    // d_log assumes a positive finite argument; a pressure <= 0 or NaN (an uninitialised halo cell) takes the library
+    // pow, which returns what the reference's would (0, Inf or NaN -- detectable, not a plausible wrong number).
+    const float x = pressure / 100000.0f;
+    if (!(x > 0.0f) || !(x < 3.0e38f)) return powf(x, Rd / cp);
+    return (float)d_exp((double)(Rd / cp) * d_log((double)x));
 }
 
 #define DIAG_BY 8

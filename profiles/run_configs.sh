@@ -1,6 +1,6 @@
 #!/bin/bash
 # profiles/run_configs.sh -- one bench line per BASELINE.json configuration that fits one MI355X (the multi-GPU configurations
-# as the tile one GPU would own).  Output: gpurun_out/configs.jsonl (copied to profiles/r01_configs.jsonl).
+# as the tile one GPU would own).  Output: gpurun_out/configs.jsonl (copied to profiles/<round>_configs.jsonl).
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; mkdir -p gpurun_out
 O=gpurun_out/configs.jsonl; : > $O
 run() { timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 "$@" 2>/dev/null | tail -1 >> $O; }

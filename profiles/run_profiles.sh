@@ -1,11 +1,13 @@
 #!/bin/bash
 # profiles/run_profiles.sh -- run on the GPU box (gpurun): bench line, rocprofv3 kernel trace of the same command, and
 # three PMC passes (SQ counters / FETCH_SIZE / WRITE_SIZE -- separate passes, no trace domains mixed in, as
-# MI355X_MICROARCH.md prescribes).  Outputs land in gpurun_out/r01/, post-processed by profiles/collect_r01.py.
+# MI355X_MICROARCH.md prescribes).  Outputs land in gpurun_out/<round>/ (default r02), post-processed by
+# profiles/collect_round.py <round>.
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
-O=gpurun_out/r01; rm -rf $O; mkdir -p $O
+RND=${1:-r02}
+O=gpurun_out/$RND; rm -rf $O; mkdir -p $O
 timeout 400 python bench.py > $O/bench_line.json 2> $O/bench.err
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- $B > $O/trace.log 2>&1
