@@ -84,7 +84,7 @@ def mp_and_halo(domain, options, dt, overlap=True):
     """time_step.f90:512-526: mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve.
 
     The strips, the pack kernels and the exchange stay on the context's main stream; the interior launch runs beside them
-    on the context's second (low-priority) stream -- a one-cell-wide strip launch cannot fill 256 CUs, and the interior
+    on the context's second stream -- a one-cell-wide strip launch cannot fill 256 CUs, and the interior
     does not have to wait for it (disjoint columns).  An image without neighbours runs exactly the same launches (its
     halo_send / halo_retrieve have nobody to talk to), so 1-image and N-image timings compare like with like."""
     from .constants import kMP_THOMPSON, kMP_SB04

@@ -95,7 +95,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *ctx);
 /* Run all kernels of this context on the caller's HIP stream (hipStream_t); NULL = own stream. */
 int icar_hip_set_stream(icar_hip_ctx *ctx, void *hip_stream);
 int icar_hip_synchronize(icar_hip_ctx *ctx);
-/* Second HIP stream of the context (created on first use, lowest priority).  time_step.f90:512-526 orders
+/* Second HIP stream of the context (created on first use).  time_step.f90:512-526 orders
  *     mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
  * so that the interior microphysics overlaps the coarray PUTs; here the strips, the pack kernels and the exchange stay
  * on the main stream while the interior launch runs beside them on the aux stream:
