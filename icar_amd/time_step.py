@@ -42,11 +42,6 @@ def compute_dt(domain, options):
     return float(dt)
 
 
-def _world(group):
-    import torch.distributed as dist
-    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-
-
 def update_dt(domain, options, group=None, device=None):
     """time_step.f90:375-423: local CFL dt, co_min over images, cap at 120 s.
 
@@ -55,10 +50,10 @@ def update_dt(domain, options, group=None, device=None):
     one read brings the global value back -- dt = factor / max is monotone, so min over images of dt == factor / max
     over images, bit for bit.  Other settings / backends combine on the host (compute_dt) and co_min the REAL(8)."""
     strict = int(options.parameters.cfl_strictness)
-    if _world(group) > 1 and strict in (3, 4):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and strict in (3, 4):
         import torch
-        import torch.distributed as dist
-        if dist.get_backend(group) == "nccl":
+        if dist.get_backend(group) == "nccl":                 # also with one rank: the same RCCL call as with eight
             f32 = np.float32
             t = getattr(domain, "_cfl_dev", None)
             if t is None:
