@@ -400,7 +400,7 @@ def main():
                              "ms_per_step": mp_ms_step,
                              "algorithmic_GBps": (mem_cells * (84 if args.mp == "thompson" else 56) / (mp_ms_step * 1e-3) / 1e9) if mp_ms_step > 0 else 0.0},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU legs are timed at N=1 only (the other ranks would idle at the barrier)
             out["cpu_baseline"] = cpu_baseline(args, nscal)
             r = cpu_reference(args, d, nscal)
             if r is not None:
