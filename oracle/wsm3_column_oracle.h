@@ -1,14 +1,18 @@
-/* icar_amd/csrc/wsm3_column.h -- WSM3 (Hong, Dudhia, Chen 2004) for ONE column: src/physics/mp_wsm3.f90:218-903 (wsm32D),
+/* oracle/wsm3_column_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT.  The checker's OWN copy of the WSM3 column restatement
+ * (frozen in round 2 from the text it used to share with the product, so that nothing under oracle/ includes product code and
+ * a change of the product's header cannot move the checker with it; the copy is what tests/test_oracle_wsm3.py pins bit for bit
+ * to the compiled mp_wsm3.f90, and tests/test_gpu_wsm3.py then compares the product against).
+ * WSM3 (Hong, Dudhia, Chen 2004) for ONE column: src/physics/mp_wsm3.f90:218-903 (wsm32D),
  * :1008-1068 (slope_wsm3), :1266-1505 (nislfv_rain_plm), :951-1006 (wsm3init), statement by statement in the reference's
  * operation order.  The reference works on (i,k) slabs of one j row; nothing couples the columns of a slab, so the column
  * is the unit here.  Plain C99 that also compiles as HIP device code: the includer defines
  *   W3_FN                    function qualifiers (static inline / __device__ __forceinline__)
  *   W3_EXP W3_LOG W3_POW W3_SQRT   REAL(4) exp, log, x**y, sqrt in the arithmetic of its side
  *   W3_MAXK                  largest number of levels
- * Included by icar_amd/csrc/mp_wsm3.hip only (the CPU checker has its own copy, oracle/wsm3_column_oracle.h).
+ * Included by oracle/wsm3_oracle.c only.
  */
-#ifndef ICAR_WSM3_COLUMN_H
-#define ICAR_WSM3_COLUMN_H
+#ifndef ORACLE_WSM3_COLUMN_H
+#define ORACLE_WSM3_COLUMN_H
 
 /* module parameters mp_wsm3.f90:37-56 */
 #define W3_dtcldcr 120.f

@@ -1,5 +1,5 @@
 /* oracle/wsm3_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT.
- * WSM3 microphysics on the CPU: the column restatement of icar_amd/csrc/wsm3_column.h (src/physics/mp_wsm3.f90:218-903,
+ * WSM3 microphysics on the CPU: the column restatement of oracle/wsm3_column_oracle.h (src/physics/mp_wsm3.f90:218-903,
  * :951-1068, :1266-1505, each block citing its lines) compiled as plain C, driven like wsm3 (:74-216) drives wsm32D.
  * PINNED by execution: tests/test_oracle_wsm3.py compares it bit-for-bit with the unmodified mp_wsm3.f90 compiled into
  * oracle/_ref (constants of wsm3init and whole tiles over several steps).
@@ -19,7 +19,7 @@ static inline float o_powf(float x, float y) { return g_math_mode ? (float)pow((
 #define W3_SQRT(x) sqrtf(x)
 #define W3_MAXK 128
 #define W3_HOST_INIT
-#include "../icar_amd/csrc/wsm3_column.h"
+#include "wsm3_column_oracle.h"
 
 static wsm3_consts g_c;
 
