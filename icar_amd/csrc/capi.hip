@@ -140,6 +140,70 @@ int icar_halo_pack(icar_hip_ctx *c, int dir, int h, const int *fields, int n, fl
     return 0;
 }
 
+// all directions of one halo_send / halo_retrieve in ONE launch (blockIdx.z = direction): a step of an image with four
+// neighbours issues 2 launches instead of 8 -- small tiles are host-launch-bound
+struct HaloDirs { int n, ns[4], start[4], skip_w, skip_e; float *buf[4]; };
+template <bool UNPACK>
+__global__ void k_halo_dirs(Dims d, HaloArgs a, int h, HaloDirs hd)
+{
+    const int z = blockIdx.z, m = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float *__restrict__ buf = hd.buf[z];
+    if (hd.ns[z]) {                                                // N/S: h contiguous rows
+        const size_t per = (size_t)d.nx * d.nz * h;
+        if (t >= per) return;
+        const size_t src = (size_t)hd.start[z] * d.sj + t;
+        if (UNPACK) {
+            // the corner cells belong to both an N/S row and an E/W column; the reference retrieves N, S, E, W in that
+            // order (exchangeable_obj.f90:138-151), so E/W win: with them in the same launch the rows leave the corners alone
+            const int i = (int)(t % d.nx);
+            if ((hd.skip_w && i < h) || (hd.skip_e && i >= d.nx - h)) return;
+            a.f[m][src] = buf[(size_t)m * per + t];
+        } else buf[(size_t)m * per + t] = a.f[m][src];
+    } else {                                                       // E/W: h columns of every (k, j) line
+        const size_t per = (size_t)h * d.nz * d.ny;
+        if (t >= per) return;
+        const int x = (int)(t % h); const size_t line = t / h;
+        const size_t src = line * d.nx + hd.start[z] + x;
+        if (UNPACK) a.f[m][src] = buf[(size_t)m * per + t]; else buf[(size_t)m * per + t] = a.f[m][src];
+    }
+}
+
+int icar_halo_pack_dirs(icar_hip_ctx *c, int ndir, const int *dirs, int h, const int *fields, int n, void *const *bufs, bool unpack)
+{
+    if (n <= 0 || ndir <= 0) return 0;
+    if (ndir > 4) { icar_set_error("halo: at most 4 directions per call"); return 1; }
+    if (n > ICAR_MAX_ADV) { icar_set_error("halo: too many fields"); return 1; }
+    if (h < 1 || 2 * h > c->d.nx || 2 * h > c->d.ny) { icar_set_error("halo: bad halo width"); return 1; }
+    HaloArgs a;
+    for (int m = 0; m < n; ++m) {
+        if (fields[m] < 0 || fields[m] >= ICAR_N_ADVECTABLE) { icar_set_error("halo: only exchangeable scalars"); return 1; }
+        a.f[m] = icar_field_f(c, fields[m]);
+        if (!a.f[m]) return 1;
+    }
+    const Dims &d = c->d;
+    HaloDirs hd; hd.n = ndir; hd.skip_w = hd.skip_e = 0;
+    size_t permax = 0;
+    for (int z = 0; z < ndir; ++z) {
+        const int dir = dirs[z];
+        if (dir < 0 || dir > 3 || !bufs[z]) { icar_set_error("halo: dir must be 0..3 with a buffer"); return 1; }
+        hd.ns[z] = (dir < 2); hd.buf[z] = (float *)bufs[z];
+        if (dir == 2) hd.skip_e = 1;
+        if (dir == 3) hd.skip_w = 1;
+        // same planes as icar_halo_pack: put_north rows ny-2h.., put_south rows h.., put_east cols nx-2h.., put_west cols h.. ;
+        // retrieve fills the outermost h rows / columns
+        if (dir < 2) hd.start[z] = !unpack ? (dir == 0 ? d.ny - 2 * h : h) : (dir == 0 ? d.ny - h : 0);
+        else         hd.start[z] = !unpack ? (dir == 2 ? d.nx - 2 * h : h) : (dir == 2 ? d.nx - h : 0);
+        permax = std::max(permax, dir < 2 ? (size_t)d.nx * d.nz * h : (size_t)h * d.nz * d.ny);
+    }
+    ScopedTimer t(c, "halo");
+    dim3 g((unsigned)((permax + 255) / 256), n, ndir), b(256);
+    if (unpack) hipLaunchKernelGGL(k_halo_dirs<true>, g, b, 0, c->stream, d, a, h, hd);
+    else        hipLaunchKernelGGL(k_halo_dirs<false>, g, b, 0, c->stream, d, a, h, hd);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // T2: compute_dt strictness-3 reduction (time_step.f90:264-289)
 // ------------------------------------------------------------------------------------------------
@@ -436,6 +500,13 @@ int icar_hip_mp_simple(icar_hip_ctx *c, float dt, int its, int ite, int jts, int
     return icar_mp_simple_run(c, dt, its, ite, jts, jte, kts, kte, err_count);
 }
 
+int icar_hip_mp_simple_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte, int *err_count)
+{
+    if (!c || !tiles) { icar_set_error("mp_simple_tiles: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_mp_simple_run_tiles(c, dt, ntiles, tiles, kts, kte, err_count);
+}
+
 int icar_hip_thompson_init(icar_hip_ctx *c, const float params[18], const int flags[2])
 {
     if (!c || !params || !flags) { icar_set_error("thompson_init: null argument"); return 1; }
@@ -706,6 +777,20 @@ int icar_hip_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, in
     if (!c || !dbuf) { icar_set_error("halo_pack: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_halo_pack(c, dir, halo, fields, nfields, (float *)dbuf, false);
+}
+
+int icar_hip_halo_pack_dirs(icar_hip_ctx *c, int ndir, const int *dirs, int halo, const int *fields, int nfields, void *const *dbufs)
+{
+    if (!c || !dirs || !dbufs) { icar_set_error("halo_pack_dirs: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_halo_pack_dirs(c, ndir, dirs, halo, fields, nfields, dbufs, false);
+}
+
+int icar_hip_halo_unpack_dirs(icar_hip_ctx *c, int ndir, const int *dirs, int halo, const int *fields, int nfields, void *const *dbufs)
+{
+    if (!c || !dirs || !dbufs) { icar_set_error("halo_unpack_dirs: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_halo_pack_dirs(c, ndir, dirs, halo, fields, nfields, dbufs, true);
 }
 
 int icar_hip_halo_unpack(icar_hip_ctx *c, int dir, int halo, const int *fields, int nfields, const void *dbuf)

@@ -76,7 +76,9 @@ struct ScopedTimer {
 int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density);
 int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_density, const int *fields, int n);
 int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err);
+int icar_mp_simple_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte, int *err);
 int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
+int icar_halo_pack_dirs(icar_hip_ctx *c, int ndir, const int *dirs, int halo, const int *fields, int n, void *const *bufs, bool unpack);
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out, float *d_out);
 int icar_max_abs_winds_run(icar_hip_ctx *c, float *out3);
 int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update);

@@ -117,19 +117,25 @@ __device__ void mp_conversions(float pressure, float &temperature, float &qv, fl
 }
 
 // one level of one column per thread; see the header comment.  All threads of the block run the same sub-step loops.
+// up to 4 tiles (the strips of process_halo, mp_driver.f90:609-658) in one launch: blockIdx.z = tile
+struct MpTiles { int i0[4], i1[4], j0[4], nrow[4], ib0[4], nb[4]; };
+
 __global__ void __launch_bounds__(1024, 4)
 k_mp_simple_pack(Dims d, const float *__restrict__ pressure, float *__restrict__ th, const float *__restrict__ pii,
                  const float *__restrict__ rho, float *__restrict__ qv_g, float *__restrict__ qc_g,
                  float *__restrict__ qr_g, float *__restrict__ qs_g, const float *__restrict__ dz,
                  double *__restrict__ precip_acc, double *__restrict__ snow_acc,
                  float dt, float cloud2rain, float cloud2snow,
-                 int i0, int i1, int j0, int kts, int kte, int cpb, int ib0, int *__restrict__ err_count)
+                 MpTiles tl, int kts, int kte, int cpb, int *__restrict__ err_count)
 {
     extern __shared__ double lds_pack[];
     const int nz = d.nz;
-    const int first = (ib0 + blockIdx.x) * cpb;
+    const int z = blockIdx.z;                                     // strip of process_halo (or the one tile)
+    if ((int)blockIdx.x >= tl.nb[z] || (int)blockIdx.y >= tl.nrow[z]) return;
+    const int i0 = tl.i0[z], i1 = tl.i1[z];
+    const int first = (tl.ib0[z] + blockIdx.x) * cpb;
     BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nz, i0 - first, i1 - first);
-    const int j = j0 + blockIdx.y;
+    const int j = tl.j0[z] + blockIdx.y;
     const int i = x.active ? first + x.col : max(i0, min(i1, first));
     const int k = x.k;
     const int c = d.idx(i, k, j);
@@ -196,17 +202,33 @@ k_mp_simple_pack(Dims d, const float *__restrict__ pressure, float *__restrict__
         precip_acc[c2] = precip_acc[c2] + rain;
         snow_acc[c2] = snow_acc[c2] + snow;
     }
-    if (err) atomicAdd(err_count, 1);
+    if (err && err_count) atomicAdd(err_count, 1);
 }
 }  // namespace
 
-int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_out)
+int icar_mp_simple_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte, int *err_out)
 {
-    if (its < c->ims || ite > c->ime || jts < c->jms || jte > c->jme || kts < c->kms || kte > c->kme) {
-        icar_set_error("mp_simple: tile outside memory bounds"); return 1;
-    }
+    if (ntiles < 0 || ntiles > 4) { icar_set_error("mp_simple: 0..4 tiles per call"); return 1; }
+    if (kts < c->kms || kte > c->kme) { icar_set_error("mp_simple: tile outside memory bounds"); return 1; }
     if (err_out) *err_out = 0;
-    if (ite < its || jte < jts || kte < kts) return 0;
+    const int nz = c->d.nz;
+    int nt = 0, cpb = 0;
+    if (!(block_comm_geometry(nz, nt, cpb) > 0.0f)) { icar_set_error("mp_simple: more than 1024 levels are not supported"); return 1; }
+    // whole columns packed into blocks of 256 threads (512 / 1024 when nz needs it), thread = level*cpb + column
+    MpTiles tl; int n = 0, nbmax = 0, nrmax = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int its = tiles[t][0], ite = tiles[t][1], jts = tiles[t][2], jte = tiles[t][3];
+        if (its < c->ims || ite > c->ime || jts < c->jms || jte > c->jme) { icar_set_error("mp_simple: tile outside memory bounds"); return 1; }
+        if (ite < its || jte < jts) continue;
+        for (int o = 0; o < n; ++o)                                // columns are updated in place: two tiles on one column would race
+            if (its - c->ims <= tl.i1[o] && ite - c->ims >= tl.i0[o] && jts - c->jms < tl.j0[o] + tl.nrow[o] && jte - c->jms >= tl.j0[o]) {
+                icar_set_error("mp_simple: tiles of one call must not overlap"); return 1;
+            }
+        tl.i0[n] = its - c->ims; tl.i1[n] = ite - c->ims; tl.j0[n] = jts - c->jms; tl.nrow[n] = jte - jts + 1;
+        tl.ib0[n] = tl.i0[n] / cpb; tl.nb[n] = tl.i1[n] / cpb - tl.ib0[n] + 1;
+        nbmax = std::max(nbmax, tl.nb[n]); nrmax = std::max(nrmax, tl.nrow[n]); ++n;
+    }
+    if (n == 0 || kte < kts) return 0;
     float *p = icar_field_f(c, ICAR_F_PRESSURE), *th = icar_field_f(c, ICAR_F_POTENTIAL_TEMPERATURE);
     float *pii = icar_field_f(c, ICAR_F_EXNER), *rho = icar_field_f(c, ICAR_F_DENSITY);
     float *qv = icar_field_f(c, ICAR_F_WATER_VAPOR), *qc = icar_field_f(c, ICAR_F_CLOUD_WATER);
@@ -216,22 +238,21 @@ int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int
     // mp_simple.f90:619-620, evaluated with the host libm like the reference
     const float cloud2snow = std::exp(-1.0f * (1 / 2000.0f) * dt);
     const float cloud2rain = std::exp(-1.0f * (1 / 500.0f) * dt);
-    HIPCHK(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    if (err_out) HIPCHK(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
     ScopedTimer t(c, "mp");
-    const int nz = c->d.nz;
-    int nt = 0, cpb = 0;
-    if (!(block_comm_geometry(nz, nt, cpb) > 0.0f)) { icar_set_error("mp_simple: more than 1024 levels are not supported"); return 1; }
-    {
-        // whole columns packed into blocks of 256 threads (512 / 1024 when nz needs it), thread = level*cpb + column
-        const int i0 = its - c->ims, i1 = ite - c->ims, ib0 = i0 / cpb, nb = i1 / cpb - ib0 + 1;
-        hipLaunchKernelGGL(k_mp_simple_pack, dim3(nb, jte - jts + 1), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d,
-                           p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa, dt, cloud2rain, cloud2snow,
-                           i0, i1, jts - c->jms, kts - c->kms, kte - c->kms, cpb, ib0, c->d_flag);
-    }
+    hipLaunchKernelGGL(k_mp_simple_pack, dim3(nbmax, nrmax, n), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d,
+                       p, th, pii, rho, qv, qc, qr, qs, dz, pa, sa, dt, cloud2rain, cloud2snow,
+                       tl, kts - c->kms, kte - c->kms, cpb, err_out ? c->d_flag : nullptr);
     HIPCHK(hipGetLastError());
     if (err_out) {
         HIPCHK(hipMemcpyAsync(err_out, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     return 0;
+}
+
+int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_out)
+{
+    const int tile[1][4] = {{its, ite, jts, jte}};
+    return icar_mp_simple_run_tiles(c, dt, 1, tile, kts, kte, err_out);
 }

@@ -210,6 +210,22 @@ def _halo_unpack(self, direction, halo, field_ids, buf):
                                      ctypes.c_void_p(buf.data_ptr())), "icar_hip_halo_unpack")
 
 
+def _halo_many(self, fn, what, directions, halo, field_ids, bufs):
+    arr = (ctypes.c_int * len(field_ids))(*field_ids)
+    dirs = (ctypes.c_int * len(directions))(*[int(x) for x in directions])
+    ptrs = (ctypes.c_void_p * len(bufs))(*[ctypes.c_void_p(b.data_ptr()) for b in bufs])
+    check(fn(self.ctx, len(directions), dirs, int(halo), arr, len(field_ids), ptrs), what)
+
+
+def _halo_pack_many(self, directions, halo, field_ids, bufs):
+    """all directions of a halo_send in one launch (icar_hip_halo_pack_dirs)"""
+    _halo_many(self, lib().icar_hip_halo_pack_dirs, "icar_hip_halo_pack_dirs", directions, halo, field_ids, bufs)
+
+
+def _halo_unpack_many(self, directions, halo, field_ids, bufs):
+    _halo_many(self, lib().icar_hip_halo_unpack_dirs, "icar_hip_halo_unpack_dirs", directions, halo, field_ids, bufs)
+
+
 def _box_pack(self, field, which, i0, ni, j0, nj, buf):
     check(lib().icar_hip_box_pack(self.ctx, int(field), int(which), int(i0), int(ni), int(j0), int(nj),
                                   ctypes.c_void_p(buf.data_ptr())), "icar_hip_box_pack")
@@ -226,3 +242,5 @@ domain_t.halo_count = _halo_count
 domain_t.new_buffer = _new_buffer
 domain_t.halo_pack = _halo_pack
 domain_t.halo_unpack = _halo_unpack
+domain_t.halo_pack_many = _halo_pack_many
+domain_t.halo_unpack_many = _halo_unpack_many

@@ -15,7 +15,7 @@ module icar_hip
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
             hip_diagnostic_update, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
-            hip_halo_unpack, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, &
+            hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, &
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
@@ -133,6 +133,18 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_halo_unpack(ctx, dir, halo, fields, n, dbuf) bind(C, name="icar_hip_halo_unpack")
        import; type(c_ptr), value :: ctx, dbuf; integer(c_int), value :: dir, halo, n; integer(c_int), intent(in) :: fields(*)
+     end function
+     integer(c_int) function icar_hip_mp_simple_tiles(ctx, dt, ntiles, tiles, kts, kte, err_count) bind(C, name="icar_hip_mp_simple_tiles")
+       import; type(c_ptr), value :: ctx, err_count; real(c_float), value :: dt; integer(c_int), value :: ntiles, kts, kte
+       integer(c_int), intent(in) :: tiles(4,*)
+     end function
+     integer(c_int) function icar_hip_halo_pack_dirs(ctx, ndirs, dirs, halo, fields, n, dbufs) bind(C, name="icar_hip_halo_pack_dirs")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: ndirs, halo, n
+       integer(c_int), intent(in) :: dirs(*), fields(*); type(c_ptr), intent(in) :: dbufs(*)
+     end function
+     integer(c_int) function icar_hip_halo_unpack_dirs(ctx, ndirs, dirs, halo, fields, n, dbufs) bind(C, name="icar_hip_halo_unpack_dirs")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: ndirs, halo, n
+       integer(c_int), intent(in) :: dirs(*), fields(*); type(c_ptr), intent(in) :: dbufs(*)
      end function
      integer(c_int) function icar_hip_thompson_tiles(ctx, dt, ntiles, tiles, kts, kte, ids, ide, jds, jde, kds, kde) &
           bind(C, name="icar_hip_thompson_tiles")
@@ -394,6 +406,33 @@ contains
     integer(c_int), intent(in) :: fields(:)
     type(c_ptr), intent(in) :: dbuf
     call check(icar_hip_halo_unpack(ctx%p, int(dir,c_int), int(halo,c_int), fields, int(size(fields),c_int), dbuf), "halo_unpack")
+  end subroutine
+
+  !> process_halo's strips for mp_simple in one launch: tiles(1:4, t) = its, ite, jts, jte of strip t
+  subroutine hip_mp_simple_tiles(ctx, dt, tiles, kts, kte)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dt
+    integer(c_int), intent(in) :: tiles(:,:)
+    integer, intent(in) :: kts, kte
+    call check(icar_hip_mp_simple_tiles(ctx%p, real(dt,c_float), int(size(tiles,2),c_int), tiles, int(kts,c_int), int(kte,c_int), &
+                                        c_null_ptr), "mp_simple_tiles")
+  end subroutine
+
+  !> every direction of one halo_send / halo_retrieve in one launch (dirs(t), dbufs(t))
+  subroutine hip_halo_pack_dirs(ctx, dirs, halo, fields, dbufs)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: dirs(:), fields(:)
+    integer, intent(in) :: halo
+    type(c_ptr), intent(in) :: dbufs(:)
+    call check(icar_hip_halo_pack_dirs(ctx%p, int(size(dirs),c_int), dirs, int(halo,c_int), fields, int(size(fields),c_int), dbufs), "halo_pack_dirs")
+  end subroutine
+
+  subroutine hip_halo_unpack_dirs(ctx, dirs, halo, fields, dbufs)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: dirs(:), fields(:)
+    integer, intent(in) :: halo
+    type(c_ptr), intent(in) :: dbufs(:)
+    call check(icar_hip_halo_unpack_dirs(ctx%p, int(size(dirs),c_int), dirs, int(halo,c_int), fields, int(size(fields),c_int), dbufs), "halo_unpack_dirs")
   end subroutine
 
   !> process_halo's strips (mp_driver.f90:609-658) in one launch: tiles(1:4, t) = its, ite, jts, jte of strip t

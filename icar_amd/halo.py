@@ -21,6 +21,26 @@ _OPPOSITE = {DIR_NORTH: DIR_SOUTH, DIR_SOUTH: DIR_NORTH, DIR_EAST: DIR_WEST, DIR
 _NAMES = {DIR_NORTH: "north", DIR_SOUTH: "south", DIR_EAST: "east", DIR_WEST: "west"}
 
 
+def _pack_all(tile, dirs, halo, field_ids, bufs):
+    """every direction in one launch where the tile can (device tiles), one call per direction otherwise (host double)"""
+    if hasattr(tile, "halo_pack_many") and len(dirs) > 1:
+        tile.halo_pack_many(dirs, halo, field_ids, bufs)
+    else:
+        for d, b in zip(dirs, bufs):
+            tile.halo_pack(d, halo, field_ids, b)
+
+
+def _unpack_all(tile, dirs, halo, field_ids, bufs):
+    """N/S rows and E/W columns both cover the corner cells; the reference retrieves N, S, E, W in that order
+    (exchangeable_obj.f90:138-151), so E/W win there.  The one-launch kernel reproduces that (its rows skip the corners
+    an E/W message of the same call fills); separate launches run in the same order."""
+    if hasattr(tile, "halo_unpack_many") and len(dirs) > 1:
+        tile.halo_unpack_many(dirs, halo, field_ids, bufs)
+    else:
+        for d, b in sorted(zip(dirs, bufs), key=lambda t: t[0]):
+            tile.halo_unpack(d, halo, field_ids, b)
+
+
 class HaloComm:
     def __init__(self, grid, image, group=None, halo=None, loopback=False):
         """loopback=True: edges WITHOUT a neighbouring image wrap around to the tile's own opposite edge (a periodic
@@ -61,14 +81,12 @@ class HaloComm:
             if self._loopbuf.get("nf") != len(field_ids):
                 self._loopbuf = {d: tile.new_buffer(tile.halo_count(d, self.halo) * len(field_ids)) for d in self.loop}
                 self._loopbuf["nf"] = len(field_ids)
-            for d in self.loop:
-                tile.halo_pack(d, self.halo, field_ids, self._loopbuf[d])
+            _pack_all(tile, self.loop, self.halo, field_ids, [self._loopbuf[d] for d in self.loop])
         if not self.peers or not field_ids:
             return
         self._buffers(tile, len(field_ids))
         ops = []
-        for d, peer in self.peers.items():
-            tile.halo_pack(d, self.halo, field_ids, self._send[d])
+        _pack_all(tile, list(self.peers), self.halo, field_ids, [self._send[d] for d in self.peers])
         sbuf, rbuf = self._send, self._recv
         self._host_sync = bool(getattr(tile, "needs_host_sync", lambda: False)()) and not self._stage
         if self._host_sync:
@@ -90,8 +108,8 @@ class HaloComm:
         """exchangeable%retrieve: `sync images(neighbors)` == wait for the posted transfers,
         then copy each inbox into the halo planes facing that neighbour."""
         if self.loop and field_ids:
-            for d in self.loop:                              # my north edge is what arrives from the south, etc.
-                tile.halo_unpack(_OPPOSITE[d], self.halo, field_ids, self._loopbuf[d])
+            # my north edge is what arrives from the south, etc.
+            _unpack_all(tile, [_OPPOSITE[d] for d in self.loop], self.halo, field_ids, [self._loopbuf[d] for d in self.loop])
         if not self.peers or not field_ids:
             return
         for r in self._reqs:
@@ -99,11 +117,11 @@ class HaloComm:
         self._reqs = []
         if getattr(self, "_host_sync", False):
             torch.cuda.current_stream().synchronize()   # r.wait() only blocks torch's stream; unpack runs on the context's
-        for d in self.peers:
-            if self._stage:
+        if self._stage:
+            for d in self.peers:
                 self._recv[d].copy_(self._hrecv[d])
-                torch.cuda.synchronize()                # the copy ran on torch's stream, unpack runs on the context's
-            tile.halo_unpack(d, self.halo, field_ids, self._recv[d])
+            torch.cuda.synchronize()                    # the copies ran on torch's stream, unpack runs on the context's
+        _unpack_all(tile, list(self.peers), self.halo, field_ids, [self._recv[d] for d in self.peers])
 
 
     # ---- exchange_u / exchange_v (exchangeable_obj.f90:158-229) -----------------------------------------------

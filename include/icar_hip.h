@@ -143,6 +143,9 @@ int icar_hip_advect(icar_hip_ctx *ctx, int scheme, int mpdata_order, int fct, in
  * the number of columns on which the reference would have hit its `stop` in phase_change. */
 int icar_hip_mp_simple(icar_hip_ctx *ctx, float dt,
                        int its, int ite, int jts, int jte, int kts, int kte, int *err_count);
+/* process_halo's strips (src/physics/mp_driver.f90:609-658: one process_subdomain -> mp_simple_driver call per strip) as
+ * ONE launch over up to 4 non-overlapping tiles {its,ite,jts,jte} (as icar_hip_mp_tiles returns them). */
+int icar_hip_mp_simple_tiles(icar_hip_ctx *ctx, float dt, int ntiles, const int tiles[][4], int kts, int kte, int *err_count);
 
 /* ---- M2-M4: Thompson microphysics ------------------------------------------------------------
  * thompson_init (src/physics/mp_thompson.f90:342-766; params/flags = mp_options_type in the
@@ -294,6 +297,10 @@ int icar_hip_box_pack(icar_hip_ctx *ctx, int field, int which, int i0, int ni, i
 int icar_hip_box_unpack(icar_hip_ctx *ctx, int field, int which, int i0, int ni, int j0, int nj, const void *dbuf);
 int icar_hip_halo_pack(icar_hip_ctx *ctx, int dir, int halo, const int *fields, int nfields, void *dbuf);
 int icar_hip_halo_unpack(icar_hip_ctx *ctx, int dir, int halo, const int *fields, int nfields, const void *dbuf);
+/* the same for several directions in ONE launch (dirs[z], dbufs[z], z < ndirs <= 4): what domain%halo_send /
+ * halo_retrieve (objects/domain_obj.f90:109-143) issue per step -- 2 launches instead of 8 for an image with 4 neighbours */
+int icar_hip_halo_pack_dirs(icar_hip_ctx *ctx, int ndirs, const int *dirs, int halo, const int *fields, int nfields, void *const *dbufs);
+int icar_hip_halo_unpack_dirs(icar_hip_ctx *ctx, int ndirs, const int *dirs, int halo, const int *fields, int nfields, void *const *dbufs);
 
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Average duration (ms) of the launches of a named kernel group since the last reset, measured

@@ -43,6 +43,33 @@ def test_pack_unpack_match_host_double(halo):
     d.close()
 
 
+@pytest.mark.parametrize("halo", [1, 2])
+@pytest.mark.parametrize("dirs", [[0, 1, 2, 3], [3, 0], [0, 1], [2, 3, 1]])
+def test_pack_unpack_dirs_one_launch_equals_per_direction(halo, dirs):
+    """icar_hip_halo_pack_dirs / _unpack_dirs == the per-direction calls in the reference's retrieve order N, S, E, W
+    (exchangeable_obj.f90:138-151): E/W win the corner cells."""
+    g = grid_t().set_grid_dimensions(70, 50, 7, 4, 1, halo_width=halo)
+    ny, nz, nx = g.jme - g.jms + 1, 7, g.ime - g.ims + 1
+    rng = np.random.default_rng(11)
+    host = {0: rng.standard_normal((ny, nz, nx)).astype(np.float32), 5: rng.standard_normal((ny, nz, nx)).astype(np.float32)}
+    d = mk_domain(g, {"water_vapor": host[0], "potential_temperature": host[5]})
+    ids = [0, 4]
+    ht = HostTile(g, {0: host[0].copy(), 4: host[5].copy()})
+    gb = [d.new_buffer(d.halo_count(x, halo) * 2) for x in dirs]
+    d.halo_pack_many(dirs, halo, ids, gb); d.synchronize()
+    for x, b in zip(dirs, gb):
+        hb = ht.new_buffer(ht.halo_count(x, halo) * 2)
+        ht.halo_pack(x, halo, ids, hb)
+        assert torch.equal(b.cpu(), hb), f"pack dir {x}"
+    inbox = [torch.from_numpy(rng.standard_normal(b.numel()).astype(np.float32)) for b in gb]
+    d.halo_unpack_many(dirs, halo, ids, [t.cuda() for t in inbox]); d.synchronize()
+    for x, t in sorted(zip(dirs, inbox), key=lambda p: p[0]):
+        ht.halo_unpack(x, halo, ids, t)
+    assert np.array_equal(d.get("water_vapor"), ht.f[0])
+    assert np.array_equal(d.get("potential_temperature"), ht.f[4])
+    d.close()
+
+
 def test_two_tiles_one_process_exchange():
     """West tile (image 1) and east tile (image 2) of a 1x2... 2x1 decomposition: my east faces land
     in the neighbour's west halo and vice versa; both end up equal to the global field."""
