@@ -36,6 +36,9 @@ __device__ __forceinline__ double d_pow(double x, double y)
     return __builtin_nan("");
 }
 __device__ __forceinline__ float d_powf(float x, float y) { return (float)d_pow((double)x, (double)y); }
+// the same values from L = d_log(x) of a base x > 0 that several powers share (one logarithm instead of one per power)
+__device__ __forceinline__ double d_pow_l(double L, double y) { return (y == 0.0) ? 1.0 : d_exp(y * L); }
+__device__ __forceinline__ float d_powf_l(double L, float y) { return (float)d_pow_l(L, (double)y); }
 // 10.**y (REAL y): exp(y ln 10), the same evaluation d_pow makes with its log already folded
 __device__ __forceinline__ float d_pow10f(float y) { return y == 0.0f ? 1.0f : (float)d_exp((double)y * 2.30258509299404568402e+00); }
 __device__ __forceinline__ float d_expf(float x) { return (float)d_exp((double)x); }
@@ -77,6 +80,35 @@ __device__ __forceinline__ int dec_index_d(double r, int n2)
         if ((r / (double)powi10f(nn)) >= 1.0 && (r / (double)powi10f(nn)) < 10.0) break;
     }
     return (int)(r / (double)powi10f(n)) + 10 * (n - n2) - (n - n2);
+}
+
+/* The two routines above cost ~200 instructions per index (a logarithm, up to three trips of repeated squaring, a
+ * reciprocal and two divisions each) and a level evaluates up to eight of them.  Their result is n = the decade D with
+ * 10**D <= r < 10**(D+1) whenever r is not within rounding distance of a power of ten: the loop starts at nic-1 with
+ * nic = nint(log10 r) in {D, D+1}, its test fails for D-1 and holds for D.  So: D from the hardware log2 (error ~1e-5
+ * decades); if the fractional part of log10 r is at least 2e-4 away from 0 and 1 (the float powers of ten are within 1e-6
+ * of the exact ones) the index is (int)(r / 10**D) + 9 (D - n2) with the SAME float 10**D (table filled by powi10f) and
+ * the same IEEE division; otherwise (about 4 values in 10^4) the reference's loop runs. */
+__device__ __forceinline__ bool dec_fast(const ThState *__restrict__ T, float rf, int &D, float &p)
+{
+    const float t = __builtin_amdgcn_logf(rf) * 0.30102999566f;          /* v_log_f32 = log2 */
+    const float fl = floorf(t), fr = t - fl;
+    D = (int)fl;
+    const bool ok = (fr > 2.e-4f) && (fr < 1.0f - 2.e-4f) && (D >= -TH_P10_OFF + 1) && (D <= TH_P10_N - TH_P10_OFF - 2) && (rf > 1.e-37f);
+    p = T->p10[ok ? D + TH_P10_OFF : TH_P10_OFF];
+    return ok;
+}
+__device__ __forceinline__ int dec_index_f(const ThState *__restrict__ T, float r, int n2)
+{
+    int D; float p;
+    if (dec_fast(T, r, D, p)) return (int)(r / p) + 10 * (D - n2) - (D - n2);
+    return dec_index_f(r, n2);
+}
+__device__ __forceinline__ int dec_index_d(const ThState *__restrict__ T, double r, int n2)
+{
+    int D; float p;
+    if (r < 1.e37 && dec_fast(T, (float)r, D, p)) return (int)(r / (double)p) + 10 * (D - n2) - (D - n2);
+    return dec_index_d(r, n2);
 }
 
 /* x**3.0 with a PARAMETER exponent is expanded to multiplications by flang (verified: the tables are
@@ -205,7 +237,15 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     th[c] = t1d / pi_;
 }
 // arguments come from the host so that nothing is folded at compile time: the value must be what a level computes at run time
-__global__ void k_thompson_constants(ThState *T, float rg, float xslw1) { T->N0_exp_default = th_graupel_N0_exp(rg, xslw1); }
+__global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
+{
+    T->N0_exp_default = th_graupel_N0_exp(rg, xslw1);
+    T->pw_cgg_obmg = d_powf(T->cgg[2] * T->ogg2 * T->ogg1, T->obmg);
+    T->pw_ccg_obmr = d_powf(T->ccg[2] * T->ocg2, T->obmr);
+    T->log_Dr_span = log(T->Dr[NBINS - 1] / T->Dr[0]);
+    T->log_Ds_span = log(T->Ds[NBINS - 1] / T->Ds[0]);
+    for (int n = 0; n < TH_P10_N; ++n) T->p10[n] = powi10f(n - TH_P10_OFF);
+}
 }  // namespace
 
 // called by icar_thompson_init_run once the device state exists

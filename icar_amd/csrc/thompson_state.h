@@ -15,6 +15,8 @@
 #define NTB_R1 37
 #define NTB_I1 55
 #define NTB_T 9
+#define TH_P10_N 84            /* 10**n, n = -TH_P10_OFF .. TH_P10_N-TH_P10_OFF-1 (= -45 .. 38) */
+#define TH_P10_OFF 45
 
 #define TH_T_0 273.15f
 #define TH_PI2 3.1415926536f
@@ -91,4 +93,10 @@ struct ThState {
     /* graupel intercept of a level without graupel above 5e-5 and without supercooled rain (mp_thompson.f90:1456-1466 with
      * rg <= 5e-5, xslw1 = 0.01): a constant, evaluated once on the device by the very function the levels use */
     double N0_exp_default;
+    /* more values a level would otherwise recompute from constants, produced by the level code's own functions
+     * (k_thompson_constants): (cgg(3)*ogg2*ogg1)**obmg (:1464, :2387), (ccg(3)*ocg2)**obmr (:1518),
+     * log(Dr(nbr)/Dr(1)) and log(Ds(nbs)/Ds(1)) (:1533, :1703), and 10.**n for the decade indices (:1562-1627) */
+    float pw_cgg_obmg, pw_ccg_obmr;
+    double log_Dr_span, log_Ds_span;
+    float p10[TH_P10_N];
 };
