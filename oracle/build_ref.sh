@@ -32,7 +32,7 @@ for f in constants/icar_constants constants/wrf_constants utilities/time_delta_o
          main/data_structures objects/opt_types objects/options_h utilities/assertions objects/grid_h \
          objects/meta_data_h objects/variable_h objects/variable_dict_h objects/exchangeable_h \
          objects/boundary_h objects/domain_h objects/grid_obj physics/adv_mpdata physics/advect \
-         physics/mp_simple physics/mp_thompson utilities/atm_utilities utilities/array_utilities physics/mp_wsm3 ; do
+         physics/mp_simple physics/mp_thompson utilities/atm_utilities utilities/array_utilities physics/mp_wsm3 physics/mp_wsm6 ; do
   o=$(basename $f).o
   if [ ! -f "$o" ] || [ "$R/$f.f90" -nt "$o" ]; then
     $FC $FLAGS "$R/$f.f90" -o "$o" 2>&1 | grep -v "multi image Fortran features" || true
@@ -42,7 +42,7 @@ $FC $FLAGS "$HERE/ref_shim.f90" -o ref_shim.o 2>&1 | grep -v "multi image Fortra
 OBJS="ref_shim.o ref_link_stubs.o ref_link_stubs_c.o \
     adv_mpdata.o advect.o mp_simple.o mp_thompson.o icar_constants.o wrf_constants.o data_structures.o \
     opt_types.o options_h.o domain_h.o grid_h.o variable_h.o variable_dict_h.o meta_data_h.o \
-    exchangeable_h.o boundary_h.o time_h.o time_delta_obj.o assertions.o grid_obj.o atm_utilities.o array_utilities.o mp_wsm3.o"
+    exchangeable_h.o boundary_h.o time_h.o time_delta_obj.o assertions.o grid_obj.o atm_utilities.o array_utilities.o mp_wsm3.o mp_wsm6.o"
 # The interface modules carry type-bound-procedure tables that point at bodies living in the
 # (uncompiled, NetCDF-dependent) *_obj.f90 submodules.  They are never called on this path; bind
 # each such dangling Fortran module symbol (_QM*) to address 0, which is what a static link with

@@ -261,3 +261,25 @@ def wsm3(th, q, qci, qrs, w, den, pii, p, delz, args18, rain, rainncv, snow, sno
     fn = lib().orc_wsm3; fn.restype = ctypes.c_int
     return int(fn(_i(nx), _i(nz), _i(ny), _p(th), _p(q), _p(qci), _p(qrs), _p(w), _p(den), _p(pii), _p(p), _p(delz), _p(a),
                   _p(rain), _p(rainncv), _p(snow), _p(snowncv), _p(sr), *[_i(x) for x in (its, ite, jts, jte, kts, kte)]))
+
+
+# ---- WSM6 (oracle/wsm6_oracle.c) -------------------------------------------------------------------------------------
+WSM6_CONSTS = ("qc0 qck1 bvtr1 bvtr2 bvtr3 bvtr4 g1pbr g3pbr g4pbr g5pbro2 pvtr eacrr pacrr bvtr6 g6pbr precr1 precr2 roqimax bvts1 bvts2 "
+               "bvts3 bvts4 g1pbs g3pbs g4pbs g5pbso2 pvts pacrs precs1 precs2 pidn0r pidn0s xlv1 pacrc pi bvtg1 bvtg2 bvtg3 bvtg4 g1pbg "
+               "g3pbg g4pbg g5pbgo2 pvtg pacrg precg1 precg2 pidn0g rslopermax rslopesmax rslopegmax rsloperbmax rslopesbmax rslopegbmax "
+               "rsloper2max rslopes2max rslopeg2max rsloper3max rslopes3max rslopeg3max").split()
+
+
+def wsm6_init(den0=WSM3_INIT_ARGS[0], denr=WSM3_INIT_ARGS[1], dens=WSM3_INIT_ARGS[2], cl=WSM3_INIT_ARGS[3], cpv=WSM3_INIT_ARGS[4]):
+    """wsm6init with the arguments of mp_driver.f90:100 (the same five as wsm3init's)"""
+    out = np.zeros(len(WSM6_CONSTS), np.float32)
+    lib().orc_wsm6_init(_f(den0), _f(denr), _f(dens), _f(cl), _f(np.float32(cpv)), _p(out))
+    return dict(zip(WSM6_CONSTS, out))
+
+
+def wsm6(th, q, qc, qr, qi, qs, qg, den, pii, p, delz, args18, rain, sr, snow, graupel, its, ite, jts, jte, kts, kte):
+    ny, nz, nx = q.shape
+    a = np.ascontiguousarray(args18, np.float32)
+    fn = lib().orc_wsm6; fn.restype = ctypes.c_int
+    return int(fn(_i(nx), _i(nz), _i(ny), _p(th), _p(q), _p(qc), _p(qr), _p(qi), _p(qs), _p(qg), _p(den), _p(pii), _p(p), _p(delz), _p(a),
+                  _p(rain), _p(sr), _p(snow), _p(graupel), *[_i(x) for x in (its, ite, jts, jte, kts, kte)]))

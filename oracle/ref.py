@@ -201,3 +201,17 @@ def wsm3(th, q, qci, qrs, w, den, pii, p, delz, delt, rain, rainncv, snow, snown
     ny, nz, nx = q.shape
     lib().ref_wsm3(_i(nx), _i(nz), _i(ny), _p(th), _p(q), _p(qci), _p(qrs), _p(w), _p(den), _p(pii), _p(p), _p(delz), _f(delt),
                    _p(rain), _p(rainncv), _p(snow), _p(snowncv), _p(sr), *[_i(x) for x in (its, ite, jts, jte, kts, kte)])
+
+
+# ---- WSM6 (physics/mp_wsm6.f90 compiled unmodified) ------------------------------------------------------------------
+def wsm6_init():
+    """wsm6init as mp_driver.f90:100 calls it -> the 60 module constants in the order of oracle.orc.WSM6_CONSTS"""
+    out = np.zeros(60, np.float32)
+    lib().ref_wsm6_init(_p(out))
+    return out
+
+
+def wsm6(th, q, qc, qr, qi, qs, qg, den, pii, p, delz, delt, rain, rainncv, sr, snow, graupel, its, ite, jts, jte, kts, kte):
+    ny, nz, nx = q.shape
+    lib().ref_wsm6(_i(nx), _i(nz), _i(ny), _p(th), _p(q), _p(qc), _p(qr), _p(qi), _p(qs), _p(qg), _p(den), _p(pii), _p(p), _p(delz),
+                   _f(delt), _p(rain), _p(rainncv), _p(sr), _p(snow), _p(graupel), *[_i(x) for x in (its, ite, jts, jte, kts, kte)])

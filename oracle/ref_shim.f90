@@ -31,6 +31,20 @@ module icar_ref_shim
        w3_precs1 => precs1, w3_precs2 => precs2, w3_pidn0r => pidn0r, w3_pidn0s => pidn0s, w3_xlv1 => xlv1, w3_pi => pi, &
        w3_rslopermax => rslopermax, w3_rslopesmax => rslopesmax, w3_rsloperbmax => rsloperbmax, w3_rslopesbmax => rslopesbmax, &
        w3_rsloper2max => rsloper2max, w3_rslopes2max => rslopes2max, w3_rsloper3max => rsloper3max, w3_rslopes3max => rslopes3max
+  use module_mp_wsm6,    only: wsm6, wsm6init, &
+       w6_qc0 => qc0, w6_qck1 => qck1, w6_bvtr1 => bvtr1, w6_bvtr2 => bvtr2, w6_bvtr3 => bvtr3, w6_bvtr4 => bvtr4, &
+       w6_g1pbr => g1pbr, w6_g3pbr => g3pbr, w6_g4pbr => g4pbr, w6_g5pbro2 => g5pbro2, w6_pvtr => pvtr, w6_eacrr => eacrr, &
+       w6_pacrr => pacrr, w6_bvtr6 => bvtr6, w6_g6pbr => g6pbr, w6_precr1 => precr1, w6_precr2 => precr2, &
+       w6_roqimax => roqimax, w6_bvts1 => bvts1, w6_bvts2 => bvts2, w6_bvts3 => bvts3, w6_bvts4 => bvts4, w6_g1pbs => g1pbs, &
+       w6_g3pbs => g3pbs, w6_g4pbs => g4pbs, w6_g5pbso2 => g5pbso2, w6_pvts => pvts, w6_pacrs => pacrs, w6_precs1 => precs1, &
+       w6_precs2 => precs2, w6_pidn0r => pidn0r, w6_pidn0s => pidn0s, w6_xlv1 => xlv1, w6_pacrc => pacrc, w6_pi => pi, &
+       w6_bvtg1 => bvtg1, w6_bvtg2 => bvtg2, w6_bvtg3 => bvtg3, w6_bvtg4 => bvtg4, w6_g1pbg => g1pbg, w6_g3pbg => g3pbg, &
+       w6_g4pbg => g4pbg, w6_g5pbgo2 => g5pbgo2, w6_pvtg => pvtg, w6_pacrg => pacrg, w6_precg1 => precg1, &
+       w6_precg2 => precg2, w6_pidn0g => pidn0g, w6_rslopermax => rslopermax, w6_rslopesmax => rslopesmax, &
+       w6_rslopegmax => rslopegmax, w6_rsloperbmax => rsloperbmax, w6_rslopesbmax => rslopesbmax, &
+       w6_rslopegbmax => rslopegbmax, w6_rsloper2max => rsloper2max, w6_rslopes2max => rslopes2max, &
+       w6_rslopeg2max => rslopeg2max, w6_rsloper3max => rsloper3max, w6_rslopes3max => rslopes3max, &
+       w6_rslopeg3max => rslopeg3max
   use mod_wrf_constants, only: wc_cpv => cpv, wc_cliq => cliq, wc_cice => cice, wc_psat => psat, wc_XLS => XLS, wc_XLV => XLV, &
        wc_XLF => XLF, wc_rhoair0 => rhoair0, wc_rhowater => rhowater, wc_rhosnow => rhosnow, wc_epsilon => epsilon
   use prif,              only: stub_num_images
@@ -312,6 +326,38 @@ contains
               rd=Rd, rv=Rw, t0c=273.15, ep1=EP1, ep2=EP2, qmin=wc_epsilon, XLS=wc_XLS, XLV0=wc_XLV, XLF0=wc_XLF, &
               den0=wc_rhoair0, denr=wc_rhowater, cliq=wc_cliq, cice=wc_cice, psat=wc_psat, rain=rain, rainncv=rainncv, &
               snow=snow, snowncv=snowncv, sr=sr, has_reqc=0, has_reqi=0, has_reqs=0, &
+              ids=1, ide=nx, jds=1, jde=ny, kds=1, kde=nz, ims=1, ime=nx, jms=1, jme=ny, kms=1, kme=nz, &
+              its=its, ite=ite, jts=jts, jte=jte, kts=kts, kte=kte)
+  end subroutine
+
+  !> wsm6init (mp_wsm6.f90:1432-1506) as mp_driver.f90:100 calls it; out(1:60) = the module constants it derives, in the order of
+  !! their SAVE declaration (mp_wsm6.f90:44-58)
+  subroutine ref_wsm6_init(out) bind(C, name="ref_wsm6_init")
+    real(c_float), intent(out) :: out(60)
+    call wsm6init(wc_rhoair0, wc_rhowater, wc_rhosnow, wc_cliq, wc_cpv)
+    out = [ &
+           w6_qc0, w6_qck1, w6_bvtr1, w6_bvtr2, w6_bvtr3, w6_bvtr4, w6_g1pbr, w6_g3pbr, w6_g4pbr, w6_g5pbro2, w6_pvtr, &
+           w6_eacrr, w6_pacrr, w6_bvtr6, w6_g6pbr, w6_precr1, w6_precr2, w6_roqimax, w6_bvts1, w6_bvts2, w6_bvts3, &
+           w6_bvts4, w6_g1pbs, w6_g3pbs, w6_g4pbs, w6_g5pbso2, w6_pvts, w6_pacrs, w6_precs1, w6_precs2, w6_pidn0r, &
+           w6_pidn0s, w6_xlv1, w6_pacrc, w6_pi, w6_bvtg1, w6_bvtg2, w6_bvtg3, w6_bvtg4, w6_g1pbg, w6_g3pbg, w6_g4pbg, &
+           w6_g5pbgo2, w6_pvtg, w6_pacrg, w6_precg1, w6_precg2, w6_pidn0g, w6_rslopermax, w6_rslopesmax, w6_rslopegmax, &
+           w6_rsloperbmax, w6_rslopesbmax, w6_rslopegbmax, w6_rsloper2max, w6_rslopes2max, w6_rslopeg2max, &
+           w6_rsloper3max, w6_rslopes3max, w6_rslopeg3max]
+  end subroutine
+
+  !> wsm6 (mp_wsm6.f90:62) on a tile exactly as mp_driver.f90:518-550 calls it (snowncv / graupelncv absent).
+  !! Arrays (nx,nz,ny) / (nx,ny).
+  subroutine ref_wsm6(nx, nz, ny, th, q, qc, qr, qi, qs, qg, den, pii, p, delz, delt, rain, rainncv, sr, snow, graupel, &
+                      its, ite, jts, jte, kts, kte) bind(C, name="ref_wsm6")
+    integer(c_int), value :: nx, nz, ny, its, ite, jts, jte, kts, kte
+    real(c_float), value :: delt
+    real(c_float), intent(inout), dimension(nx,nz,ny) :: th, q, qc, qr, qi, qs, qg
+    real(c_float), intent(in), dimension(nx,nz,ny) :: den, pii, p, delz
+    real(c_float), intent(inout), dimension(nx,ny) :: rain, rainncv, sr, snow, graupel
+    call wsm6(q=q, th=th, qc=qc, qi=qi, qr=qr, qs=qs, qg=qg, pii=pii, p=p, delz=delz, den=den, delt=delt, g=gravity, cpd=cp, &
+              cpv=wc_cpv, rd=Rd, rv=Rw, t0c=273.15, ep1=EP1, ep2=EP2, qmin=wc_epsilon, XLS=wc_XLS, XLV0=wc_XLV, XLF0=wc_XLF, &
+              den0=wc_rhoair0, denr=wc_rhowater, cliq=wc_cliq, cice=wc_cice, psat=wc_psat, rain=rain, rainncv=rainncv, sr=sr, &
+              snow=snow, graupel=graupel, &
               ids=1, ide=nx, jds=1, jde=ny, kds=1, kde=nz, ims=1, ime=nx, jms=1, jme=ny, kms=1, kme=nz, &
               its=its, ite=ite, jts=jts, jte=jte, kts=kts, kte=kte)
   end subroutine
