@@ -36,7 +36,7 @@ def build_tile(args, rank, world, device):
     from icar_amd.halo import HaloComm
     from icar_amd.microphysics import mp_var_request, mp_init
     from icar_amd.advection import adv_var_request, adv_init
-    from icar_amd.constants import kADV_MPDATA, kADV_UPWIND, kMP_THOMPSON, kMP_SB04, kMP_WSM3, KVARS, ADVECTION_ORDER
+    from icar_amd.constants import kADV_MPDATA, kADV_UPWIND, kMP_THOMPSON, kMP_SB04, kMP_WSM3, kMP_WSM6, KVARS, ADVECTION_ORDER
 
     xs, ys = domain_decomposition(args.nx, args.ny, world) if world > 1 else (1, 1)
     # weak scaling: the global domain grows with the image grid so each tile keeps nx x ny owned cells
@@ -48,7 +48,7 @@ def build_tile(args, rank, world, device):
     case["water_vapor"] = (case["water_vapor"] * np.float32(1.4)).astype(np.float32)
     opt = options_t()
     opt.physics.advection = kADV_UPWIND if args.adv == "upwind" else kADV_MPDATA
-    opt.physics.microphysics = {"thompson": kMP_THOMPSON, "simple": kMP_SB04, "wsm3": kMP_WSM3, "none": 0}[args.mp]
+    opt.physics.microphysics = {"thompson": kMP_THOMPSON, "simple": kMP_SB04, "wsm3": kMP_WSM3, "wsm6": kMP_WSM6, "none": 0}[args.mp]
     opt.parameters.ideal = True
     opt.parameters.dx = float(case["dx"])
     opt.parameters.dz_levels = case["dz_levels"]
@@ -136,6 +136,8 @@ def ref_child(args):
         ref.thompson_init(workdir=args.ref_child)
     if args.mp == "wsm3":
         ref.wsm3_init()
+    if args.mp == "wsm6":
+        ref.wsm6_init()
     acc = [z2() for _ in range(5)]
     t0 = time.perf_counter()
     if args.mp == "thompson":
@@ -148,6 +150,9 @@ def ref_child(args):
     elif args.mp == "wsm3":
         ref.wsm3(c["potential_temperature"], c["water_vapor"], c["cloud_water"], c["rain"], c["w"], c["density"], c["exner"], c["pressure"],
                  c["dz_mass"], dt, *acc, 2, nx - 1, 2, ny - 1, 1, nz)
+    elif args.mp == "wsm6":
+        ref.wsm6(c["potential_temperature"], c["water_vapor"], c["cloud_water"], c["rain"], c["cloud_ice"], c["snow"], c["graupel"], c["density"],
+                 c["exner"], c["pressure"], c["dz_mass"], dt, *acc, 2, nx - 1, 2, ny - 1, 1, nz)
     ref.advect(1 if args.adv == "upwind" else 2, q, c["u"], c["v"], c["w"], c["density"], c["jacobian"], c["jacobian_u"],
                c["jacobian_v"], c["jacobian_w"], c["advection_dz"], c["dz_levels"], float(c["dx"]), dt)
     el = time.perf_counter() - t0
@@ -210,6 +215,12 @@ def cpu_baseline(args, nscalars):
         w3args = np.array([dt, 9.81, 1012.0, 4 * np.float32(461.6), 287.058, 461.5, 273.15, np.float32(461.5) / np.float32(287.058) - np.float32(1),
                            np.float32(287.058) / np.float32(461.5), 1e-15, 2.85e6, 2.5e6, 3.5e5, 1.28, 1000.0, 4190.0, 2106.0, 610.78], np.float32)
         w3tmp = [np.zeros((ny, nx), np.float32) for _ in range(3)]
+    if args.mp == "wsm6":
+        orc.wsm6_init()
+        w3args = np.array([dt, 9.81, 1012.0, 4 * np.float32(461.6), 287.058, 461.5, 273.15, np.float32(461.5) / np.float32(287.058) - np.float32(1),
+                           np.float32(287.058) / np.float32(461.5), 1e-15, 2.85e6, 2.5e6, 3.5e5, 1.28, 1000.0, 4190.0, 2106.0, 610.78], np.float32)
+        w6 = {k: c[k].copy() for k in ["cloud_ice", "graupel"]}
+        w6.update(sr=np.zeros((ny, nx), np.float32), graupel_acc=np.zeros((ny, nx), np.float32))
 
     def step():
         if args.mp == "thompson":
@@ -222,6 +233,9 @@ def cpu_baseline(args, nscalars):
         elif args.mp == "wsm3":
             orc.wsm3(s["potential_temperature"], s["water_vapor"], s["cloud_water"], s["rain"], c["w"], s["density"], s["exner"], s["pressure"],
                      s["dz_mass"], w3args, rain, w3tmp[0], snow, w3tmp[1], w3tmp[2], 2, nx - 1, 2, ny - 1, 1, nz)
+        elif args.mp == "wsm6":
+            orc.wsm6(s["potential_temperature"], s["water_vapor"], s["cloud_water"], s["rain"], w6["cloud_ice"], s["snow"], w6["graupel"],
+                     s["density"], s["exner"], s["pressure"], s["dz_mass"], w3args, rain, w6["sr"], snow, w6["graupel_acc"], 2, nx - 1, 2, ny - 1, 1, nz)
         orc.advect(scheme, q, c["u"], c["v"], c["w"], c["density"], c["jacobian"], c["jacobian_u"], c["jacobian_v"],
                    c["jacobian_w"], c["advection_dz"], c["dz_levels"], float(c["dx"]), dt)
 
@@ -231,7 +245,7 @@ def cpu_baseline(args, nscalars):
         step(); n += 1
     el = time.perf_counter() - t0
     cells = (nx - 2) * (ny - 2) * nz * n
-    mpname = {"thompson": "Thompson", "simple": "mp_simple", "wsm3": "WSM3", "none": "no microphysics"}[args.mp]
+    mpname = {"thompson": "Thompson", "simple": "mp_simple", "wsm3": "WSM3", "wsm6": "WSM6", "none": "no microphysics"}[args.mp]
     return {"value": cells / el, "unit": "grid-cell updates/s", "cores": orc.num_threads(), "kind": "port",
             "sample": f"{n} steps of {nx}x{ny}x{nz}, {args.adv} advection of {nscalars} scalars + {mpname}, "
                       f"oracle/*.c CPU restatement (bit-identical to the reference kernels) with OpenMP on {orc.num_threads()} threads, {el:.1f} s"}
@@ -259,7 +273,7 @@ def main():
     ap.add_argument("--nz", type=int, default=40)
     ap.add_argument("--hill", type=float, default=1000.0)
     ap.add_argument("--adv", default="mpdata", choices=["mpdata", "upwind"])
-    ap.add_argument("--mp", default=os.environ.get("ICAR_BENCH_MP", "thompson"), choices=["thompson", "simple", "wsm3", "none"])
+    ap.add_argument("--mp", default=os.environ.get("ICAR_BENCH_MP", "thompson"), choices=["thompson", "simple", "wsm3", "wsm6", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ref-child", default=None, help=argparse.SUPPRESS)      # internal: cpu_reference()'s child process
     ap.add_argument("--ref-nscal", type=int, default=9, help=argparse.SUPPRESS)
@@ -396,7 +410,7 @@ def main():
                          "measured_copy_GBps": stream_gbs,
                          "frac_of_measured_copy": (achieved / stream_gbs) if stream_gbs else None},
             # informational: the microphysics is VALU-bound, its share of the step and its algorithmic traffic
-            "microphysics": {"kernel": {"thompson": "k_thompson_pack", "simple": "k_mp_simple_pack", "wsm3": "k_wsm3"}.get(args.mp, "none"), "bound": "valu",
+            "microphysics": {"kernel": {"thompson": "k_thompson_pack", "simple": "k_mp_simple_pack", "wsm3": "k_wsm3", "wsm6": "k_w6"}.get(args.mp, "none"), "bound": "valu",
                              "ms_per_step": mp_ms_step,
                              "algorithmic_GBps": (mem_cells * (84 if args.mp == "thompson" else 56) / (mp_ms_step * 1e-3) / 1e9) if mp_ms_step > 0 else 0.0},
         }

@@ -6,6 +6,7 @@ kADV_UPWIND = 1
 kADV_MPDATA = 2
 kMP_THOMPSON = 1
 kMP_SB04 = 2
+kMP_WSM6 = 4
 kMP_WSM3 = 6
 kDEFAULT_HALO_SIZE = 1          # icar_constants.f90:320
 

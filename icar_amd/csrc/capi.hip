@@ -395,6 +395,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     if (c->iw_adj) hipFree(c->iw_adj);
     if (c->wgr_tmp) hipFree(c->wgr_tmp);
     icar_wsm3_free(c);
+    icar_wsm6_free(c);
     icar_thompson_free(c);
     icar_linwinds_free(c);
     if (c->on_aux) c->stream = c->main_saved;
@@ -600,6 +601,20 @@ int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
     if (!c || (n > 0 && !fields)) { icar_set_error("enforce_limits: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_enforce_limits_run(c, fields, n);
+}
+
+int icar_hip_wsm6_init(icar_hip_ctx *c)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_wsm6_init_run(c);
+}
+
+int icar_hip_wsm6(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_wsm6_run(c, dt, its, ite, jts, jte, kts, kte);
 }
 
 int icar_hip_wsm3_init(icar_hip_ctx *c)

@@ -24,6 +24,7 @@ struct TimingGroup { double total_ms = 0; int launches = 0; };
 struct ThompsonTables;   // mp_thompson.hip
 struct LinWinds;         // linear_winds.hip
 struct Wsm3State;        // mp_wsm3.hip
+struct Wsm6State;        // mp_wsm6.hip
 
 struct icar_hip_ctx {
     int device = 0;
@@ -51,6 +52,7 @@ struct icar_hip_ctx {
     ThompsonTables *thompson = nullptr;
     LinWinds *linwinds = nullptr;
     Wsm3State *wsm3 = nullptr;
+    Wsm6State *wsm6 = nullptr;
     // timing
     bool timing = false;
     std::map<std::string, TimingGroup> timers;
@@ -101,6 +103,9 @@ void icar_linwinds_free(icar_hip_ctx *c);
 void icar_wsm3_free(icar_hip_ctx *c);
 int icar_wsm3_init_run(icar_hip_ctx *c);
 int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte);
+void icar_wsm6_free(icar_hip_ctx *c);
+int icar_wsm6_init_run(icar_hip_ctx *c);
+int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte);
 int icar_linwinds_setup_run(icar_hip_ctx *c, const icar_hip_lt_options *o, const float *terrain, int nxg, int nyg, int ids, int jds, float dx);
 int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, float zb, float zt, float minimum_step, double *u_out, double *v_out);
 int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *zt, int nlev);

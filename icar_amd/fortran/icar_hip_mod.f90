@@ -15,7 +15,7 @@ module icar_hip
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
             hip_diagnostic_update, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
-            hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, &
+            hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, &
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
@@ -105,6 +105,12 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_balance_uvw(ctx, dx) bind(C, name="icar_hip_balance_uvw")
        import; type(c_ptr), value :: ctx; real(c_float), value :: dx
+     end function
+     integer(c_int) function icar_hip_wsm6_init(ctx) bind(C, name="icar_hip_wsm6_init")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_wsm6(ctx, dt, its, ite, jts, jte, kts, kte) bind(C, name="icar_hip_wsm6")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dt; integer(c_int), value :: its, ite, jts, jte, kts, kte
      end function
      integer(c_int) function icar_hip_wsm3_init(ctx) bind(C, name="icar_hip_wsm3_init")
        import; type(c_ptr), value :: ctx
@@ -334,6 +340,20 @@ contains
     type(hip_ctx_t), intent(in) :: ctx
     real, intent(in) :: dx
     call check(icar_hip_balance_uvw(ctx%p, real(dx,c_float)), "balance_uvw")
+  end subroutine
+
+  !> wsm6init / wsm6 as mp_driver.f90:100 and :518-550 call them
+  subroutine hip_wsm6_init(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_wsm6_init(ctx%p), "wsm6_init")
+  end subroutine
+
+  subroutine hip_wsm6(ctx, dt, its, ite, jts, jte, kts, kte)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dt
+    integer, intent(in) :: its, ite, jts, jte, kts, kte
+    call check(icar_hip_wsm6(ctx%p, real(dt,c_float), int(its,c_int), int(ite,c_int), int(jts,c_int), int(jte,c_int), &
+                             int(kts,c_int), int(kte,c_int)), "wsm6")
   end subroutine
 
   !> wsm3init / wsm3 as mp_driver.f90:105 and :552-585 call them (qci = cloud_water_mass, qrs = rain_mass, w = w_real)

@@ -1,7 +1,7 @@
 """microphysics driver mirror (src/physics/mp_driver.f90): mp_var_request / mp_init / mp / mp_finish."""
 import ctypes
 from .capi import lib, check
-from .constants import kMP_THOMPSON, kMP_SB04, kMP_WSM3
+from .constants import kMP_THOMPSON, kMP_SB04, kMP_WSM3, kMP_WSM6
 
 
 def mp_var_request(options):
@@ -22,6 +22,13 @@ def mp_var_request(options):
         options.restart_vars(["pressure", "potential_temperature", "water_vapor", "cloud_water", "rain_in_air",
                               "rain_number_concentration", "snow_in_air", "cloud_ice", "ice_number_concentration",
                               "graupel_in_air", "precipitation", "snowfall", "graupel", "dz"])
+    elif mp == kMP_WSM6:                                # mp_driver.f90:146-172
+        options.alloc_vars(["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water", "rain_in_air",
+                            "snow_in_air", "cloud_ice", "dz", "snowfall", "precipitation", "graupel", "graupel_in_air"])
+        options.advect_vars(["potential_temperature", "water_vapor", "cloud_water", "snow_in_air", "cloud_ice", "rain_in_air",
+                             "graupel_in_air"])
+        options.restart_vars(["pressure", "potential_temperature", "water_vapor", "cloud_water", "rain_in_air", "snow_in_air",
+                              "precipitation", "snowfall", "graupel", "dz", "snow_in_air", "cloud_ice", "rain_in_air", "graupel_in_air"])
     elif mp == kMP_WSM3:                                # mp_driver.f90:174-198
         options.alloc_vars(["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water", "rain_in_air",
                             "dz", "snowfall", "precipitation"])
@@ -40,6 +47,10 @@ def mp_init(options, domain=None):
         p, f = options.mp_options.as_arrays()
         check(lib().icar_hip_thompson_init(domain.ctx, p.ctypes.data_as(ctypes.c_void_p),
                                            f.ctypes.data_as(ctypes.c_void_p)), "icar_hip_thompson_init")
+    if options.physics.microphysics == kMP_WSM6:
+        if domain is None:
+            raise ValueError("mp_init(options, domain): the WSM6 constants live in the domain's device context")
+        check(lib().icar_hip_wsm6_init(domain.ctx), "icar_hip_wsm6_init")
     if options.physics.microphysics == kMP_WSM3:
         if domain is None:
             raise ValueError("mp_init(options, domain): the WSM3 constants live in the domain's device context")
@@ -63,6 +74,8 @@ def _process_subdomain(domain, options, dt, its, ite, jts, jte, kts, kte):
     if mp_ == kMP_SB04:
         check(lib().icar_hip_mp_simple(domain.ctx, ctypes.c_float(dt), its, ite, jts, jte, kts, kte, None),
               "icar_hip_mp_simple")
+    elif mp_ == kMP_WSM6:
+        check(lib().icar_hip_wsm6(domain.ctx, ctypes.c_float(dt), its, ite, jts, jte, kts, kte), "icar_hip_wsm6")
     elif mp_ == kMP_WSM3:
         check(lib().icar_hip_wsm3(domain.ctx, ctypes.c_float(dt), its, ite, jts, jte, kts, kte), "icar_hip_wsm3")
     elif mp_ == kMP_THOMPSON:

@@ -179,6 +179,14 @@ int icar_hip_mp_tiles(int its, int ite, int jts, int jte, int halo, int subset, 
 int icar_hip_wsm3_init(icar_hip_ctx *ctx);
 int icar_hip_wsm3(icar_hip_ctx *ctx, float dt, int its, int ite, int jts, int jte, int kts, int kte);
 
+/* ---- WSM6 (src/physics/mp_wsm6.f90), the kMP_WSM6 slot of mp()'s dispatch (mp_driver.f90:98-101, :518-550) ----------------
+ * wsm6_init == wsm6init(rhoair0, rhowater, rhosnow, cliq, cpv) (:1432-1506).  wsm6 == process_subdomain's call of wsm6 (:62):
+ * q = WATER_VAPOR, qc = CLOUD_WATER, qi = CLOUD_ICE, qr = RAIN, qs = SNOW, qg = GRAUPEL, th = POTENTIAL_TEMPERATURE, with
+ * EXNER, PRESSURE, DZ_MASS, DENSITY; the tile's rain / snow / graupel surface sums are added to PRECIPITATION, SNOWFALL and
+ * GRAUPEL_ACC as mp_driver.f90:587-595 does.  4..64 levels. */
+int icar_hip_wsm6_init(icar_hip_ctx *ctx);
+int icar_hip_wsm6(icar_hip_ctx *ctx, float dt, int its, int ite, int jts, int jte, int kts, int kte);
+
 /* ---- T2: CFL reduction for compute_dt (src/main/time_step.f90:217-330, cfl_strictness 3) -----
  * out = max over the tile of max(|u_i|,|u_i+1|)/dx + max(|v_j|,|v_j+1|)/dx + max(|w_k|,|w_k-1|)/dz_levels(k) */
 int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, float *out);

@@ -1,0 +1,99 @@
+"""WSM6 on the device (icar_amd/csrc/mp_wsm6.hip) through mp()'s dispatch vs the CPU oracle (oracle/wsm6_oracle.c, a separate
+restatement pinned bit-for-bit to the compiled mp_wsm6.f90 in tests/test_oracle_wsm6.py):
+  * oracle math mode 1 (exp / log / x**y = FP64 function rounded once, as the device evaluates them): BIT-EXACT, state and the
+    REAL(8) precipitation / snowfall / graupel accumulators;
+  * oracle math mode 0 (libm, = the reference): rtol 1e-5 on all but a small share of cells (<= 2.5 %; a 1-ulp change of a
+    transcendental can flip one of the scheme's threshold tests), precipitation within 1e-4 relative."""
+import numpy as np
+import pytest
+from icar_amd import ideal
+from icar_amd.options import options_t
+from icar_amd.microphysics import mp, mp_init, mp_var_request
+from icar_amd.constants import kMP_WSM6
+from util import single_image_domain, parity_record, field_stats
+
+pytestmark = pytest.mark.gpu
+CASES = {"warm_rain": dict(nx=70, ny=21, nz=25, steps=6, dt=45.0, moist=1.8, cool0=0.0, cool=1.0, seed=3),
+         "snow_graupel_at_surface": dict(nx=66, ny=20, nz=30, steps=8, dt=60.0, moist=1.3, cool0=28.0, cool=0.5, seed=4),
+         "two_minor_loops_40_levels": dict(nx=40, ny=17, nz=40, steps=4, dt=200.0, moist=1.5, cool0=22.0, cool=1.0, seed=8),
+         "mixed_phase": dict(nx=68, ny=15, nz=32, steps=10, dt=75.0, moist=2.0, cool0=8.0, cool=1.5, seed=11),
+         "64_levels": dict(nx=34, ny=12, nz=64, steps=3, dt=90.0, moist=1.6, cool0=10.0, cool=1.0, seed=5, uniform_dz=150.0)}
+ARGS18 = np.array([0, 9.81, 1012.0, 4 * np.float32(461.6), 287.058, 461.5, 273.15, np.float32(461.5) / np.float32(287.058) - np.float32(1),
+                   np.float32(287.058) / np.float32(461.5), 1e-15, 2.85e6, 2.5e6, 3.5e5, 1.28, 1000.0, 4190.0, 2106.0, 610.78], np.float32)
+KEYS = ["potential_temperature", "water_vapor", "cloud_water", "rain", "cloud_ice", "snow", "graupel"]
+NAMES = {"cloud_water": "cloud_water_mass", "rain": "rain_mass", "cloud_ice": "cloud_ice_mass", "snow": "snow_mass", "graupel": "graupel_mass"}
+
+
+def run(oracle, k, mode, split=False):
+    nx, ny, nz, dt = k["nx"], k["ny"], k["nz"], k["dt"]
+    c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.03, seed=k["seed"], n_hydro=1, cool=k["cool0"], uniform_dz=k.get("uniform_dz"))
+    c["water_vapor"] = (c["water_vapor"] * np.float32(k["moist"])).astype(np.float32)
+    rng = np.random.default_rng(k["seed"])
+    for n, amp in (("cloud_ice", 2e-5), ("snow", 2e-4), ("graupel", 1e-4)):      # every class present from the first call
+        f = (amp * rng.random(c["water_vapor"].shape) ** 3).astype(np.float32)
+        f[rng.random(f.shape) < 0.4] = 0.0
+        c[n] = f
+    B = {n: c[n].copy() for n in KEYS}
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_WSM6
+    mp_var_request(opt); mp_init(opt, d)
+    assert all(opt.vars_to_advect.get(v, 0) > 0 for v in ("rain_in_air", "snow_in_air", "cloud_ice", "graupel_in_air"))
+    z2 = lambda: np.zeros((ny, nx), np.float32)
+    acc = {n: np.zeros((ny, nx), np.float64) for n in ("rain", "snow", "graupel")}
+    a18 = ARGS18.copy(); a18[0] = dt
+    oracle.set_math_mode(mode)
+    try:
+        oracle.wsm6_init()
+        for s in range(k["steps"]):
+            rb = dict(rain=z2(), sr=z2(), snow=z2(), graupel=z2())
+            assert oracle.wsm6(B["potential_temperature"], B["water_vapor"], B["cloud_water"], B["rain"], B["cloud_ice"], B["snow"], B["graupel"],
+                               c["density"], c["exner"], c["pressure"], c["dz_mass"], a18, rb["rain"], rb["sr"], rb["snow"], rb["graupel"],
+                               2, nx - 1, 2, ny - 1, 1, nz) == 0
+            for n in acc: acc[n] += rb[n]
+            B["potential_temperature"] -= np.float32(k["cool"])
+            if split:
+                mp(d, opt, dt, halo=1); mp(d, opt, dt, subset=1)      # strips + interior == whole tile
+            else:
+                mp(d, opt, dt)
+            d.model_time_seconds += dt
+            d.set("potential_temperature", d.get("potential_temperature") - np.float32(k["cool"]))
+    finally:
+        oracle.set_math_mode(0)
+    got = {n: d.get(NAMES.get(n, n)) for n in KEYS}
+    dacc = {"rain": d.get("accumulated_precipitation"), "snow": d.get("accumulated_snowfall"), "graupel": d.get("graupel")}
+    d.close()
+    return got, B, dacc, acc
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_wsm6_bit_exact_vs_oracle_device_math(oracle, case):
+    got, want, dacc, acc = run(oracle, CASES[case], mode=1, split=(case == "warm_rain"))
+    for n in KEYS:
+        parity_record("wsm6", f"{case}/mode1", {n: field_stats(got[n], want[n], 1e-5)})
+        assert np.array_equal(got[n].view(np.int32), want[n].view(np.int32)), f"{n}: {(got[n] != want[n]).sum()} cells differ"
+    for n in acc:
+        assert np.array_equal(dacc[n], acc[n]), n
+    assert acc["rain"].max() > 0.05 and want["cloud_water"].max() > 1e-5
+    if case == "snow_graupel_at_surface":
+        assert acc["snow"].max() > 0.05 and acc["graupel"].max() > 0
+    if case == "mixed_phase":
+        assert want["graupel"].max() > 1e-4 and want["snow"].max() > 1e-4 and want["cloud_ice"].max() > 1e-6
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_wsm6_within_tolerance_of_reference_math(oracle, case):
+    got, want, dacc, acc = run(oracle, CASES[case], mode=0)
+    for n in KEYS:
+        parity_record("wsm6", f"{case}/mode0", {n: field_stats(got[n], want[n], 1e-5)})
+        a, b = got[n].astype(np.float64), want[n].astype(np.float64)
+        scale = max(np.abs(b).max(), 1e-30)
+        bad = np.abs(a - b) > 1e-5 * np.maximum(np.abs(b), 1e-3 * scale)
+        # measured (profiles/r02_parity.json, wsm6): <= 1.3e-2 after 10 calls of the mixed-phase case (six classes, every rate
+        # behind a threshold test), <= 8e-3 elsewhere
+        assert bad.mean() <= 2.5e-2, f"{n}: {bad.mean():.2e} of cells beyond rtol 1e-5"
+    for n in acc:
+        rel = abs(dacc[n].sum() - acc[n].sum()) / max(acc[n].sum(), 1e-9)
+        parity_record("wsm6", f"{case}/mode0", {"acc_" + n: {"sum_rel_diff": float(rel), "sum": float(acc[n].sum())}})
+        # rain: 1e-4.  The snow / graupel that reaches the ground in these cases is the small remainder of what melts on the
+        # way down, decided by the scheme's threshold tests: a 1-ulp change of a transcendental moves it by up to ~2e-3
+        assert rel <= (1e-4 if n == "rain" else 5e-3) + 1e-9 / max(acc[n].sum(), 1e-9), (n, rel)
