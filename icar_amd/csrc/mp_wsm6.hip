@@ -270,6 +270,19 @@ __device__ void w6_fall_column(const W6Consts &C, int km, int st, const float *_
     if (MODE == 2) precip[1] = w6_remap(km, st, G, qa2, rql2);
 }
 
+// thread -> cell / column of the tile, flattened with i fastest: full waves whatever the tile's shape (the strips of
+// process_halo are one column wide), coalesced rows for ordinary tiles.  `nrow` = number of j rows of the tile.
+#define W6_CELL_INDEX                                                                                   \
+    const int w_ = i1 - i0 + 1;                                                                         \
+    const long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;                               \
+    if (t_ >= (long long)w_ * km * nrow) return;                                                        \
+    const int i = i0 + (int)(t_ % w_), k = k0 + (int)((t_ / w_) % km), j = j0 + (int)(t_ / ((long long)w_ * km));
+#define W6_COLUMN_INDEX                                                                                 \
+    const int w_ = i1 - i0 + 1;                                                                         \
+    const long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;                               \
+    if (t_ >= (long long)w_ * nrow) return;                                                             \
+    const int i = i0 + (int)(t_ % w_), j = j0 + (int)(t_ / w_);
+
 // ---------------- work fields ----------------
 struct W6Work {
     float *t, *cpm, *xl, *denfac, *qs1, *qs2, *rh1, *rh2, *xni, *workr, *worka, *dq1, *dq2, *dq3, *vti, *dqi, *frz;   // (nx, nz, ny)
@@ -289,10 +302,9 @@ template <bool FIRST>
 __global__ void __launch_bounds__(256)
 k_w6_prep(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ q,
           float *__restrict__ qc, float *__restrict__ qi, float *__restrict__ qr, float *__restrict__ qs, float *__restrict__ qg,
-          const float *__restrict__ den, const float *__restrict__ p, int i0, int i1, int j0, int k0, int km)
+          const float *__restrict__ den, const float *__restrict__ p, int i0, int i1, int j0, int k0, int km, int nrow)
 {
-    const int i = i0 + blockIdx.x * 64 + threadIdx.x, k = k0 + blockIdx.y * 4 + threadIdx.y, j = j0 + blockIdx.z;
-    if (i > i1 || k - k0 >= km) return;
+    W6_CELL_INDEX
     const int c = d.idx(i, k, j);
     float t, qr_ = qr[c], qs_ = qs[c], qg_ = qg[c], qi_ = qi[c];
     const float q_ = q[c], dn = den[c], pp = p[c];
@@ -322,16 +334,15 @@ k_w6_prep(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ th, 
     W.dq1[c] = dn * qr_; W.dq2[c] = dn * qs_; W.dq3[c] = dn * qg_;
 }
 
-// per column: blockIdx.z = 0 rain, 1 snow + graupel
+// per column: blockIdx.y = 0 rain, 1 snow + graupel
 __global__ void __launch_bounds__(64)
-k_w6_fall(Dims d, W6Consts C, W6Work W, const float *__restrict__ den, const float *__restrict__ delz, float dtcld, int i0, int i1, int j0, int k0, int km)
+k_w6_fall(Dims d, W6Consts C, W6Work W, const float *__restrict__ den, const float *__restrict__ delz, float dtcld, int i0, int i1, int j0, int k0, int km, int nrow)
 {
-    const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y;
-    if (i > i1) return;
+    W6_COLUMN_INDEX
     const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
     const size_t n2 = (size_t)d.nx * d.ny;
     float pr[2];
-    if (blockIdx.z == 0) {
+    if (blockIdx.y == 0) {
         w6_fall_column<0>(C, km, d.sk, den + c0, W.denfac + c0, W.t + c0, delz + c0, W.workr + c0, W.dq1 + c0, nullptr, dtcld, pr);
         W.delq[c2] = pr[0];
     } else {
@@ -343,10 +354,9 @@ k_w6_fall(Dims d, W6Consts C, W6Work W, const float *__restrict__ den, const flo
 // per cell, between the falls
 __global__ void __launch_bounds__(256)
 k_w6_melt(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ qi, float *__restrict__ qr, float *__restrict__ qs, float *__restrict__ qg,
-          const float *__restrict__ den, const float *__restrict__ p, float dtcld, int i0, int i1, int j0, int k0, int km)
+          const float *__restrict__ den, const float *__restrict__ p, float dtcld, int i0, int i1, int j0, int k0, int km, int nrow)
 {
-    const int i = i0 + blockIdx.x * 64 + threadIdx.x, k = k0 + blockIdx.y * 4 + threadIdx.y, j = j0 + blockIdx.z;
-    if (i > i1 || k - k0 >= km) return;
+    W6_CELL_INDEX
     const int c = d.idx(i, k, j);
     const float dn = den[c], pp = p[c], denfac = W.denfac[c], cpm = W.cpm[c];
     float t = W.t[c];
@@ -390,10 +400,9 @@ k_w6_melt(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ qi, 
 // per column: the fall of cloud ice and the surface sums of this minor loop (:659-697)
 __global__ void __launch_bounds__(64)
 k_w6_icefall(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ den, const float *__restrict__ delz, float dtcld,
-             int i0, int i1, int j0, int k0, int km)
+             int i0, int i1, int j0, int k0, int km, int nrow)
 {
-    const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y;
-    if (i > i1) return;
+    W6_COLUMN_INDEX
     const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
     const size_t n2 = (size_t)d.nx * d.ny;
     float pr[2];
@@ -414,10 +423,9 @@ template <bool LAST>
 __global__ void __launch_bounds__(256)
 k_w6_rates(Dims d, W6Consts C, W6Args A, W6Work W, float *__restrict__ th, const float *__restrict__ pii, float *__restrict__ q,
            float *__restrict__ qc, float *__restrict__ qi, float *__restrict__ qr, float *__restrict__ qs, float *__restrict__ qg,
-           const float *__restrict__ den, const float *__restrict__ p, float dtcld, int i0, int i1, int j0, int k0, int km)
+           const float *__restrict__ den, const float *__restrict__ p, float dtcld, int i0, int i1, int j0, int k0, int km, int nrow)
 {
-    const int i = i0 + blockIdx.x * 64 + threadIdx.x, k = k0 + blockIdx.y * 4 + threadIdx.y, j = j0 + blockIdx.z;
-    if (i > i1 || k - k0 >= km) return;
+    W6_CELL_INDEX
     const int c = d.idx(i, k, j);
     const float dn = den[c], pp = p[c], denfac = W.denfac[c], cpm = W.cpm[c], xl = W.xl[c], qs1 = W.qs1[c], qs2 = W.qs2[c], rh1 = W.rh1[c], rh2 = W.rh2[c];
     const float t0c = A.t0c, qmin = A.qmin, xls = A.xls, pi = C.pi, denr = A.denr;
@@ -658,10 +666,9 @@ k_w6_rates(Dims d, W6Consts C, W6Args A, W6Work W, float *__restrict__ th, const
 
 // mp_driver.f90:587-595: REAL(8) accumulators += this call's REAL(4) precipitation / snowfall / graupel
 __global__ void k_w6_accumulate(Dims d, W6Work W, double *__restrict__ precip_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
-                                int i0, int i1, int j0)
+                                int i0, int i1, int j0, int nrow)
 {
-    const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y;
-    if (i > i1) return;
+    W6_COLUMN_INDEX
     const int c2 = i + d.nx * j;
     precip_acc[c2] = precip_acc[c2] + W.rain[c2];
     snow_acc[c2] = snow_acc[c2] + W.snow[c2];
@@ -774,18 +781,19 @@ int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     HIPCHK(hipMemsetAsync(W.rain, 0, n2 * sizeof(float), c->stream));          // process_subdomain: precipitation = 0, snowfall = 0, graupel = 0
     HIPCHK(hipMemsetAsync(W.snow, 0, n2 * sizeof(float), c->stream));
     HIPCHK(hipMemsetAsync(W.graupel, 0, n2 * sizeof(float), c->stream));
-    const int i0 = its - c->ims, i1 = ite - c->ims, j0 = jts - c->jms, k0 = kts - c->kms, nxb = (ite - its + 1 + 63) / 64, nyt = jte - jts + 1;
-    const dim3 gc(nxb, (km + 3) / 4, nyt), bc(64, 4), g2(nxb, nyt), b2(64);
+    const int i0 = its - c->ims, i1 = ite - c->ims, j0 = jts - c->jms, k0 = kts - c->kms, nyt = jte - jts + 1;
+    const long long ncol = (long long)(ite - its + 1) * nyt, ncell = ncol * km;
+    const dim3 gc((unsigned)((ncell + 255) / 256)), bc(256), g2((unsigned)((ncol + 63) / 64)), b2(64);
     for (int loop = 1; loop <= loops; ++loop) {
-        if (loop == 1) hipLaunchKernelGGL((k_w6_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km);
-        else           hipLaunchKernelGGL((k_w6_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km);
-        hipLaunchKernelGGL(k_w6_fall, dim3(nxb, nyt, 2), b2, 0, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km);
-        hipLaunchKernelGGL(k_w6_melt, gc, bc, 0, c->stream, c->d, S->c, A, W, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km);
-        hipLaunchKernelGGL(k_w6_icefall, g2, b2, 0, c->stream, c->d, S->c, A, W, den, dz, dtcld, i0, i1, j0, k0, km);
-        if (loop == loops) hipLaunchKernelGGL((k_w6_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km);
-        else               hipLaunchKernelGGL((k_w6_rates<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km);
+        if (loop == 1) hipLaunchKernelGGL((k_w6_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
+        else           hipLaunchKernelGGL((k_w6_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
+        hipLaunchKernelGGL(k_w6_fall, dim3(g2.x, 2), b2, 0, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
+        hipLaunchKernelGGL(k_w6_melt, gc, bc, 0, c->stream, c->d, S->c, A, W, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
+        hipLaunchKernelGGL(k_w6_icefall, g2, b2, 0, c->stream, c->d, S->c, A, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
+        if (loop == loops) hipLaunchKernelGGL((k_w6_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
+        else               hipLaunchKernelGGL((k_w6_rates<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
     }
-    hipLaunchKernelGGL(k_w6_accumulate, g2, b2, 0, c->stream, c->d, W, pa, sa, ga, i0, i1, j0);
+    hipLaunchKernelGGL(k_w6_accumulate, g2, b2, 0, c->stream, c->d, W, pa, sa, ga, i0, i1, j0, nyt);
     HIPCHK(hipGetLastError());
     return 0;
 }
