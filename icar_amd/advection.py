@@ -23,14 +23,30 @@ def advected_field_ids(options):
     return [KVARS[n][0] for n in ADVECTION_ORDER if options.vars_to_advect.get(n, 0) > 0]
 
 
+def setup_winds(domain, options, dt):
+    """setup_module_winds (advect.f90:306-351 / adv_mpdata.f90:496-506): U_m, V_m, W_m (, W_m/dz) of this step's dt."""
+    scheme = options.physics.advection
+    dens = int(bool(options.parameters.advect_density))
+    check(lib().icar_hip_setup_winds(domain.ctx, scheme, ctypes.c_float(dt), ctypes.c_float(domain.dx), dens),
+          "icar_hip_setup_winds")
+    domain._winds_prepared = (scheme, float(dt), dens)
+
+
+def _winds_prepared(domain, scheme, dt, dens):
+    # set by time_step.mp_and_halo, which launches setup_winds beside the interior microphysics; the C side refuses to advect
+    # with Courant winds that anything has invalidated since (ctx.winds_valid), so a stale claim cannot go unnoticed
+    return getattr(domain, "_winds_prepared", None) == (scheme, float(dt), dens)
+
+
 def advect(domain, options, dt):
     """advection_driver.f90:51-77: advect every scalar with vars_to_advect>0 over one step dt."""
     scheme = options.physics.advection
     if scheme not in (kADV_UPWIND, kADV_MPDATA):
         return
     dens = int(bool(options.parameters.advect_density))
-    check(lib().icar_hip_setup_winds(domain.ctx, scheme, ctypes.c_float(dt), ctypes.c_float(domain.dx), dens),
-          "icar_hip_setup_winds")
+    if not _winds_prepared(domain, scheme, dt, dens):
+        setup_winds(domain, options, dt)
+    domain._winds_prepared = None
     ids = advected_field_ids(options)
     arr = (ctypes.c_int * len(ids))(*ids)
     check(lib().icar_hip_advect(domain.ctx, scheme, int(options.adv_options.mpdata_order),

@@ -75,14 +75,15 @@ def update_dt(domain, options, group=None, device=None):
     return min(seconds, 120.0)
 
 
-def mp_and_halo(domain, options, dt, overlap=True):
+def mp_and_halo(domain, options, dt, overlap=True, prepare_advection=True):
     """time_step.f90:512-526: mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve.
 
     The strips, the pack kernels and the exchange stay on the context's main stream; the interior launch runs beside them
     on the context's second stream -- a one-cell-wide strip launch cannot fill 256 CUs, and the interior
     does not have to wait for it (disjoint columns).  An image without neighbours runs exactly the same launches (its
-    halo_send / halo_retrieve have nobody to talk to), so 1-image and N-image timings compare like with like."""
-    from .constants import kMP_THOMPSON, kMP_SB04
+    halo_send / halo_retrieve have nobody to talk to), so 1-image and N-image timings compare like with like.
+    prepare_advection: also launch the wind setup of the advect() that follows, on the main stream beside the interior."""
+    from .constants import kMP_THOMPSON, kMP_SB04, kADV_UPWIND, kADV_MPDATA
     overlap = overlap and options.physics.microphysics in (kMP_THOMPSON, kMP_SB04)   # WSM3 re-zeroes whole-tile scratch per call
     if overlap:
         domain.aux_fork()
@@ -94,6 +95,11 @@ def mp_and_halo(domain, options, dt, overlap=True):
             mp(domain, options, dt, subset=1)                  # :523
         finally:
             domain.aux_end()
+        if prepare_advection and options.physics.advection in (kADV_UPWIND, kADV_MPDATA):
+            # the Courant winds of the advect() that follows (setup_module_winds) read u, v, w, density and the jacobians, none
+            # of which the microphysics touches: a streaming kernel on the main stream beside the VALU-bound interior launch
+            from .advection import setup_winds
+            setup_winds(domain, options, dt)
         domain.aux_join()
     else:
         mp(domain, options, dt, subset=1)

@@ -48,10 +48,16 @@ def test_mp_and_halo_orders_strips_exchange_interior(monkeypatch):
     from icar_amd.options import options_t
     from icar_amd.constants import kMP_THOMPSON, kMP_WSM3
     calls = []
+    from icar_amd import advection
     monkeypatch.setattr(time_step, "mp", lambda d, o, dt, halo=None, subset=None: d.log.append("mp_halo" if halo else "mp_subset"))
+    monkeypatch.setattr(advection, "setup_winds", lambda d, o, dt: d.log.append("setup_winds"))
     opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
     d = _FakeDomain()
     time_step.mp_and_halo(d, opt, 10.0)
+    # the wind setup of the following advect() goes out on the main stream while the interior runs on the second one
+    assert d.log == ["aux_fork", "mp_halo", "halo_send", "aux_begin", "mp_subset", "aux_end", "setup_winds", "aux_join", "halo_retrieve"]
+    d = _FakeDomain()
+    time_step.mp_and_halo(d, opt, 10.0, prepare_advection=False)
     assert d.log == ["aux_fork", "mp_halo", "halo_send", "aux_begin", "mp_subset", "aux_end", "aux_join", "halo_retrieve"]
     opt.physics.microphysics = kMP_WSM3                     # WSM3 zeroes whole-tile scratch per call: stays on one stream
     d = _FakeDomain()
