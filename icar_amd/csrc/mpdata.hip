@@ -182,8 +182,23 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     // (the bulk of a chunk): the stage conditions and the first/last-row forms of the y limiter are compiled out, and
     // with them the zero-initialisations and merge copies of ~70 values per step.  The generic form runs the warm-up
     // steps of a chunk, its last steps and the chunks that touch row 0 / ny-1.
+    // Level flags.  "Is slot h the ground / the top of the column" is wave-uniform and loop-invariant; written as k-comparisons
+    // per slot the compiler keeps every one of them as a 64-bit select mask in SGPRs (~50 pairs, half of them spilled to
+    // VGPR lanes and read back with v_readlane every step).  Most of them are not needed at all:
+    //   * the halo slots are CLAMPED loads, so the slot above the top level holds the top level's own values and the slot
+    //     below level 0 those of level 0: upw(q(top), q(top+1), W) IS q(top) W (adv_mpdata.f90:96), and the z limiter's
+    //     first-cell form (extrema without the cell below, no flux through the ground) falls out of the general one because
+    //     max(q2(0), l(0)) is the cell's own extremum and the ground flux is +-0;
+    //   * what is left -- zero pseudo-velocity through the ground and the top face, no z cross terms in the lowest and highest
+    //     level, the last-cell form of the z limiter, the store range -- is decided from four scalars per step (ground, slot of the
+    //     top level, first / last stored slot), made opaque below so that the comparisons are redone by the scalar unit inside the
+    //     step instead of living in SGPR pairs across it.
+    const int htop_u = __builtin_amdgcn_readfirstlane(nz - k0), gnd_u = __builtin_amdgcn_readfirstlane((k0 == 0) ? 1 : 0),    // slot h = level k0-1+h
+              kst0_u = __builtin_amdgcn_readfirstlane(ka - k0), kst1_u = __builtin_amdgcn_readfirstlane(kb - k0);
     auto step = [&](auto steady_tag, const int P) {
         constexpr bool STEADY = decltype(steady_tag)::value;
+        int htop = htop_u, gnd = gnd_u, kst0 = kst0_u, kst1 = kst1_u;
+        asm volatile("" : "+s"(htop), "+s"(gnd), "+s"(kst0), "+s"(kst1));
         const int N = P + 1;
         const int pP = CLAMPJ(P), pN = CLAMPJ(N), pNN = CLAMPJ(N + 1);
         const int par = (P - P0) & 1;
@@ -208,11 +223,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 float FzT[KB + 1];                                 // flux through the face ABOVE level k0-1+h
 #pragma unroll
                 for (int h = 0; h <= KB; ++h) {
-                    const int k = k0 - 1 + h;
                     const float Wc = WN[h];
-                    float f = upw(qN[h], qN[h + 1], Wc);
-                    if (k >= nz - 1) f = qN[h] * Wc;              // top of the column: q*W (adv_mpdata.f90:96)
-                    if (k < 0) f = 0.f;                           // the ground
+                    float f = upw(qN[h], qN[h + 1], Wc);          // at the top of the column q(h+1) == q(h): q*W (adv_mpdata.f90:96)
+                    if (h == 0 && gnd) f = 0.f;                   // the ground
                     FzT[h] = f;
                 }
 #pragma unroll
@@ -276,8 +289,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         if (STEADY || (P >= 0 && haveN)) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
-                const int h = kk + 1, k = k0 + kk;
-                const bool kin = (k > 0) && (k < nz - 1);
+                const int h = kk + 1;
+                const bool kin = !((kk == 0 && gnd) || (h >= htop));          // not the lowest / highest level
                 const float Vc = VN[h];
                 const float rG = frcp(GN[kk] + GP[h]);
                 const float Us = UP[h] + UN[kk];
@@ -312,8 +325,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             float Fx[KB], u2[KB];
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
-                const int h = kk + 1, k = k0 + kk;
-                const bool kin = (k > 0) && (k < nz - 1);
+                const int h = kk + 1;
+                const bool kin = !((kk == 0 && gnd) || (h >= htop));
                 const float Uc = UP[h];
                 const float rG = frcp(GP[h] + dpp_l(GP[h]));
                 const float evv = Vsum[h] + dpp_l(Vsum[h]);
@@ -335,7 +348,6 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             float Fz[KB + 1], w2[KB + 1];
 #pragma unroll
             for (int hf = 0; hf <= KB; ++hf) {
-                const int k = k0 - 1 + hf;
                 const float Wc = WzP[hf];
                 const float rG = frcp(GP[hf] + GP[hf + 1]);
                 const float Uk = UP[hf] + UP[hf + 1];
@@ -347,7 +359,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                         - cwu * (DxA[hf] + DxA[hf + 1]) * frcp(SxA[hf] + SxA[hf + 1] + EPSQ)
                         - cwv * (Dy[hf] + Dy[hf + 1]) * frcp(Sy[hf] + Sy[hf + 1] + EPSQ);
                 t = t * dzP[hf];
-                if (k < 0 || k >= nz - 1) t = 0.0f;              // no face below the ground; w2(top) = 0 (adv_mpdata.f90:214)
+                if ((hf == 0 && gnd) || hf >= htop) t = 0.0f;    // no face below the ground; w2(top) = 0 (adv_mpdata.f90:214)
                 w2[hf] = t; Fz[hf] = upw(q2P[hf], q2P[hf + 1], t);
             }
             // ---- limiter, x direction
@@ -376,14 +388,14 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 float bZin[H], bZout[H];
 #pragma unroll
                 for (int kk = 0; kk < KB; ++kk) {
-                    const int h = kk + 1, k = k0 + kk;
+                    const int h = kk + 1;
                     const float qc = q2P[h], FzB = Fz[h - 1], FzT = Fz[h];
                     const float mlo = (kk > 0) ? mP[kk - 1] : fmaxf(q2P[0], qPh0), nlo = (kk > 0) ? nP[kk - 1] : fminf(q2P[0], qPh0);
                     const float mhi = (kk < KB - 1) ? mP[kk + 1] : fmaxf(q2P[H - 1], qPh1), nhi = (kk < KB - 1) ? nP[kk + 1] : fminf(q2P[H - 1], qPh1);
                     float qmax = max3f(mlo, mP[kk], mhi), qmin = min3f(nlo, nP[kk], nhi);
                     float fin = fmaxf(0.f, FzB) - fminf(0.f, FzT), fout = fmaxf(0.f, FzT) - fminf(0.f, FzB);
-                    if (k == 0) { qmax = fmaxf(mP[kk], mhi); qmin = fminf(nP[kk], nhi); fin = 0.f - fminf(0.f, FzT); fout = fmaxf(0.f, FzT); }
-                    if (k >= nz - 1) { qmax = fmaxf(mlo, qc); qmin = fminf(nlo, qc); fin = fmaxf(0.f, FzB) - fminf(0.f, FzB); fout = fin; }
+                    // (level 0: mlo / nlo are the cell's own extrema and FzB = +-0, which is the reference's first-cell form)
+                    if (h >= htop) { qmax = fmaxf(mlo, qc); qmin = fminf(nlo, qc); fin = fmaxf(0.f, FzB) - fminf(0.f, FzB); fout = fin; }
                     bZin[h] = (qmax - qc) * frcp(fin + EPSF); bZout[h] = (qc - qmin) * frcp(fout + EPSF);
                 }
                 s_bz[par][wv][0][lane] = bZin[1]; s_bz[par][wv][1][lane] = bZout[1]; s_bz[par][wv][2][lane] = bZin[KB]; s_bz[par][wv][3][lane] = bZout[KB];
@@ -445,19 +457,19 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const float v = xring ? q2M[kk + 1] : acc[kk] - FyLimS[kk] * rdhM[kk];
-                if ((lane_out || (xring && lane < 64)) && (k0 + kk >= ka && k0 + kk <= kb)) stb(out + (size_t)M * sj + kc[kk + 1], bx, v);
+                if ((lane_out || (xring && lane < 64)) && (kk >= kst0 && kk <= kst1)) stb(out + (size_t)M * sj + kc[kk + 1], bx, v);
             }
         }
         // the boundary rows of the new field are the old ones (adv_mpdata.f90:63-65)
         if (!STEADY && M == 0 && ja == 1) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (k0 + kk >= ka && k0 + kk <= kb)) stb(out + kc[kk + 1], bx, q2M[kk + 1]);
+                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out + kc[kk + 1], bx, q2M[kk + 1]);
         }
         if (!STEADY && P == ny - 1 && jb == ny - 2) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (k0 + kk >= ka && k0 + kk <= kb)) stb(out + (size_t)(ny - 1) * sj + kc[kk + 1], bx, q2P[kk + 1]);
+                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out + (size_t)(ny - 1) * sj + kc[kk + 1], bx, q2P[kk + 1]);
         }
         // ---- roll the window
 #pragma unroll
