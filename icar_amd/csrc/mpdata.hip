@@ -55,8 +55,13 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float upw(float l, float r, float U) { return U * (U > 0.0f ? l : r); }      // == flux1 (adv_mpdata.f90:40)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
-__device__ __forceinline__ float ldb(const float *__restrict__ p, unsigned b) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + b); }
-__device__ __forceinline__ void stb(float *__restrict__ p, unsigned b, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(p) + b) = v; }
+// Global accesses are raw buffer loads / stores: descriptor (4 SGPRs per array) + per-lane byte offset (one VGPR, the
+// column) + scalar byte offset (plane and level, wave-uniform).  With flat addressing every one of the ~80 loads of a step
+// paid a 64-bit VALU add for its address (v_lshl_add_u64).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t mkrsrc(const float *p) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, -1, 0x00020000); }
+__device__ __forceinline__ float ldb(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ void stb(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0); }
 
 // KB levels per thread (at most MP_NW waves per block), RHO: advect_density, FCT: limiter on,
 // PASS1: first corrective iteration (donor-cell pass inside); false: iord >= 3, where q2 == q (adv_mpdata.f90:393-402)
@@ -82,7 +87,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y), nw = blockDim.y;
     const int tid = lane + 64 * wv;
     const int nx = d.nx, nz = d.nz, ny = d.ny;
-    const size_t sj = (size_t)d.sj;
+    const int sj4 = 4 * d.sj;                       // bytes per plane (the host checks that a field is < 2 GiB)
     // work item.  Items are ordered group-major (group = (tile, chunk), then the scalars of that group) and dealt to the 8
     // XCDs in contiguous runs of `cap` items; consecutive block ids go to the XCDs round-robin, so block id = xcd + 8 * slot.
     // The scalars of a group therefore share an XCD (at most two groups per XCD are split) and start together: the
@@ -101,25 +106,27 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     // levels [ka, kb] and computes MP_ZH more on either side (whatever a fake edge corrupts stays inside those halo levels);
     // the flags of the real bottom / top are those of the global level index, so a range edge is not a boundary.
     const int ka = kr * kstore, kb = min(ka + kstore - 1, nz - 1), kbase = max(ka - MP_ZH, 0);
-    const float *__restrict__ q = qin.p[0];
-    float *__restrict__ out = qout.p[0];
+    const float *__restrict__ qp = qin.p[0];
+    float *__restrict__ outp = qout.p[0];
 #pragma unroll
-    for (int mm = 1; mm < ICAR_MAX_ADV; ++mm) if (mm == m) { q = qin.p[mm]; out = qout.p[mm]; }   // (a dynamic index would put the tables in scratch)
+    for (int mm = 1; mm < ICAR_MAX_ADV; ++mm) if (mm == m) { qp = qin.p[mm]; outp = qout.p[mm]; }   // (a dynamic index would put the tables in scratch)
+    const rsrc_t q = mkrsrc(qp), out = mkrsrc(outp), Ur = mkrsrc(Ug), Vr = mkrsrc(Vg), Wr = mkrsrc(Wg), Wzr = mkrsrc(Wzg),
+                 rhor = mkrsrc(rho), jacor = mkrsrc(jaco), dzr = mkrsrc(dzg);
 
     const int i = 1 - MP_HL + tile * MP_XOUT + lane;
     const int ic = min(max(i, 0), nx - 1);
     const bool xlo = (i == 0), xhi = (i == nx - 1), xin = (i > 0) && (i < nx - 1);
     const bool xring = xlo || xhi;
     const bool lane_out = (lane >= MP_HL) && (lane < 64 - MP_HL) && xin;
-    const unsigned bx = 4u * (unsigned)ic;
+    const int bx = 4 * ic;
     const int ja = 1 + chunk * clen, jb = min(ja + clen - 1, ny - 2);
     const int k0 = kbase + wv * KB;
     // level of slot h (0..H-1) = k0-1+h, clamped for addressing; flags are wave-uniform
     int kc[H];
 #pragma unroll
-    for (int h = 0; h < H; ++h) kc[h] = min(max(k0 - 1 + h, 0), nz - 1) * nx;
+    for (int h = 0; h < H; ++h) kc[h] = min(max(k0 - 1 + h, 0), nz - 1) * nx * 4;       // byte offset of the level
 
-#define LDP(arr, h, plane) ldb((arr) + (size_t)(plane) * sj + kc[h], bx)
+#define LDP(arr, h, plane) ldb(arr, bx, (plane) * sj4 + kc[h])
 #define CLAMPJ(p) min(max((p), 0), ny - 1)
 
     // ---- rolling state (planes relative to the step's in-plane index P; N = P+1, M = P-1) ----
@@ -157,18 +164,18 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #define ISSUE_LOADS_A(PP)                                                                                                \
     {                                                                                                                    \
         const int lN = CLAMPJ((PP) + 1), lNN = CLAMPJ((PP) + 2);                                                         \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) GN[kk] = LDP(jaco, kk + 1, lN);                                \
-        _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = LDP(Wg, h, lN);                                          \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = LDP(Ug, kk + 1, lN); VNN[kk] = LDP(Vg, kk + 1, lNN); dzN[kk] = LDP(dzg, kk + 1, lN); } \
-        _Pragma("unroll") for (int h = 0; h < H; ++h) VN[h] = LDP(Vg, h, lN);                                            \
-        if (RHO) { _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) rN[kk] = LDP(rho, kk + 1, lN); }                    \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) GN[kk] = LDP(jacor, kk + 1, lN);                                \
+        _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = LDP(Wr, h, lN);                                          \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = LDP(Ur, kk + 1, lN); VNN[kk] = LDP(Vr, kk + 1, lNN); dzN[kk] = LDP(dzr, kk + 1, lN); } \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) VN[h] = LDP(Vr, h, lN);                                            \
+        if (RHO) { _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) rN[kk] = LDP(rhor, kk + 1, lN); }                    \
     }
 #define ISSUE_LOADS_B(PP)                                                                                                \
     {                                                                                                                    \
         const int lP = CLAMPJ(PP), lN = CLAMPJ((PP) + 1);                                                                \
-        _Pragma("unroll") for (int h = 0; h < H; ++h) { GP[h] = LDP(jaco, h, lP); VP[h] = LDP(Vg, h, lP); UP[h] = LDP(Ug, h, lP); } \
-        if (RHO) { _Pragma("unroll") for (int h = 0; h < H; ++h) rP[h] = LDP(rho, h, lP); }                              \
-        _Pragma("unroll") for (int h = 0; h <= KB; ++h) { WzP[h] = LDP(Wzg, h, lP); WzN[h] = LDP(Wzg, h, lN); dzP[h] = LDP(dzg, h, lP); } \
+        _Pragma("unroll") for (int h = 0; h < H; ++h) { GP[h] = LDP(jacor, h, lP); VP[h] = LDP(Vr, h, lP); UP[h] = LDP(Ur, h, lP); } \
+        if (RHO) { _Pragma("unroll") for (int h = 0; h < H; ++h) rP[h] = LDP(rhor, h, lP); }                              \
+        _Pragma("unroll") for (int h = 0; h <= KB; ++h) { WzP[h] = LDP(Wzr, h, lP); WzN[h] = LDP(Wzr, h, lN); dzP[h] = LDP(dzr, h, lP); } \
     }
 // the scalar itself: every plane of it comes from HBM exactly once, so its latency is the longest of all inputs
 #define ISSUE_LOADS_Q(DST, PLANE)                                                                                        \
@@ -457,19 +464,19 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const float v = xring ? q2M[kk + 1] : acc[kk] - FyLimS[kk] * rdhM[kk];
-                if ((lane_out || (xring && lane < 64)) && (kk >= kst0 && kk <= kst1)) stb(out + (size_t)M * sj + kc[kk + 1], bx, v);
+                if ((lane_out || (xring && lane < 64)) && (kk >= kst0 && kk <= kst1)) stb(out, bx, M * sj4 + kc[kk + 1], v);
             }
         }
         // the boundary rows of the new field are the old ones (adv_mpdata.f90:63-65)
         if (!STEADY && M == 0 && ja == 1) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out + kc[kk + 1], bx, q2M[kk + 1]);
+                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out, bx, kc[kk + 1], q2M[kk + 1]);
         }
         if (!STEADY && P == ny - 1 && jb == ny - 2) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out + (size_t)(ny - 1) * sj + kc[kk + 1], bx, q2P[kk + 1]);
+                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out, bx, (ny - 1) * sj4 + kc[kk + 1], q2P[kk + 1]);
         }
         // ---- roll the window
 #pragma unroll
@@ -529,6 +536,7 @@ int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, co
 {
     const int nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
     if (nx < 3 || ny < 3) { icar_set_error("mpdata: tile must be at least 3 x 3 cells"); return 1; }
+    if ((size_t)nx * nz * ny * sizeof(float) >= ((size_t)1 << 31)) { icar_set_error("mpdata: a field of 2 GiB or more is not supported (32-bit buffer offsets)"); return 1; }
     const int ntile = std::max(1, (nx - 2 + MP_XOUT - 1) / MP_XOUT);
     // levels: one block holds at most MP_NW x MP_KB = 40; taller columns are cut into level ranges with MP_ZH halo levels
     const int cap_lv = MP_NW * MP_KB;
