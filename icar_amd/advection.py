@@ -33,9 +33,9 @@ def setup_winds(domain, options, dt):
 
 
 def _winds_prepared(domain, scheme, dt, dens):
-    # set by time_step.mp_and_halo, which launches setup_winds beside the interior microphysics; the C side refuses to advect
-    # with Courant winds that anything has invalidated since (ctx.winds_valid), so a stale claim cannot go unnoticed
-    return getattr(domain, "_winds_prepared", None) == (scheme, float(dt), dens)
+    # set by time_step.mp_and_halo, which launches setup_winds beside the interior microphysics; anything that rewrote u, v, w,
+    # density or a jacobian since has cleared the context's flag, and the setup is then simply redone
+    return getattr(domain, "_winds_prepared", None) == (scheme, float(dt), dens) and bool(lib().icar_hip_winds_valid(domain.ctx))
 
 
 def advect(domain, options, dt):

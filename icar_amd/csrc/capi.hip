@@ -603,6 +603,8 @@ int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
     return icar_enforce_limits_run(c, fields, n);
 }
 
+int icar_hip_winds_valid(icar_hip_ctx *c) { return (c && c->winds_valid) ? 1 : 0; }
+
 int icar_hip_wsm6_init(icar_hip_ctx *c)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }

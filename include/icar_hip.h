@@ -135,6 +135,10 @@ int icar_hip_setup_winds(icar_hip_ctx *ctx, int scheme, float dt, float dx, int 
  * use 1-ulp reciprocals and agree with it to 1e-5 of the local field scale (tests/test_gpu_advect.py). */
 int icar_hip_advect(icar_hip_ctx *ctx, int scheme, int mpdata_order, int fct, int advect_density,
                     const int *fields, int nfields);
+/* 1 while the Courant winds of the last icar_hip_setup_winds still belong to the state (nothing has rewritten u, v, w, density
+ * or a jacobian since), else 0: a host that launches the setup early -- beside the interior microphysics, see INTEGRATION.md --
+ * asks before it skips the setup in advect(). */
+int icar_hip_winds_valid(icar_hip_ctx *ctx);
 
 /* ---- M1: mp_simple_driver (src/physics/mp_simple.f90:595-646) on the tile its..kte -----------
  * uses PRESSURE, POTENTIAL_TEMPERATURE, EXNER, DENSITY, WATER_VAPOR, CLOUD_WATER, RAIN, SNOW,
