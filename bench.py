@@ -74,16 +74,14 @@ FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), 
 
 
 def one_step(d, opt, group=None, device=None, cool=0.0):
-    from icar_amd.time_step import update_dt, mp_and_halo
-    from icar_amd.advection import advect
+    from icar_amd.time_step import update_dt, substep
     dt = update_dt(d, opt, group=group, device=device)
-    d.diagnostic_update()
-    # mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve at EVERY world size: the strips + pack on the main stream,
-    # the interior on the second stream.  With one image the edges wrap around to the tile itself (HaloComm loopback:
-    # same pack / unpack kernels, no transport), so the N=1 line times the launches every rank of an N>1 run pays.
-    mp_and_halo(d, opt, dt)
-    advect(d, opt, dt)
-    d.apply_forcing(dt, FORCED)
+    # time_step.substep: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect -> apply_forcing
+    # at EVERY world size: the strips + pack on the main stream, the interior on the second stream (with the wind setup and the
+    # w_real diagnostic beside it), the whole-field forcing of u, v, w, p beside the advection.  With one image the edges wrap
+    # around to the tile itself (HaloComm loopback: same pack / unpack kernels, no transport), so the N=1 line times the
+    # launches every rank of an N>1 run pays.
+    substep(d, opt, dt, forced=FORCED)
     d.model_time_seconds += dt
     return dt
 

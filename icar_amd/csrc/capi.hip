@@ -574,7 +574,15 @@ int icar_hip_diagnostic_update(icar_hip_ctx *c)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
     HIPCHK(hipSetDevice(c->device));
-    return icar_diagnostic_update_run(c);
+    return icar_diagnostic_update_run(c, 3);
+}
+
+int icar_hip_diagnostic_update_parts(icar_hip_ctx *c, int parts)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (parts < 1 || parts > 3) { icar_set_error("diagnostic_update_parts: parts is 1 (thermodynamics), 2 (w_real) or 3"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_diagnostic_update_run(c, parts);
 }
 
 int icar_hip_dqdt_upload(icar_hip_ctx *c, int f, const void *host)

@@ -89,7 +89,7 @@ int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update);
 int icar_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int update);
 int icar_make_winds_grid_relative(icar_hip_ctx *c, int update);
 int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, float *buf, bool unpack);
-int icar_diagnostic_update_run(icar_hip_ctx *c);
+int icar_diagnostic_update_run(icar_hip_ctx *c, int parts);
 int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);
 int icar_enforce_limits_run(icar_hip_ctx *c, const int *fields, int n);
 int icar_thompson_init_run(icar_hip_ctx *c, const float *params, const int *flags);

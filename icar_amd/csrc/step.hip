@@ -175,8 +175,11 @@ k_enforce_limits(size_t n, LimitArgs a)
 }
 }  // namespace
 
-int icar_diagnostic_update_run(icar_hip_ctx *c)
+// parts: 1 = thermodynamics, mass-point winds, column integrals (:60-144) ; 2 = w_real (:165-194) ; 3 = all of diagnostic_update
+int icar_diagnostic_update_run(icar_hip_ctx *c, int parts)
 {
+    const float *u = (const float *)c->field[ICAR_F_U], *v = (const float *)c->field[ICAR_F_V];
+    if (parts & 1) {
     const float *p = icar_field_f(c, ICAR_F_PRESSURE), *th = icar_field_f(c, ICAR_F_POTENTIAL_TEMPERATURE);
     if (!p || !th) return 1;
     c->winds_valid = false;                                       // density is rewritten: Courant winds (advect_density) are stale
@@ -184,7 +187,6 @@ int icar_diagnostic_update_run(icar_hip_ctx *c)
     float *ps = icar_field_f(c, ICAR_F_SURFACE_PRESSURE, false), *T = icar_field_f(c, ICAR_F_TEMPERATURE, false);
     float *Ti = icar_field_f(c, ICAR_F_TEMPERATURE_INTERFACE, false), *rho = icar_field_f(c, ICAR_F_DENSITY, false);
     if (!ex || !pi || !ps || !T || !Ti || !rho) return 1;
-    const float *u = (const float *)c->field[ICAR_F_U], *v = (const float *)c->field[ICAR_F_V];
     float *um = u ? icar_field_f(c, ICAR_F_U_MASS, false) : nullptr, *vm = v ? icar_field_f(c, ICAR_F_V_MASS, false) : nullptr;
     ScopedTimer t(c, "diag");
     dim3 g((c->d.nx + 63) / 64, (c->d.nz + DIAG_BY - 1) / DIAG_BY, c->d.ny), b(64, DIAG_BY);
@@ -201,11 +203,14 @@ int icar_diagnostic_update_run(icar_hip_ctx *c)
         if (ca.ivt && (!um || !vm)) { icar_set_error("diagnostic_update: ivt needs u and v on the device"); return 1; }
         hipLaunchKernelGGL(k_diag_columns, dim3((c->d.nx + 63) / 64, c->d.ny), dim3(64), 0, c->stream, c->d, ca);
     }
+    }
+    if (!(parts & 2)) { HIPCHK(hipGetLastError()); return 0; }
     const float *w = (const float *)c->field[ICAR_F_W], *dzdx = (const float *)c->field[ICAR_F_DZDX];
     const float *dzdy = (const float *)c->field[ICAR_F_DZDY], *jaco = (const float *)c->field[ICAR_F_JACOBIAN];
     if (u && v && w && dzdx && dzdy && jaco) {
         float *wr = icar_field_f(c, ICAR_F_W_REAL, false);
         if (!wr) return 1;
+        ScopedTimer t(c, "diag");
         dim3 g2((c->d.nx - 2 + 63) / 64, c->d.ny - 2), b2(64);
         hipLaunchKernelGGL(k_diag_wreal, g2, b2, 0, c->stream, c->d, u, v, w, dzdx, dzdy, jaco, wr);
     }

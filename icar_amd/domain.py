@@ -108,9 +108,9 @@ class domain_t:
         ids = (ctypes.c_int * len(names))(*[self.fid(n) for n in names])
         check(lib().icar_hip_enforce_limits(self.ctx, ids, len(names)), "enforce_limits")
 
-    def diagnostic_update(self):
-        """diagnostic_update(domain, options) (time_step.f90:49-198)."""
-        check(lib().icar_hip_diagnostic_update(self.ctx), "diagnostic_update")
+    def diagnostic_update(self, parts=3):
+        """diagnostic_update(domain, options) (time_step.f90:49-198).  parts: 1 = all but w_real, 2 = w_real only, 3 = both."""
+        check(lib().icar_hip_diagnostic_update_parts(self.ctx, int(parts)), "diagnostic_update")
 
     def fill(self, name, value):
         check(lib().icar_hip_field_fill(self.ctx, self.fid(name), ctypes.c_double(value)), f"fill {name}")

@@ -14,7 +14,7 @@ module icar_hip
   public :: hip_ctx_t, hip_create, hip_destroy, hip_upload, hip_download, hip_upload_2dd, hip_download_2dd, &
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
-            hip_diagnostic_update, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
+            hip_diagnostic_update, hip_diagnostic_update_parts, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
             hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_winds_valid, &
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
@@ -120,6 +120,9 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_wsm3(ctx, dt, its, ite, jts, jte, kts, kte) bind(C, name="icar_hip_wsm3")
        import; type(c_ptr), value :: ctx; real(c_float), value :: dt; integer(c_int), value :: its, ite, jts, jte, kts, kte
+     end function
+     integer(c_int) function icar_hip_diagnostic_update_parts(ctx, parts) bind(C, name="icar_hip_diagnostic_update_parts")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: parts
      end function
      integer(c_int) function icar_hip_diagnostic_update(ctx) bind(C, name="icar_hip_diagnostic_update")
        import; type(c_ptr), value :: ctx
@@ -377,6 +380,13 @@ contains
     integer, intent(in) :: its, ite, jts, jte, kts, kte
     call check(icar_hip_wsm3(ctx%p, real(dt,c_float), int(its,c_int), int(ite,c_int), int(jts,c_int), int(jte,c_int), &
                              int(kts,c_int), int(kte,c_int)), "wsm3")
+  end subroutine
+
+  !> diagnostic_update in parts: 1 = all but w_real, 2 = w_real only (can run beside the interior microphysics), 3 = both
+  subroutine hip_diagnostic_update_parts(ctx, parts)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: parts
+    call check(icar_hip_diagnostic_update_parts(ctx%p, int(parts,c_int)), "diagnostic_update_parts")
   end subroutine
 
   !> diagnostic_update (time_step.f90:49-198)

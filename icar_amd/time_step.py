@@ -75,14 +75,16 @@ def update_dt(domain, options, group=None, device=None):
     return min(seconds, 120.0)
 
 
-def mp_and_halo(domain, options, dt, overlap=True, prepare_advection=True):
+def mp_and_halo(domain, options, dt, overlap=True, prepare_advection=True, beside_interior=()):
     """time_step.f90:512-526: mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve.
 
     The strips, the pack kernels and the exchange stay on the context's main stream; the interior launch runs beside them
     on the context's second stream -- a one-cell-wide strip launch cannot fill 256 CUs, and the interior
     does not have to wait for it (disjoint columns).  An image without neighbours runs exactly the same launches (its
     halo_send / halo_retrieve have nobody to talk to), so 1-image and N-image timings compare like with like.
-    prepare_advection: also launch the wind setup of the advect() that follows, on the main stream beside the interior."""
+    prepare_advection: also launch the wind setup of the advect() that follows, on the main stream beside the interior.
+    beside_interior: further callables whose launches neither read what the microphysics writes nor write what it reads
+    (the w_real part of diagnostic_update); they go out on the main stream beside the interior too, or right away without overlap."""
     from .constants import kMP_THOMPSON, kMP_SB04, kADV_UPWIND, kADV_MPDATA
     overlap = overlap and options.physics.microphysics in (kMP_THOMPSON, kMP_SB04)   # WSM3 re-zeroes whole-tile scratch per call
     if overlap:
@@ -100,10 +102,57 @@ def mp_and_halo(domain, options, dt, overlap=True, prepare_advection=True):
             # of which the microphysics touches: a streaming kernel on the main stream beside the VALU-bound interior launch
             from .advection import setup_winds
             setup_winds(domain, options, dt)
+        for fn in beside_interior:
+            fn()
         domain.aux_join()
     else:
+        for fn in beside_interior:
+            fn()
         mp(domain, options, dt, subset=1)
     domain.halo_retrieve()                                     # :526
+
+
+# whole-field forcing of these members (domain_obj.f90:2427, :2436: `x += dqdt * dt`) touches nothing the advection reads
+# (it works from the Courant winds of setup_module_winds, the scalars, density and the jacobians)
+_FORCING_BESIDE_ADVECT = ("u", "v", "w", "pressure")
+
+
+def substep(domain, options, dt, forced=None, diagnostics=True, enforce=False):
+    """One pass of time_step.f90:474-539: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve ->
+    advect -> apply_forcing (-> enforce_limits), with the streaming kernels that do not depend on the two heavy ones issued
+    beside them: the w_real diagnostic (read by WSM3 and the output only) beside the interior microphysics, the whole-field
+    forcing of u, v, w, pressure on the second stream beside the advection (which works from the Courant winds set up
+    before).  Same launches, same operands, same results as the plain sequence."""
+    from .constants import ADVECTION_ORDER, kMP_WSM3
+    beside = ()
+    if diagnostics:
+        if options.physics.microphysics != kMP_WSM3:           # WSM3 reads w_real
+            domain.diagnostic_update(parts=1)                  # :474 (exner, density, ... before the microphysics)
+            beside = (lambda: domain.diagnostic_update(parts=2),)
+        else:
+            domain.diagnostic_update()
+    if dt > 1e-3:                                              # :483
+        mp_and_halo(domain, options, dt, beside_interior=beside)   # :512-526
+        aside = [f for f in (forced or []) if not f[1] and f[0] in _FORCING_BESIDE_ADVECT]
+        rest = [f for f in (forced or []) if f not in aside]
+        if aside:
+            domain.aux_fork()                                  # the second stream starts from the state BEFORE the advection
+        advect(domain, options, dt)                            # :529
+        if aside:
+            domain.aux_begin()
+            try:
+                domain.apply_forcing(dt, aside)                # :534, the part that does not wait for the advection
+            finally:
+                domain.aux_end()
+            domain.aux_join()
+        if rest:
+            domain.apply_forcing(dt, rest)                     # :534, boundary relaxation of the advected scalars
+        if enforce:                                            # :537-539
+            names = [n for n in ADVECTION_ORDER if options.vars_to_advect.get(n, 0) > 0]
+            domain.enforce_limits(names)
+    else:
+        for fn in beside:
+            fn()
 
 
 def step(domain, end_time, options, group=None, device=None, forced=None, diagnostics=True):
@@ -111,22 +160,13 @@ def step(domain, end_time, options, group=None, device=None, forced=None, diagno
          update_dt -> diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
          -> advect -> apply_forcing -> enforce_limits (last two sub-steps).
     forced = [(member, force_boundaries), ...] with uploaded dqdt (domain.set_dqdt); None skips apply_forcing."""
-    from .constants import ADVECTION_ORDER
     nsteps = 0
     while domain.model_time_seconds < end_time:
         dt = update_dt(domain, options, group=group, device=device)
         if domain.model_time_seconds + dt > end_time:          # :469-471
             dt = end_time - domain.model_time_seconds
-        if diagnostics:
-            domain.diagnostic_update()                         # :474
-        if dt > 1e-3:                                          # :483
-            mp_and_halo(domain, options, dt)                   # :512-526
-            advect(domain, options, dt)                        # :529
-            if forced:
-                domain.apply_forcing(dt, forced)               # :534
-            if (end_time - domain.model_time_seconds) < dt * 2:    # :537-539
-                names = [n for n in ADVECTION_ORDER if options.vars_to_advect.get(n, 0) > 0]
-                domain.enforce_limits(names)
+        substep(domain, options, dt, forced=forced, diagnostics=diagnostics,
+                enforce=(end_time - domain.model_time_seconds) < dt * 2)
         domain.model_time_seconds += dt                        # :547
         nsteps += 1
     return nsteps

@@ -208,6 +208,10 @@ int icar_hip_max_abs_winds(icar_hip_ctx *ctx, float out[3]);
  * host has uploaded once (= `associated(domain%ivt%data_2d)`); iwl / iwi sum the hydrometeor fields that are on the
  * device, like the reference's `associated` tests.  The 10 m winds need roughness_z0 (LSM) and stay host-side. */
 int icar_hip_diagnostic_update(icar_hip_ctx *ctx);
+/* the same in two parts, for a host that overlaps: parts = 1: everything but w_real (what the microphysics and the advection
+ * read: exner, density ...) ; 2: w_real only (:165-194; read by WSM3 and the output, not by Thompson / mp_simple / WSM6 / advect:
+ * a streaming kernel that can run beside the VALU-bound interior microphysics) ; 3: both = icar_hip_diagnostic_update. */
+int icar_hip_diagnostic_update_parts(icar_hip_ctx *ctx, int parts);
 
 /* ---- F1: apply_forcing / enforce_limits (src/objects/domain_obj.f90:2383-2448, 2228-2243) ----
  * dqdt mirrors variable_t%dqdt_3d.  For each listed field: force_boundaries[i]!=0 -> only the true
