@@ -241,8 +241,26 @@ k_max_courant(Dims d, const float *__restrict__ u, const float *__restrict__ v,
 // out != nullptr: the maximum is copied to the host (one stream synchronisation).  d_out != nullptr: it is left in device
 // memory at d_out (a REAL(4) the caller owns) and nothing waits -- the caller all-reduces it on the device (co_min of
 // time_step.f90:413 as max over images of the Courant sum: dt = factor / max is monotone, so min(dt) == factor / max).
+// A maximum taken ahead of time (icar_hip_max_courant_prefetch, typically on the second stream beside the advection) is
+// handed out instead of a new reduction as long as no entry point has written u, v or w since and the arguments are the same.
+static bool cfl_prefetched(icar_hip_ctx *c, float dx, const float *dz_levels)
+{
+    return c->cfl_pre.valid && !c->wind_ptr_escaped && c->cfl_pre.ver == c->wind_version && c->cfl_pre.dx == dx
+        && (int)c->cfl_pre.dzl.size() == c->d.nz && memcmp(c->cfl_pre.dzl.data(), dz_levels, sizeof(float) * c->d.nz) == 0;
+}
+
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out, float *d_out)
 {
+    if (cfl_prefetched(c, dx, dz_levels)) {
+        c->cfl_pre.valid = false;
+        if (out) { HIPCHK(hipEventSynchronize(c->cfl_ev)); *out = *c->h_cfl_pre; }
+        else {
+            HIPCHK(hipStreamWaitEvent(c->stream, c->cfl_ev, 0));
+            HIPCHK(hipMemcpyAsync(d_out, c->d_red + 8, sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+        return 0;
+    }
+    c->cfl_pre.valid = false;
     const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V), *w = icar_field_f(c, ICAR_F_W);
     if (!u || !v || !w) return 1;
     float *dzl = c->d_red + 16;
@@ -261,6 +279,17 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
         HIPCHK(hipMemcpyAsync(out, red, sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels)
+{
+    c->cfl_pre.valid = false;
+    if (!c->h_cfl_pre) { HIPCHK(hipHostMalloc((void **)&c->h_cfl_pre, sizeof(float), hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&c->cfl_ev, hipEventDisableTiming)); }
+    if (icar_max_courant_run(c, dx, dz_levels, nullptr, c->d_red + 8)) return 1;             // on the current stream, nothing waits
+    HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
+    c->cfl_pre.valid = true; c->cfl_pre.ver = c->wind_version; c->cfl_pre.dx = dx; c->cfl_pre.dzl.assign(dz_levels, dz_levels + c->d.nz);
     return 0;
 }
 
@@ -333,7 +362,7 @@ int icar_balance_uvw_run(icar_hip_ctx *c, float dx, int update)
     dim3 g((c->d.nx + 63) / 64, c->d.ny), b(64);
     hipLaunchKernelGGL(k_balance_uvw, g, b, 0, c->stream, c->d, u, v, w, ju, jv, jw, dz, dx);
     HIPCHK(hipGetLastError());
-    if (!update) c->winds_valid = false;                          // w changed: the Courant winds are stale
+    if (!update) icar_winds_changed(c);                          // w changed: the Courant winds are stale
     return 0;
 }
 
@@ -392,6 +421,8 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     float *scr[] = {c->U, c->V, c->W, c->Wdz, c->d_red};
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
+    if (c->h_cfl_pre) hipHostFree(c->h_cfl_pre);
+    if (c->cfl_ev) hipEventDestroy(c->cfl_ev);
     if (c->iw_adj) hipFree(c->iw_adj);
     if (c->wgr_tmp) hipFree(c->wgr_tmp);
     icar_wsm3_free(c);
@@ -439,7 +470,7 @@ int icar_hip_field_upload(icar_hip_ctx *c, int f, const void *host)
     if (!p) return 1;
     HIPCHK(hipMemcpyAsync(p, host, icar_field_count(c, f) * icar_hip_field_elem_size(f), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W || (f >= ICAR_F_DENSITY && f <= ICAR_F_ADVECTION_DZ)) c->winds_valid = false;
+    if (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W || (f >= ICAR_F_DENSITY && f <= ICAR_F_ADVECTION_DZ)) icar_winds_changed(c);
     return 0;
 }
 
@@ -467,6 +498,7 @@ int icar_hip_field_fill(icar_hip_ctx *c, int f, double value)
     if (field_is_2dd(f)) hipLaunchKernelGGL(k_fill_d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (double *)p, n, value);
     else                 hipLaunchKernelGGL(k_fill_f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p, n, (float)value);
     HIPCHK(hipGetLastError());
+    if (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W || (f >= ICAR_F_DENSITY && f <= ICAR_F_ADVECTION_DZ)) icar_winds_changed(c);
     return 0;
 }
 
@@ -477,6 +509,7 @@ int icar_hip_field_device_ptr(icar_hip_ctx *c, int f, void **dptr)
     float *p = icar_field_f(c, f, false);
     if (!p) return 1;
     *dptr = p;
+    if (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W) { c->wind_ptr_escaped = true; icar_winds_changed(c); }   // the caller may write them behind our back
     return 0;
 }
 
@@ -568,6 +601,14 @@ int icar_hip_max_courant_device(icar_hip_ctx *c, float dx, const float *dz_level
     HIPCHK(hipSetDevice(c->device));
     if (c->d.nz > 4096) { icar_set_error("max_courant_device: nz too large"); return 1; }
     return icar_max_courant_run(c, dx, dz_levels, nullptr, (float *)d_out);
+}
+
+int icar_hip_max_courant_prefetch(icar_hip_ctx *c, float dx, const float *dz_levels)
+{
+    if (!c || !dz_levels) { icar_set_error("max_courant_prefetch: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->d.nz > 4096) { icar_set_error("max_courant_prefetch: nz too large"); return 1; }
+    return icar_max_courant_prefetch_run(c, dx, dz_levels);
 }
 
 int icar_hip_diagnostic_update(icar_hip_ctx *c)
@@ -702,6 +743,7 @@ int icar_hip_box_unpack(icar_hip_ctx *c, int field, int which, int i0, int ni, i
 {
     if (!c || !dbuf) { icar_set_error("box_unpack: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
+    if (which == 0 && (field == ICAR_F_U || field == ICAR_F_V || field == ICAR_F_W)) icar_winds_changed(c);
     return icar_box_copy(c, field, which, i0, ni, j0, nj, (float *)dbuf, true);
 }
 

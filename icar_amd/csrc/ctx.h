@@ -43,6 +43,13 @@ struct icar_hip_ctx {
     float *U = nullptr, *V = nullptr, *W = nullptr, *Wdz = nullptr;
     float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
     bool winds_valid = false;
+    // u / v / w bookkeeping for the prefetched CFL reduction (icar_hip_max_courant_prefetch): every entry point that writes a wind
+    // field bumps the version; a raw device pointer to one of them handed out (icar_hip_field_device_ptr) disables the cache
+    unsigned long long wind_version = 0;
+    bool wind_ptr_escaped = false;
+    struct { bool valid = false; unsigned long long ver = 0; float dx = 0.f; std::vector<float> dzl; } cfl_pre;
+    float *h_cfl_pre = nullptr;          // pinned host copy of the prefetched maximum (d_red[8] on the device)
+    hipEvent_t cfl_ev = nullptr;
     float *iw_adj = nullptr;             // iterative_winds ADJ scratch (iterative_winds.hip)
     float *wgr_tmp = nullptr;            // make_winds_grid_relative: rotated mass-grid u | v (2 x n3)
     // reductions / flags
@@ -90,6 +97,8 @@ int icar_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int updat
 int icar_make_winds_grid_relative(icar_hip_ctx *c, int update);
 int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, float *buf, bool unpack);
 int icar_diagnostic_update_run(icar_hip_ctx *c, int parts);
+int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels);
+inline void icar_winds_changed(icar_hip_ctx *c) { c->winds_valid = false; ++c->wind_version; }   // u, v, w (or density / jacobians) rewritten
 int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);
 int icar_enforce_limits_run(icar_hip_ctx *c, const int *fields, int n);
 int icar_thompson_init_run(icar_hip_ctx *c, const float *params, const int *flags);

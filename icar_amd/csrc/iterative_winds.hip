@@ -115,7 +115,7 @@ int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update)
     hipLaunchKernelGGL(k_divide, dim3(2048), dim3(256), 0, c->stream, icar_field_count(c, ICAR_F_U), u, au);
     hipLaunchKernelGGL(k_divide, dim3(2048), dim3(256), 0, c->stream, icar_field_count(c, ICAR_F_V), v, av);
     HIPCHK(hipGetLastError());
-    c->winds_valid = false;
+    icar_winds_changed(c);
     return 0;
 }
 
@@ -171,7 +171,7 @@ int icar_make_winds_grid_relative(icar_hip_ctx *c, int update)
     hipLaunchKernelGGL(k_wgr_rotate, dim3((c->d.nx + 63) / 64, c->d.nz, c->d.ny), dim3(64), 0, c->stream, c->d, u, v, st, ct, ur, vr);
     hipLaunchKernelGGL(k_wgr_restagger, dim3((c->d.nx + 1 + 63) / 64, c->d.nz, c->d.ny + 1), dim3(64), 0, c->stream, c->d, ur, vr, u, v);
     HIPCHK(hipGetLastError());
-    if (!update) c->winds_valid = false;
+    if (!update) icar_winds_changed(c);
     return 0;
 }
 
@@ -203,7 +203,7 @@ int icar_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int updat
         hipLaunchKernelGGL(k_iw_apply, g, b, 0, c->stream, c->d, q.u, q.v, c->iw_adj);
     }
     HIPCHK(hipGetLastError());
-    c->winds_valid = false;
+    icar_winds_changed(c);
     return 0;
 }
 

@@ -846,7 +846,7 @@ int icar_spatial_winds_run(icar_hip_ctx *c, int update)
 {
     LinWinds *w = c->linwinds;
     if (!w || !w->lut_ready) { icar_set_error("spatial_winds: the LUT has not been built or uploaded"); return 1; }
-    if (!update) c->winds_valid = false;                          // u, v change: the Courant winds of setup_winds are stale
+    if (!update) icar_winds_changed(c);                          // u, v change: the Courant winds of setup_winds are stale
     ScopedTimer t(c, "spatial_winds");
     const Dims d = c->d;
     float *u3d = update ? c->dqdt[ICAR_F_U] : icar_field_f(c, ICAR_F_U);

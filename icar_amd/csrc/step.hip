@@ -182,7 +182,7 @@ int icar_diagnostic_update_run(icar_hip_ctx *c, int parts)
     if (parts & 1) {
     const float *p = icar_field_f(c, ICAR_F_PRESSURE), *th = icar_field_f(c, ICAR_F_POTENTIAL_TEMPERATURE);
     if (!p || !th) return 1;
-    c->winds_valid = false;                                       // density is rewritten: Courant winds (advect_density) are stale
+    icar_winds_changed(c);                                       // density is rewritten: Courant winds (advect_density) are stale
     float *ex = icar_field_f(c, ICAR_F_EXNER, false), *pi = icar_field_f(c, ICAR_F_PRESSURE_INTERFACE, false);
     float *ps = icar_field_f(c, ICAR_F_SURFACE_PRESSURE, false), *T = icar_field_f(c, ICAR_F_TEMPERATURE, false);
     float *Ti = icar_field_f(c, ICAR_F_TEMPERATURE_INTERFACE, false), *rho = icar_field_f(c, ICAR_F_DENSITY, false);
@@ -235,7 +235,7 @@ int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const 
         a.stag[m] = (f == ICAR_F_U || f == ICAR_F_JACOBIAN_U || f == ICAR_F_DZDX) ? 1 : (f == ICAR_F_V || f == ICAR_F_JACOBIAN_V || f == ICAR_F_DZDY) ? 2 : 0;
         a.fb[m] = fb[m];
         // the Courant winds of icar_hip_setup_winds are stale once u, v, w, density or a jacobian moved
-        if (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W || (f >= ICAR_F_DENSITY && f <= ICAR_F_ADVECTION_DZ)) c->winds_valid = false;
+        if (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W || (f >= ICAR_F_DENSITY && f <= ICAR_F_ADVECTION_DZ)) icar_winds_changed(c);
     }
     ScopedTimer t(c, "forcing");
     dim3 g(2048, 1, n), b(256);

@@ -108,6 +108,13 @@ class domain_t:
         ids = (ctypes.c_int * len(names))(*[self.fid(n) for n in names])
         check(lib().icar_hip_enforce_limits(self.ctx, ids, len(names)), "enforce_limits")
 
+    def prefetch_courant(self, options):
+        """The strictness-3 / 4 CFL reduction of the NEXT update_dt, launched now on the current stream (time_step.substep puts it
+        on the second stream beside the advection); the library hands it out only if nothing writes u, v, w in between."""
+        dzl = np.ascontiguousarray(options.parameters.dz_levels, np.float32)
+        check(lib().icar_hip_max_courant_prefetch(self.ctx, ctypes.c_float(self.dx), dzl.ctypes.data_as(ctypes.c_void_p)),
+              "icar_hip_max_courant_prefetch")
+
     def diagnostic_update(self, parts=3):
         """diagnostic_update(domain, options) (time_step.f90:49-198).  parts: 1 = all but w_real, 2 = w_real only, 3 = both."""
         check(lib().icar_hip_diagnostic_update_parts(self.ctx, int(parts)), "diagnostic_update")

@@ -15,7 +15,7 @@ module icar_hip
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
             hip_diagnostic_update, hip_diagnostic_update_parts, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
-            hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_winds_valid, &
+            hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_winds_valid, hip_max_courant_prefetch, &
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
@@ -105,6 +105,9 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_balance_uvw(ctx, dx) bind(C, name="icar_hip_balance_uvw")
        import; type(c_ptr), value :: ctx; real(c_float), value :: dx
+     end function
+     integer(c_int) function icar_hip_max_courant_prefetch(ctx, dx, dz_levels) bind(C, name="icar_hip_max_courant_prefetch")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dx; real(c_float), intent(in) :: dz_levels(*)
      end function
      integer(c_int) function icar_hip_winds_valid(ctx) bind(C, name="icar_hip_winds_valid")
        import; type(c_ptr), value :: ctx
@@ -346,6 +349,14 @@ contains
     type(hip_ctx_t), intent(in) :: ctx
     real, intent(in) :: dx
     call check(icar_hip_balance_uvw(ctx%p, real(dx,c_float)), "balance_uvw")
+  end subroutine
+
+  !> the CFL reduction of the NEXT update_dt taken now, on the current stream (beside the advection, after the forcing of u, v, w)
+  subroutine hip_max_courant_prefetch(ctx, dx, dz_levels)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dx
+    real(c_float), intent(in) :: dz_levels(:)
+    call check(icar_hip_max_courant_prefetch(ctx%p, real(dx,c_float), dz_levels), "max_courant_prefetch")
   end subroutine
 
   !> .true. while the Courant winds of the last hip_setup_winds still belong to the state

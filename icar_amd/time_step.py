@@ -117,12 +117,13 @@ def mp_and_halo(domain, options, dt, overlap=True, prepare_advection=True, besid
 _FORCING_BESIDE_ADVECT = ("u", "v", "w", "pressure")
 
 
-def substep(domain, options, dt, forced=None, diagnostics=True, enforce=False):
+def substep(domain, options, dt, forced=None, diagnostics=True, enforce=False, prefetch_dt=True):
     """One pass of time_step.f90:474-539: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve ->
     advect -> apply_forcing (-> enforce_limits), with the streaming kernels that do not depend on the two heavy ones issued
     beside them: the w_real diagnostic (read by WSM3 and the output only) beside the interior microphysics, the whole-field
     forcing of u, v, w, pressure on the second stream beside the advection (which works from the Courant winds set up
-    before).  Same launches, same operands, same results as the plain sequence."""
+    before), followed there by the CFL reduction of the next update_dt (the library discards it if anything writes u, v, w
+    before it is asked for).  Same launches, same operands, same results as the plain sequence."""
     from .constants import ADVECTION_ORDER, kMP_WSM3
     beside = ()
     if diagnostics:
@@ -135,13 +136,17 @@ def substep(domain, options, dt, forced=None, diagnostics=True, enforce=False):
         mp_and_halo(domain, options, dt, beside_interior=beside)   # :512-526
         aside = [f for f in (forced or []) if not f[1] and f[0] in _FORCING_BESIDE_ADVECT]
         rest = [f for f in (forced or []) if f not in aside]
-        if aside:
+        cfl_ahead = prefetch_dt and int(options.parameters.cfl_strictness) in (3, 4)
+        if aside or cfl_ahead:
             domain.aux_fork()                                  # the second stream starts from the state BEFORE the advection
         advect(domain, options, dt)                            # :529
-        if aside:
+        if aside or cfl_ahead:
             domain.aux_begin()
             try:
-                domain.apply_forcing(dt, aside)                # :534, the part that does not wait for the advection
+                if aside:
+                    domain.apply_forcing(dt, aside)            # :534, the part that does not wait for the advection
+                if cfl_ahead:
+                    domain.prefetch_courant(options)           # the reduction of the next update_dt (:217-330), winds now final
             finally:
                 domain.aux_end()
             domain.aux_join()

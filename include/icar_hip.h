@@ -198,6 +198,11 @@ int icar_hip_max_courant(icar_hip_ctx *ctx, float dx, const float *dz_levels, fl
  * `call co_min(seconds)` (time_step.f90:413) becomes a 1-element all-reduce(max) of d_out over the images on the device
  * (dt = cfl_reduction_factor / max is monotone, so the minimum dt is the quotient of the maximum). */
 int icar_hip_max_courant_device(icar_hip_ctx *ctx, float dx, const float *dz_levels, void *d_out);
+/* the same reduction taken ahead of time, on the current stream (typically the second one, beside the advection, right after the
+ * forcing of u, v, w): the next icar_hip_max_courant / _device call with the same arguments returns this value without launching
+ * anything, provided no entry point has written u, v or w in between (the library counts those writes; handing out a raw
+ * device pointer to a wind field disables the shortcut for good). */
+int icar_hip_max_courant_prefetch(icar_hip_ctx *ctx, float dx, const float *dz_levels);
 /* the other cfl_strictness settings (:238-259, :293-305) also need out[0..2] = maxval(abs(u)), maxval(abs(v)), maxval(abs(w)) */
 int icar_hip_max_abs_winds(icar_hip_ctx *ctx, float out[3]);
 

@@ -331,3 +331,27 @@ def test_update_dt_device_side_all_reduce_over_rccl():
     """) % (root, root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_DT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_prefetched_courant_is_used_only_while_the_winds_stand(oracle):
+    """icar_hip_max_courant_prefetch: the reduction taken ahead of time (on the second stream) is what the next
+    icar_hip_max_courant returns -- unless an entry point wrote u, v or w in between, then the reduction is redone."""
+    c = case(66, 30, 12, seed=9)
+    d = single_image_domain(c)
+    opt = options_t(); opt.parameters.dz_levels = c["dz_levels"]
+    m0 = np.float32(oracle.max_courant(c["u"], c["v"], c["w"], c["dz_levels"], float(c["dx"])))
+    d.aux_fork(); d.aux_begin(); d.prefetch_courant(opt); d.aux_end(); d.aux_join()
+    assert compute_dt(d, opt) == float(np.float32(0.9) / m0)                 # served from the prefetch
+    assert compute_dt(d, opt) == float(np.float32(0.9) / m0)                 # consumed: a fresh reduction, same winds
+    d.prefetch_courant(opt)
+    u2 = (c["u"] * np.float32(1.5)).astype(np.float32)
+    d.set("u", u2)                                                           # a write of u invalidates what was prefetched
+    m1 = np.float32(oracle.max_courant(u2, c["v"], c["w"], c["dz_levels"], float(c["dx"])))
+    assert m1 != m0 and compute_dt(d, opt) == float(np.float32(0.9) / m1)
+    d.prefetch_courant(opt)                                                  # forcing of a wind field does too
+    dq = np.full_like(c["v"], 0.01); d.set_dqdt("v", dq)
+    d.apply_forcing(10.0, [("v", False)])
+    v2 = (c["v"].astype(np.float64) + dq.astype(np.float64) * 10.0).astype(np.float32)
+    m2 = np.float32(oracle.max_courant(u2, v2, c["w"], c["dz_levels"], float(c["dx"])))
+    assert compute_dt(d, opt) == float(np.float32(0.9) / m2)
+    d.close()
