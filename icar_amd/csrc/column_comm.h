@@ -231,13 +231,14 @@ struct BlockComm {
 // Returns the fraction of busy threads (0 when nz > 1024).
 static inline float block_comm_geometry(int nz, int &nt, int &cpb)
 {
-    // 512-thread blocks are preferred over 256 whenever they waste no more threads (measured at nz = 40, Thompson:
-    // 12 columns per block 2.5 % faster than 6; 1024-thread blocks 8 % slower unless they fill much better)
+    // the smallest block wins unless a bigger one fills clearly better (measured at nz = 40, Thompson after round 2's work removal:
+    // 6 columns per 256-thread block 1.98 ms, 12 per 512-thread block 2.08 ms, 25 per 1024-thread block 2.50 ms -- round 1's
+    // kernel had 512 ahead by 2.5 %)
     float best = 0.0f; nt = 0; cpb = 0;
     for (int t = 256; t <= 1024; t *= 2) {
         if (t < nz) continue;
         const float u = (float)((t / nz) * nz) / t;
-        const float need = !nt ? 0.0f : (t == 512 && nt == 256) ? -1e-6f : 0.10f;
+        const float need = !nt ? 0.0f : 0.10f;
         if (u > best + need) { best = u; nt = t; cpb = t / nz; }
     }
     return best;
