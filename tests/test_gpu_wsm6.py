@@ -97,3 +97,64 @@ def test_wsm6_within_tolerance_of_reference_math(oracle, case):
         # rain: 1e-4.  The snow / graupel that reaches the ground in these cases is the small remainder of what melts on the
         # way down, decided by the scheme's threshold tests: a 1-ulp change of a transcendental moves it by up to ~2e-3
         assert rel <= (1e-4 if n == "rain" else 5e-3) + 1e-9 / max(acc[n].sum(), 1e-9), (n, rel)
+
+
+def test_wsm6_full_size_budget_and_column_subset_vs_oracle(oracle):
+    """BASELINE size (512x512x40): (a) every species stays non-negative and finite, (b) the column water budget closes (the scheme
+    only moves water between classes / levels / the surface), (c) 3000 random columns, re-run by the CPU oracle as a small domain
+    of their own (the scheme is column-local), are bit-identical in device math."""
+    nx = ny = 512; nz = 40; dt = 60.0; steps = 3
+    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, n_hydro=1, cool=6.0)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.8)).astype(np.float32)
+    rng = np.random.default_rng(21)
+    for n, amp in (("cloud_ice", 2e-5), ("snow", 2e-4), ("graupel", 1e-4)):
+        f = (amp * rng.random(c["water_vapor"].shape, dtype=np.float32) ** 3).astype(np.float32)
+        f[rng.random(f.shape, dtype=np.float32) < 0.4] = 0.0
+        c[n] = f
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_WSM6
+    mp_var_request(opt); mp_init(opt, d)
+    jj = rng.integers(1, ny - 1, 3000); ii = rng.integers(1, nx - 1, 3000)
+    names = KEYS + ["exner", "pressure", "dz_mass", "density"]
+    sub = {k: np.ascontiguousarray(np.stack([c[k][jj, :, ii].T] * 3, axis=0)) for k in names}          # (3, nz, 3000)
+    sub = {k: np.ascontiguousarray(np.pad(v, ((0, 0), (0, 0), (1, 1)), mode="edge")) for k, v in sub.items()}
+    n = sub["pressure"].shape[2]
+    wp = lambda f: (sum(f[k].astype(np.float64) for k in KEYS[1:]) * c["density"] * c["dz_mass"]).sum(axis=1)
+    before = wp(c)
+    a18 = ARGS18.copy(); a18[0] = dt
+    z = lambda: np.zeros((3, n), np.float32)
+    rain_acc = np.zeros((3, n), np.float64)
+    oracle.set_math_mode(1)
+    try:
+        oracle.wsm6_init()
+        for _ in range(steps):
+            mp(d, opt, dt); d.model_time_seconds += dt
+            acc = dict(rain=z(), sr=z(), snow=z(), graupel=z())          # process_subdomain zeroes its REAL(4) sums per call
+            assert oracle.wsm6(sub["potential_temperature"], sub["water_vapor"], sub["cloud_water"], sub["rain"], sub["cloud_ice"], sub["snow"],
+                               sub["graupel"], sub["density"], sub["exner"], sub["pressure"], sub["dz_mass"], a18, acc["rain"], acc["sr"],
+                               acc["snow"], acc["graupel"], 2, n - 1, 2, 2, 1, nz) == 0
+            rain_acc += acc["rain"]                                       # ... and adds them to the REAL(8) accumulators
+    finally:
+        oracle.set_math_mode(0)
+    out = {k: d.get(NAMES.get(k, k)) for k in KEYS}
+    precip = d.get("accumulated_precipitation")
+    d.close()
+    for k, a in out.items():
+        assert np.isfinite(a).all(), k
+        if k != "potential_temperature":
+            assert a.min() >= 0.0, f"{k}: negative values"
+    assert out["rain"].max() > 1e-5 and out["snow"].max() > 1e-5 and out["graupel"].max() > 1e-5 and precip.max() > 0
+    # (b) what left the columns is what reached the ground (mm = kg/m2).  Not exact in the reference either: its remap drops the
+    # part of the highest arrival cell that overlaps a level whose top lies above every arrival point (qn = 0 there,
+    # mp_wsm6.f90:1881-1890), which the hydrometeors seeded up to the model top lose in the first calls (CPU oracle: 2.25, 1.10,
+    # 1.004 lost / fallen in calls 1-3 of this state); over the three calls the budget closes to a few per cent
+    after = wp(out)
+    lost = (before - after)[1:-1, 1:-1]; fell = precip[1:-1, 1:-1]
+    assert lost.sum() >= fell.sum() and abs(lost.sum() - fell.sum()) <= 0.1 * fell.sum(), (lost.sum(), fell.sum())
+    # (c) the sampled columns, bit for bit
+    for k in KEYS:
+        got = out[k][jj, :, ii].T
+        want = sub[k][1, :, 1:-1]
+        parity_record("wsm6", "full_size_subset/mode1", {k: field_stats(got, want, 1e-5)})
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), f"{k}: {(got != want).sum()} of {got.size} cells differ"
+    assert np.array_equal(precip[jj, ii], rain_acc[1, 1:-1])
