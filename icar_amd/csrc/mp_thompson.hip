@@ -192,7 +192,11 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 struct ThTiles { int n, i0[4], i1[4], j0[4], ib0[4], nbx[4], off[5], xcd_run; };
 
 // cpb whole columns per block (aligned to multiples of cpb in i), thread = level*cpb + column (thompson_lane.inc: BlockComm)
-__global__ void __launch_bounds__(1024, 4)      // any block size <= 1024; register budget for 4 waves per SIMD (128 VGPRs)
+// MAXT = largest block this instantiation is launched with.  Blocks of up to 512 threads (columns of up to 512 levels) get the
+// register budget of 3 waves per SIMD (168 VGPRs, no spills); at 128 VGPRs / 4 waves the kernel ran exactly as fast but spilled
+// 62 VGPRs -- 4 GB of scratch traffic per launch against 0.9 GB of algorithmic bytes.  1024-thread blocks need the 128.
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT, MAXT > 512 ? 4 : 3)
 k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
@@ -302,8 +306,12 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
             tl.ib0[t] = tl.i0[t] / cpb; tl.nbx[t] = tl.i1[t] / cpb - tl.ib0[t] + 1;
             tl.off[t + 1] = tl.off[t] + tl.nbx[t] * (T4[t][3] - T4[t][2] + 1);
         }
-        hipLaunchKernelGGL(k_thompson_pack, dim3(tl.off[nt_]), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
-                           qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb);
+        if (nt <= 512)
+            hipLaunchKernelGGL(k_thompson_pack<512>, dim3(tl.off[nt_]), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
+                               qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb);
+        else
+            hipLaunchKernelGGL(k_thompson_pack<1024>, dim3(tl.off[nt_]), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
+                               qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb);
         HIPCHK(hipGetLastError());
         return 0;
     }
