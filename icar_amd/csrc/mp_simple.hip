@@ -147,6 +147,9 @@ k_mp_simple_pack(Dims d, const float *__restrict__ pressure, float *__restrict__
     const bool in_k = x.active && k >= kts && k <= kte;
     const int top = (kte < nz - 2) ? kte : nz - 2;
     if (in_k) mp_conversions(p, T, qv, qc, qr, qs, cloud2rain, cloud2snow, err);
+    // saturation mixing ratio of the fall sub-steps (:516-528, :543-562): a level whose temperature did not change since the last
+    // evaluation (saturated air: no evaporation) would compute the same exp again, 14 + 3 times at dt = 68 s
+    float T_sat = -1.0f, qvsat_c = 0.0f;
     // one fall sub-step of species q (:437-459): F = flux leaving this level, upF = flux arriving from the level above
 #define MPS_SEDIMENT(q, vfall, acc)                                                                   \
     {                                                                                                 \
@@ -168,10 +171,10 @@ k_mp_simple_pack(Dims d, const float *__restrict__ pressure, float *__restrict__
         for (int nmax = x.loop_max(ncfl), s = 1; s <= nmax; ++s) {
             const bool on = s <= ncfl;
             MPS_SEDIMENT(qr, vfall, rain = rain + F)
-            if (on && in_k) {
+            if (on && in_k && qr > SMALL_VALUE) {             // (the reference evaluates sat_mr first; its value is only read here)
                 const float L_evap = -1 * (LH_vapor + (373.15f - T) * dLHvdt);
-                const float qvsat = sat_mr(T, p);
-                if (qv < qvsat && qr > SMALL_VALUE) phase_change(T, qr, qvsat, qv, L_evap, rate, err);
+                if (T != T_sat) { qvsat_c = sat_mr(T, p); T_sat = T; }      // same T, same p: the same number as a new evaluation
+                if (qv < qvsat_c) phase_change(T, qr, qvsat_c, qv, L_evap, rate, err);
             }
         }
     }
@@ -185,11 +188,11 @@ k_mp_simple_pack(Dims d, const float *__restrict__ pressure, float *__restrict__
         for (int nmax = x.loop_max(ncfl), s = 1; s <= nmax; ++s) {
             const bool on = s <= ncfl;
             MPS_SEDIMENT(qs, vfall, { snow = snow + F; rain = rain + F; })
-            if (on && in_k) {
+            if (on && in_k && qs > SMALL_VALUE) {
                 const float L_evap = -1 * (LH_vapor + (373.15f - T) * dLHvdt);
                 const float L_subl = L_melt + L_evap;
-                const float qvsat = sat_mr(T, p);
-                if (qv < qvsat && qs > SMALL_VALUE) phase_change(T, qs, qvsat, qv, L_subl, rate, err);
+                if (T != T_sat) { qvsat_c = sat_mr(T, p); T_sat = T; }
+                if (qv < qvsat_c) phase_change(T, qs, qvsat_c, qv, L_subl, rate, err);
             }
         }
     }
