@@ -270,6 +270,160 @@ __device__ void w6_fall_column(const W6Consts &C, int km, int st, const float *_
     if (MODE == 2) precip[1] = w6_remap(km, st, G, qa2, rql2);
 }
 
+
+// ---------------- the same falls with one WAVE per column: lane = level (cells) / interface (wi, zi, za, dza, qa live on lanes 0..km).
+// nislfv_rain_plm / _plm6 are sequential in k in four places only, which stay sequential so that every sum and comparison sees the
+// reference's operands (the scheme of mp_wsm3.hip's fall, here with DPP wave shifts for the nearest-neighbour reads):
+//   zi          the running sum of dz: a field filled once per call (k_w6_zi)
+//   wi limiter  k = km..1 uses the wi(k+1) it may just have changed: evaluated for all k at once with the unmodified values;
+//               only from the highest level that trips the limit downward is it re-walked serially (rare)
+//   kb / kt     "first kk >= previous-1 with zi <= za(kk)": za increases strictly (the limiter guarantees dza >= 0.95 dz), so the
+//               first kk is the count of arrival heights below zi -- a binary search per lane; where kt is not found the
+//               reference's stale kt is < kb and the level gets qn = 0 either way
+//   sums        the kb+1..kt-1 partial sums and the surface flux are short loops in k order
+// Needs km + 1 <= 64 lanes; every cross-lane read happens with all lanes active.
+__device__ __forceinline__ float w6_up(float x)      // value of lane-1 (0 in lane 0): v_mov_b32_dpp wave_shr:1
+{ return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float w6_dn(float x)      // value of lane+1 (0 in lane 63): wave_shl:1
+{ return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130, 0xf, 0xf, true)); }
+
+// interface speeds, limiter, arrival heights (:1755-1790): ww per cell lane -> za, dza per interface lane
+__device__ __forceinline__ void w6w_arrival(int km, int lane, float ww, float dz, float zi, float dt, float &za, float &dza)
+{
+    const bool cell = lane < km;
+    const float wm1 = w6_up(ww), wm2 = w6_up(wm1), wp1 = w6_dn(ww);
+    const float fa1 = 9.f / 16.f, fa2 = 1.f / 16.f, con1 = 0.05f;
+    float wi;
+    if (lane == 0) wi = ww;
+    else if (lane == 1) wi = 0.5f * (ww + wm1);
+    else if (lane <= km - 2) wi = fa1 * (ww + wm1) - fa2 * (wp1 + wm2);
+    else if (lane == km - 1) wi = 0.5f * (ww + wm1);
+    else wi = wm1;                                           // lane == km: wi(km+1) = ww(km)
+    if (lane >= 1 && lane < km && ww == 0.0f) wi = wm1;      // terminate at the top of the rain shaft
+    const float wip1 = w6_dn(wi);
+    const float dec = (wip1 - wi) * dt / dz;
+    const unsigned long long bad = __ballot(cell && dec > con1);
+    if (bad) {                                               // wave-uniform
+        // level k must be re-evaluated when wi(k+1) has just been changed; when a level is left alone everything below it still
+        // sees the values the parallel evaluation saw, so the walk jumps to the next level that tripped there
+        const float cdz = con1 * dz / dt;
+        unsigned long long rem = bad;
+        int k = 63 - __builtin_clzll(rem);
+        while (k >= 0) {
+            const float wk1 = __shfl(wi, k + 1), wk = __shfl(wi, k), dzk = __shfl(dz, k), ck = __shfl(cdz, k);
+            const float decfl = (wk1 - wk) * dt / dzk;
+            rem &= (k == 0) ? 0ull : ((1ull << k) - 1ull);
+            if (decfl > con1) { if (lane == k) wi = wk1 - ck; k = k - 1; }
+            else k = rem ? 63 - __builtin_clzll(rem) : -1;
+        }
+    }
+    za = zi - wi * dt;                                       // interfaces 0..km
+    const float zap1 = w6_dn(za);
+    dza = (lane < km) ? zap1 - za : zi - za;                 // dza(km+1) = zi(km+1) - za(km+1)
+}
+
+// reconstruction, remap and rain-out of one arrived field (:1815-1948): returns this lane's qn, adds to precip
+__device__ __forceinline__ float w6w_remap(int km, int lane, float zi, float za, float dza, float qa, float &precip)
+{
+    const bool cell = lane < km;
+    float qmi = qa, qpi = qa;
+    {
+        const float qap1 = w6_dn(qa), qam1 = w6_up(qa), dzap1 = w6_dn(dza), dzam1 = w6_up(dza);
+        if (lane >= 1 && lane < km) {
+            const float dip = (qap1 - qa) / (dzap1 + dza);
+            const float dim = (qa - qam1) / (dzam1 + dza);
+            if (!(dip * dim <= 0.0f)) {
+                qpi = qa + 0.5f * (dip + dim) * dza;
+                qmi = 2.0f * qa - qpi;
+                if (qpi < 0.0f || qmi < 0.0f) { qpi = qa; qmi = qa; }
+            }
+        }
+    }
+    const float zlo = zi, zhi = w6_dn(zi);                   // the output cell of this lane is [zi(lane), zi(lane+1)]
+    const float za_top = __shfl(za, km);
+    int lo1 = 0, hi1 = km + 1, lo2 = 0, hi2 = km;            // arrival heights below zlo among 1..km (nb), below zhi among 0..km-1 (nt)
+    for (int step = 0; step < 6; ++step) {
+        const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+        const float v1 = __shfl(za, m1 < 63 ? m1 : 63), v2 = __shfl(za, m2 < 63 ? m2 : 63);
+        if (lo1 < hi1) { if (v1 < zlo) lo1 = m1 + 1; else hi1 = m1; }
+        if (lo2 < hi2) { if (v2 < zhi) lo2 = m2 + 1; else hi2 = m2; }
+    }
+    const float za0 = __shfl(za, 0);
+    const int nb = lo1 - (za0 < zlo ? 1 : 0), nt = lo2;
+    const bool live = cell && !(zlo >= za_top);              // not yet `exit intp`
+    const int kb = live ? nb + 1 : 1;
+    const bool found = live && nt < km;
+    const int kt = found ? nt : 0;
+    const int ib = kb - 1, it = (kt >= 1 ? kt : 1) - 1;
+    const float za_b = __shfl(za, ib), dza_b = __shfl(dza, ib), qpi_b = __shfl(qpi, ib), qmi_b = __shfl(qmi, ib), qa_b = __shfl(qa, ib);
+    const float za_t = __shfl(za, it), dza_t = __shfl(dza, it), qpi_t = __shfl(qpi, it), qmi_t = __shfl(qmi, it);
+    const float tl = (zlo - za_b) / dza_b;
+    const float tl2 = tl * tl;
+    const float qqd_b = 0.5f * (qpi_b - qmi_b);
+    const float qql = qqd_b * tl2 + qmi_b * tl;
+    float zsum = (1.f - tl) * dza_b, qsum = (qa_b - qql) * dza_b;
+    const int cnt = (found && kt > kb) ? kt - kb - 1 : 0;
+    int cmax = cnt;
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(cmax, o); cmax = v > cmax ? v : cmax; }
+    for (int s2 = 1; s2 <= cmax; ++s2) {
+        const int m = kb + s2 - 1 <= 63 ? kb + s2 - 1 : 63;
+        const float dm = __shfl(dza, m), qm = __shfl(qa, m);
+        if (s2 <= cnt) { zsum = zsum + dm; qsum = qsum + qm * dm; }
+    }
+    float qn = 0.0f;
+    if (found && kt == kb) {
+        const float th = (zhi - za_b) / dza_b;
+        const float th2 = th * th;
+        const float qqh = qqd_b * th2 + qmi_b * th;
+        qn = (qqh - qql) / (th - tl);
+    } else if (found && kt > kb) {
+        const float th = (zhi - za_t) / dza_t;
+        const float th2 = th * th;
+        const float qqd = 0.5f * (qpi_t - qmi_t);
+        const float dqh = qqd * th2 + qmi_t * th;
+        zsum = zsum + th * dza_t;
+        qsum = qsum + dqh * dza_t;
+        qn = qsum / zsum;
+    }
+    for (int k = 0; k < km; ++k) {                           // rain out, k ascending (wave-uniform loop on broadcast values)
+        const float zk = __shfl(za, k), zk1 = __shfl(za, k + 1), qk = __shfl(qa, k), dk = __shfl(dza, k);
+        if (zk < 0.0f && zk1 < 0.0f) { precip = precip + qk * dk; continue; }
+        else if (zk < 0.0f && zk1 >= 0.0f) { precip = precip + qk * (0.0f - zk); break; }
+        break;
+    }
+    return qn;
+}
+
+// one column on one wave.  MODE as in w6_fall_column.  qn / qn2 = the fallen den*q of this lane's level.
+template <int MODE>
+__device__ __forceinline__ void w6_fall_wave(const W6Consts &C, int km, int lane, float dz, float den, float denfac, float tk, float wwl,
+                                             float rql, float rql2, float zi, float dt, float &qn, float &qn2, float precip[2])
+{
+    const bool cell = lane < km;
+    precip[0] = 0.0f; precip[1] = 0.0f;
+    qn = rql; qn2 = rql2;                                    // an empty column keeps den*q as it is (cycle i_loop)
+    // allold > 0: den*q >= 0, so the sum is positive iff one term is
+    if (__ballot(cell && (rql > 0.0f || (MODE == 2 && rql2 > 0.0f))) == 0ull) return;
+    float ww = cell ? wwl : 0.0f, za, dza, qa, qa2 = 0.0f;
+    for (int n = 1;; ++n) {
+        w6w_arrival(km, lane, ww, dz, zi, dt, za, dza);
+        qa = cell ? rql * dz / dza : 0.0f;                   // qa(km+1) = 0
+        if (MODE == 2) qa2 = cell ? rql2 * dz / dza : 0.0f;
+        if (MODE == 1 || n > 1) break;
+        float wa;                                            // one refinement of the speed with the arrived mixing ratios
+        if (MODE == 0) wa = w6_slope<0>(C, cell ? qa / den : 0.f, den, denfac, 0.f).vt;
+        else {
+            const float qr = cell ? qa / den : 0.f, qr2 = cell ? qa2 / den : 0.f;
+            const float was = w6_slope<1>(C, qr, den, denfac, tk).vt, wag = w6_slope<2>(C, qr2, den, denfac, 0.f).vt;
+            const float tmp = mx(qr + qr2, 1.E-15f);
+            if (tmp > 1.e-15f) wa = (was * qr + wag * qr2) / tmp; else wa = 0.f;
+        }
+        ww = cell ? 0.5f * (wwl + wa) : 0.0f;
+    }
+    qn = w6w_remap(km, lane, zi, za, dza, qa, precip[0]);
+    if (MODE == 2) qn2 = w6w_remap(km, lane, zi, za, dza, qa2, precip[1]);
+}
+
 // thread -> cell / column of the tile, flattened with i fastest: full waves whatever the tile's shape (the strips of
 // process_halo are one column wide), coalesced rows for ordinary tiles.  `nrow` = number of j rows of the tile.
 #define W6_CELL_INDEX                                                                                   \
@@ -285,7 +439,7 @@ __device__ void w6_fall_column(const W6Consts &C, int km, int st, const float *_
 
 // ---------------- work fields ----------------
 struct W6Work {
-    float *t, *cpm, *xl, *denfac, *qs1, *qs2, *rh1, *rh2, *xni, *workr, *worka, *dq1, *dq2, *dq3, *vti, *dqi, *frz;   // (nx, nz, ny)
+    float *t, *cpm, *xl, *denfac, *qs1, *qs2, *rh1, *rh2, *xni, *workr, *worka, *dq1, *dq2, *dq3, *vti, *dqi, *frz, *zi;   // (nx, nz, ny)
     float *rain, *snow, *graupel, *delq;                                                                                 // (nx, ny) ; delq: 3 of them
 };
 }  // namespace
@@ -297,6 +451,92 @@ struct Wsm6State {
 };
 
 namespace {
+
+// zi(k+1) = zi(k) + dz(k) (:1747-1750), the reference's running sum, once per call and column
+__global__ void __launch_bounds__(64)
+k_w6_zi(Dims d, const float *__restrict__ delz, float *__restrict__ zi, int i0, int i1, int j0, int k0, int km, int nrow)
+{
+    W6_COLUMN_INDEX
+    float run = 0.0f;
+    for (int k = 0; k < km; ++k) { const int c = d.idx(i, k0 + k, j); run = run + delz[c]; zi[c] = run; }
+}
+
+// The falls with lane = level.  A block = 4 waves = one row segment of W6_TC columns of one fall (blockIdx.z: 0 rain, 1 snow +
+// graupel, 2 cloud ice -- launched as z = 0..1 before the melting kernel and z = 2 after it): the column arrays are staged through
+// LDS as [level][column] tiles (coalesced row reads; the column-per-wave access pattern itself would touch one cache line per
+// lane), each wave then walks its W6_TC / 4 columns, and the results go back the same way.
+#define W6_TC 32
+__global__ void __launch_bounds__(256)
+k_w6_fall_tile(Dims d, W6Consts C, W6Work W, const float *__restrict__ den_, const float *__restrict__ delz, float dt,
+               int i0, int i1, int j0, int k0, int km, int zbase)
+{
+    extern __shared__ float w6_lds[];                                // [8][km][W6_TC + 1]
+    const int fall = zbase + blockIdx.z;                             // 0 rain, 1 snow + graupel, 2 cloud ice
+    const int ib = i0 + blockIdx.x * W6_TC, j = j0 + blockIdx.y;
+    const int ncol = min(W6_TC, i1 - ib + 1);
+    const int LS = W6_TC + 1, plane = km * LS;
+    float *__restrict__ dq = fall == 0 ? W.dq1 : fall == 1 ? W.dq2 : W.dqi;
+    float *__restrict__ dqb = fall == 1 ? W.dq3 : nullptr;
+    const float *src[8] = {delz, den_, W.denfac, W.t, fall == 0 ? W.workr : fall == 1 ? W.worka : W.vti, dq, W.zi, dqb};
+    const int narr = fall == 1 ? 8 : 7;
+    for (int a = 0; a < narr; ++a)
+        for (int e = threadIdx.x; e < km * W6_TC; e += 256) {
+            const int k = e / W6_TC, ci = e % W6_TC;
+            if (ci < ncol) w6_lds[a * plane + k * LS + ci] = src[a][d.idx(ib + ci, k0 + k, j)];
+        }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kl = lane < km ? lane : km - 1;                        // lanes beyond the column read a valid level (values unused)
+    const size_t n2 = (size_t)d.nx * d.ny;
+    for (int t = 0; t < W6_TC / 4; ++t) {
+        const int ci = wave * (W6_TC / 4) + t;
+        if (ci >= ncol) break;                                       // wave-uniform
+        const float dz = w6_lds[0 * plane + kl * LS + ci], den = w6_lds[1 * plane + kl * LS + ci], denfac = w6_lds[2 * plane + kl * LS + ci],
+                    tk = w6_lds[3 * plane + kl * LS + ci], wwl = w6_lds[4 * plane + kl * LS + ci], rql = w6_lds[5 * plane + kl * LS + ci];
+        const float rql2 = fall == 1 ? w6_lds[7 * plane + kl * LS + ci] : 0.0f;
+        const int kz = (lane <= km ? lane : km) - 1;
+        const float zi = lane == 0 ? 0.0f : w6_lds[6 * plane + kz * LS + ci];
+        float qn, qn2, pr[2];
+        if (fall == 0) w6_fall_wave<0>(C, km, lane, dz, den, denfac, tk, wwl, rql, 0.f, zi, dt, qn, qn2, pr);
+        else if (fall == 1) w6_fall_wave<2>(C, km, lane, dz, den, denfac, tk, wwl, rql, rql2, zi, dt, qn, qn2, pr);
+        else w6_fall_wave<1>(C, km, lane, dz, den, denfac, tk, wwl, rql, 0.f, zi, dt, qn, qn2, pr);
+        if (lane < km) { w6_lds[5 * plane + lane * LS + ci] = qn; if (fall == 1) w6_lds[7 * plane + lane * LS + ci] = qn2; }
+        if (lane == 0) {
+            const size_t c2 = (size_t)(ib + ci) + (size_t)d.nx * j;
+            if (fall == 0) W.delq[c2] = pr[0];
+            else if (fall == 1) { W.delq[n2 + c2] = pr[0]; W.delq[2 * n2 + c2] = pr[1]; }
+            else W.delq[3 * n2 + c2] = pr[0];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < km * W6_TC; e += 256) {
+        const int k = e / W6_TC, ci = e % W6_TC;
+        if (ci < ncol) {
+            const int c = d.idx(ib + ci, k0 + k, j);
+            dq[c] = w6_lds[5 * plane + k * LS + ci];                 // rql(i,:) = qn(:)
+            if (fall == 1) dqb[c] = w6_lds[7 * plane + k * LS + ci];
+        }
+    }
+}
+
+// per column: the surface sums of this minor loop from the four fall integrals (:586-588, :666, :672-697)
+__global__ void __launch_bounds__(64)
+k_w6_surface(Dims d, W6Args A, W6Work W, const float *__restrict__ delz, float dtcld, int i0, int i1, int j0, int k0, int nrow)
+{
+    W6_COLUMN_INDEX
+    const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
+    const size_t n2 = (size_t)d.nx * d.ny;
+    const float dz0 = delz[c0];
+    const float fall1 = W.delq[c2] / dz0 / dtcld, fall2 = W.delq[n2 + c2] / dz0 / dtcld, fall3 = W.delq[2 * n2 + c2] / dz0 / dtcld;
+    const float fallc = W.delq[3 * n2 + c2] / dz0 / dtcld;
+    const float fallsum = fall1 + fall2 + fall3 + fallc;
+    const float fallsum_qsi = fall2 + fallc;
+    const float fallsum_qg = fall3;
+    if (fallsum > 0.f) W.rain[c2] = fallsum * dz0 / A.denr * dtcld * 1000.f + W.rain[c2];
+    if (fallsum_qsi > 0.f) W.snow[c2] = fallsum_qsi * dz0 / A.denr * dtcld * 1000.f + W.snow[c2];
+    if (fallsum_qg > 0.f) W.graupel[c2] = fallsum_qg * dz0 / A.denr * dtcld * 1000.f + W.graupel[c2];
+}
+
 // per cell, top of a minor loop
 template <bool FIRST>
 __global__ void __launch_bounds__(256)
@@ -690,7 +930,7 @@ void icar_wsm6_free(icar_hip_ctx *c)
 {
     if (!c->wsm6) return;
     W6Work &w = c->wsm6->w;
-    float *ps[] = {w.t, w.cpm, w.xl, w.denfac, w.qs1, w.qs2, w.rh1, w.rh2, w.xni, w.workr, w.worka, w.dq1, w.dq2, w.dq3, w.vti, w.dqi, w.frz,
+    float *ps[] = {w.t, w.cpm, w.xl, w.denfac, w.qs1, w.qs2, w.rh1, w.rh2, w.xni, w.workr, w.worka, w.dq1, w.dq2, w.dq3, w.vti, w.dqi, w.frz, w.zi,
                    w.rain, w.snow, w.graupel, w.delq};
     for (float *p : ps) if (p) hipFree(p);
     delete c->wsm6; c->wsm6 = nullptr;
@@ -761,10 +1001,10 @@ int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     W6Work &W = S->w;
     const size_t n2 = (size_t)c->d.nx * c->d.ny;
     if (!W.t) {
-        float **p3[] = {&W.t, &W.cpm, &W.xl, &W.denfac, &W.qs1, &W.qs2, &W.rh1, &W.rh2, &W.xni, &W.workr, &W.worka, &W.dq1, &W.dq2, &W.dq3, &W.vti, &W.dqi, &W.frz};
+        float **p3[] = {&W.t, &W.cpm, &W.xl, &W.denfac, &W.qs1, &W.qs2, &W.rh1, &W.rh2, &W.xni, &W.workr, &W.worka, &W.dq1, &W.dq2, &W.dq3, &W.vti, &W.dqi, &W.frz, &W.zi};
         for (float **x : p3) HIPCHK(hipMalloc(x, c->n3 * sizeof(float)));
         HIPCHK(hipMalloc(&W.rain, n2 * sizeof(float))); HIPCHK(hipMalloc(&W.snow, n2 * sizeof(float))); HIPCHK(hipMalloc(&W.graupel, n2 * sizeof(float)));
-        HIPCHK(hipMalloc(&W.delq, 3 * n2 * sizeof(float)));
+        HIPCHK(hipMalloc(&W.delq, 4 * n2 * sizeof(float)));
     }
     // what mp_driver.f90:518-550 passes: gravity, cp, cpv, Rd, Rw, 273.15, EP1, EP2, epsilon, XLS, XLV, XLF, rhoair0, rhowater,
     // cliq, cice, psat (icar_constants.f90:391-420, wrf_constants.f90:10-67)
@@ -784,12 +1024,22 @@ int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     const int i0 = its - c->ims, i1 = ite - c->ims, j0 = jts - c->jms, k0 = kts - c->kms, nyt = jte - jts + 1;
     const long long ncol = (long long)(ite - its + 1) * nyt, ncell = ncol * km;
     const dim3 gc((unsigned)((ncell + 255) / 256)), bc(256), g2((unsigned)((ncol + 63) / 64)), b2(64);
+    const bool wave_falls = km + 1 <= 64;                       // lane = level; taller columns: one thread per column
+    const dim3 gt((ite - its + 1 + W6_TC - 1) / W6_TC, nyt, 1);
+    const size_t tile_lds = 8 * (size_t)km * (W6_TC + 1) * sizeof(float);
+    if (wave_falls && tile_lds > 64 * 1024)                     // more than 61 levels: above HIP's default dynamic-LDS limit (160 kB per CU on gfx950)
+        HIPCHK(hipFuncSetAttribute((const void *)k_w6_fall_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+    if (wave_falls) hipLaunchKernelGGL(k_w6_zi, g2, b2, 0, c->stream, c->d, dz, W.zi, i0, i1, j0, k0, km, nyt);
     for (int loop = 1; loop <= loops; ++loop) {
         if (loop == 1) hipLaunchKernelGGL((k_w6_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
         else           hipLaunchKernelGGL((k_w6_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
-        hipLaunchKernelGGL(k_w6_fall, dim3(g2.x, 2), b2, 0, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
+        if (wave_falls) hipLaunchKernelGGL(k_w6_fall_tile, dim3(gt.x, gt.y, 2), dim3(256), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 0);
+        else hipLaunchKernelGGL(k_w6_fall, dim3(g2.x, 2), b2, 0, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
         hipLaunchKernelGGL(k_w6_melt, gc, bc, 0, c->stream, c->d, S->c, A, W, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
-        hipLaunchKernelGGL(k_w6_icefall, g2, b2, 0, c->stream, c->d, S->c, A, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
+        if (wave_falls) {
+            hipLaunchKernelGGL(k_w6_fall_tile, gt, dim3(256), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 2);
+            hipLaunchKernelGGL(k_w6_surface, g2, b2, 0, c->stream, c->d, A, W, dz, dtcld, i0, i1, j0, k0, nyt);
+        } else hipLaunchKernelGGL(k_w6_icefall, g2, b2, 0, c->stream, c->d, S->c, A, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
         if (loop == loops) hipLaunchKernelGGL((k_w6_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
         else               hipLaunchKernelGGL((k_w6_rates<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
     }
