@@ -98,6 +98,11 @@ k_wsm3_prep(Dims d, wsm3_consts C, wsm3_args A, W3Work W, const float *__restric
 // Needs km + 1 <= 64 lanes; all cross-lane reads happen with every lane active.
 // one (column, species) on one wave: lane = level for dz, den, denfac, tk, wwl (terminal velocity), rql (den*q); zi = height of
 // interface `lane` (0 at lane 0).  Returns the surface flux integral; *qn_out = the fallen den*q of this lane's level.
+// nearest-neighbour lane reads as DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1: one VALU slot; __shfl_up / __shfl_down are
+// ds_bpermute_b32 at 24 cycles per wave, profiles/micro/valubench.hip).  A lane without a source reads 0; none of those values is used.
+__device__ __forceinline__ float w3_up(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float w3_dn(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130, 0xf, 0xf, true)); }
+
 __device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int km, int lane, float dz, float den, float denfac, float tk,
                                                      float wwl, float rql, float zi, int iter, float dt, float *qn_out)
 {
@@ -106,7 +111,7 @@ __device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int k
     if (__ballot(cell && rql > 0.0f) != 0ull) {                      // allold > 0: den*q >= 0, so the sum is positive iff one term is
         float ww = cell ? wwl : 0.0f, wi, za, dza, qa;
         for (int n = 1;; ++n) {
-            const float wm1 = __shfl_up(ww, 1), wm2 = __shfl_up(ww, 2), wp1 = __shfl_down(ww, 1);
+            const float wm1 = w3_up(ww), wm2 = w3_up(wm1), wp1 = w3_dn(ww);
             const float fa1 = 9.f / 16.f, fa2 = 1.f / 16.f;
             if (lane == 0) wi = ww;
             else if (lane == 1) wi = 0.5f * (ww + wm1);
@@ -115,7 +120,7 @@ __device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int k
             else wi = wm1;                                           // lane == km: wi(km+1) = ww(km)
             if (lane >= 1 && lane < km && ww == 0.0f) wi = wm1;      // terminate at the top of the rain shaft
             const float con1 = 0.05f;                                // limiter, k = km-1 .. 0
-            const float wip1 = __shfl_down(wi, 1);
+            const float wip1 = w3_dn(wi);
             const float dec = (wip1 - wi) * dt / dz;
             const unsigned long long bad = __ballot(cell && dec > con1);
             if (bad) {                                               // wave-uniform
@@ -136,7 +141,7 @@ __device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int k
                 }
             }
             za = zi - wi * dt;                                       // interfaces 0..km
-            const float zap1 = __shfl_down(za, 1);
+            const float zap1 = w3_dn(za);
             dza = (lane < km) ? zap1 - za : zi - za;                 // dza(km+1) = zi(km+1) - za(km+1)
             qa = cell ? rql * dz / dza : 0.0f;                       // qa(km+1) = 0
             if (n <= iter) {                                         // wave-uniform
@@ -149,7 +154,7 @@ __device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int k
         }
         float qmi = qa, qpi = qa;                                    // piecewise-linear reconstruction
         {
-            const float qap1 = __shfl_down(qa, 1), qam1 = __shfl_up(qa, 1), dzap1 = __shfl_down(dza, 1), dzam1 = __shfl_up(dza, 1);
+            const float qap1 = w3_dn(qa), qam1 = w3_up(qa), dzap1 = w3_dn(dza), dzam1 = w3_up(dza);
             if (lane >= 1 && lane < km) {
                 const float dip = (qap1 - qa) / (dzap1 + dza);
                 const float dim = (qa - qam1) / (dzam1 + dza);
@@ -161,7 +166,7 @@ __device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int k
             }
         }
         // interpolation to the regular grid: the output cell of this lane is [zi(lane), zi(lane+1)]
-        const float zlo = zi, zhi = __shfl_down(zi, 1);
+        const float zlo = zi, zhi = w3_dn(zi);
         const float za_top = __shfl(za, km);
         // arrival heights below zlo among interfaces 1..km (nb) and below zhi among 0..km-1 (nt): za increases strictly, so each
         // count is the position of the first za >= z -- a 6-step binary search per lane instead of km+1 comparisons
@@ -224,7 +229,7 @@ __device__ __forceinline__ float w3_fall_wave_column(const wsm3_consts *C, int k
 // a block = 4 waves = one row segment of W3_TC columns of one species: the seven column arrays are staged through LDS as
 // [level][column] tiles (coalesced 128-B row reads; the column-per-wave access pattern itself would touch one cache line per
 // lane), each wave then walks its W3_TC/4 columns with lane = level, and the results go back the same way.
-#define W3_TC 32
+#define W3_TC 16      // (16 columns = 15 kB of LDS per block: more blocks per CU than with 32; measured with mp_wsm6.hip's falls)
 __global__ void __launch_bounds__(256)
 k_wsm3_fall_tile(Dims d, wsm3_consts C, W3Work W, float *__restrict__ qci, float *__restrict__ qrs, const float *__restrict__ den_,
                  const float *__restrict__ delz, float *__restrict__ delq, float dt, int i0, int i1, int j0, int k0, int km)

@@ -461,12 +461,15 @@ k_w6_zi(Dims d, const float *__restrict__ delz, float *__restrict__ zi, int i0, 
     for (int k = 0; k < km; ++k) { const int c = d.idx(i, k0 + k, j); run = run + delz[c]; zi[c] = run; }
 }
 
-// The falls with lane = level.  A block = 4 waves = one row segment of W6_TC columns of one fall (blockIdx.z: 0 rain, 1 snow +
+// The falls with lane = level.  A block = W6_NT / 64 waves = one row segment of W6_TC columns of one fall (blockIdx.z: 0 rain, 1 snow +
 // graupel, 2 cloud ice -- launched as z = 0..1 before the melting kernel and z = 2 after it): the column arrays are staged through
 // LDS as [level][column] tiles (coalesced row reads; the column-per-wave access pattern itself would touch one cache line per
 // lane), each wave then walks its W6_TC / 4 columns, and the results go back the same way.
-#define W6_TC 32
-__global__ void __launch_bounds__(256)
+// (tile width / block size measured at 512x512x40: 16 / 256 4.03 ms per step; 32 / 256 4.56; 32 / 512 4.28; 8 / 256 4.17; 64 / 512 5.53 --
+// the 21 kB of LDS of a 16-column tile keep 7 blocks per CU resident)
+#define W6_TC 16
+#define W6_NT 256
+__global__ void __launch_bounds__(W6_NT)
 k_w6_fall_tile(Dims d, W6Consts C, W6Work W, const float *__restrict__ den_, const float *__restrict__ delz, float dt,
                int i0, int i1, int j0, int k0, int km, int zbase)
 {
@@ -480,7 +483,7 @@ k_w6_fall_tile(Dims d, W6Consts C, W6Work W, const float *__restrict__ den_, con
     const float *src[8] = {delz, den_, W.denfac, W.t, fall == 0 ? W.workr : fall == 1 ? W.worka : W.vti, dq, W.zi, dqb};
     const int narr = fall == 1 ? 8 : 7;
     for (int a = 0; a < narr; ++a)
-        for (int e = threadIdx.x; e < km * W6_TC; e += 256) {
+        for (int e = threadIdx.x; e < km * W6_TC; e += W6_NT) {
             const int k = e / W6_TC, ci = e % W6_TC;
             if (ci < ncol) w6_lds[a * plane + k * LS + ci] = src[a][d.idx(ib + ci, k0 + k, j)];
         }
@@ -488,8 +491,8 @@ k_w6_fall_tile(Dims d, W6Consts C, W6Work W, const float *__restrict__ den_, con
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kl = lane < km ? lane : km - 1;                        // lanes beyond the column read a valid level (values unused)
     const size_t n2 = (size_t)d.nx * d.ny;
-    for (int t = 0; t < W6_TC / 4; ++t) {
-        const int ci = wave * (W6_TC / 4) + t;
+    for (int t = 0; t < W6_TC / (W6_NT / 64); ++t) {
+        const int ci = wave * (W6_TC / (W6_NT / 64)) + t;
         if (ci >= ncol) break;                                       // wave-uniform
         const float dz = w6_lds[0 * plane + kl * LS + ci], den = w6_lds[1 * plane + kl * LS + ci], denfac = w6_lds[2 * plane + kl * LS + ci],
                     tk = w6_lds[3 * plane + kl * LS + ci], wwl = w6_lds[4 * plane + kl * LS + ci], rql = w6_lds[5 * plane + kl * LS + ci];
@@ -509,7 +512,7 @@ k_w6_fall_tile(Dims d, W6Consts C, W6Work W, const float *__restrict__ den_, con
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < km * W6_TC; e += 256) {
+    for (int e = threadIdx.x; e < km * W6_TC; e += W6_NT) {
         const int k = e / W6_TC, ci = e % W6_TC;
         if (ci < ncol) {
             const int c = d.idx(ib + ci, k0 + k, j);
@@ -1033,11 +1036,11 @@ int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     for (int loop = 1; loop <= loops; ++loop) {
         if (loop == 1) hipLaunchKernelGGL((k_w6_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
         else           hipLaunchKernelGGL((k_w6_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
-        if (wave_falls) hipLaunchKernelGGL(k_w6_fall_tile, dim3(gt.x, gt.y, 2), dim3(256), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 0);
+        if (wave_falls) hipLaunchKernelGGL(k_w6_fall_tile, dim3(gt.x, gt.y, 2), dim3(W6_NT), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 0);
         else hipLaunchKernelGGL(k_w6_fall, dim3(g2.x, 2), b2, 0, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
         hipLaunchKernelGGL(k_w6_melt, gc, bc, 0, c->stream, c->d, S->c, A, W, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
         if (wave_falls) {
-            hipLaunchKernelGGL(k_w6_fall_tile, gt, dim3(256), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 2);
+            hipLaunchKernelGGL(k_w6_fall_tile, gt, dim3(W6_NT), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 2);
             hipLaunchKernelGGL(k_w6_surface, g2, b2, 0, c->stream, c->d, A, W, dz, dtcld, i0, i1, j0, k0, nyt);
         } else hipLaunchKernelGGL(k_w6_icefall, g2, b2, 0, c->stream, c->d, S->c, A, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
         if (loop == loops) hipLaunchKernelGGL((k_w6_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
