@@ -564,6 +564,13 @@ int icar_hip_thompson_tiles(icar_hip_ctx *c, float dt, int ntiles, const int til
     return icar_thompson_run_tiles(c, dt, ntiles, tiles, kts, kte, ids, ide, jds, jde, kds, kde);
 }
 
+int icar_hip_thompson_dec_index(icar_hip_ctx *c, const float *r4, const double *r8, int n, int n2, int which, int *out)
+{
+    if (!c || !out || (!r4 && !r8) || (r4 && r8)) { icar_set_error("thompson_dec_index: exactly one of r4 / r8, and out"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_thompson_dec_index_run(c, r4, r8, n, n2, which ? 1 : 0, out);
+}
+
 int icar_hip_thompson_table(icar_hip_ctx *c, const char *name, double *out, size_t capacity, size_t *count)
 {
     if (!c || !name) { icar_set_error("thompson_table: null argument"); return 1; }

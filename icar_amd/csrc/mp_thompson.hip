@@ -250,7 +250,33 @@ __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
     T->log_Ds_span = log(T->Ds[NBINS - 1] / T->Ds[0]);
     for (int n = 0; n < TH_P10_N; ++n) T->p10[n] = powi10f(n - TH_P10_OFF);
 }
+// the decade index of the level code for n values: which = 0 the product's form (dec_index_f / dec_index_d with the table), 1 the
+// reference's loop alone -- so that a test can compare them value by value (icar_hip_thompson_dec_index)
+__global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__ rf, const double *__restrict__ rd, int n, int n2, int which, int *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (rf) out[t] = which ? dec_index_f(rf[t], n2) : dec_index_f(T, rf[t], n2);
+    else    out[t] = which ? dec_index_d(rd[t], n2) : dec_index_d(T, rd[t], n2);
+}
 }  // namespace
+
+int icar_thompson_dec_index_run(icar_hip_ctx *c, const float *rf, const double *rd, int n, int n2, int which, int *out)
+{
+    const ThState *T = icar_thompson_device_state(c);
+    if (!T) { icar_set_error("thompson: call icar_hip_thompson_init first"); return 1; }
+    if (n <= 0) return 0;
+    float *drf = nullptr; double *drd = nullptr; int *dout = nullptr;
+    HIPCHK(hipMalloc(&dout, sizeof(int) * n));
+    if (rf) { HIPCHK(hipMalloc(&drf, sizeof(float) * n)); HIPCHK(hipMemcpy(drf, rf, sizeof(float) * n, hipMemcpyHostToDevice)); }
+    else    { HIPCHK(hipMalloc(&drd, sizeof(double) * n)); HIPCHK(hipMemcpy(drd, rd, sizeof(double) * n, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_thompson_dec_index, dim3((n + 255) / 256), dim3(256), 0, c->stream, T, drf, drd, n, n2, which, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, dout, sizeof(int) * n, hipMemcpyDeviceToHost));
+    hipFree(dout); if (drf) hipFree(drf); if (drd) hipFree(drd);
+    return 0;
+}
 
 // called by icar_thompson_init_run once the device state exists
 int icar_thompson_prepare_constants(icar_hip_ctx *c)

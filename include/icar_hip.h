@@ -171,6 +171,12 @@ int icar_hip_thompson_tiles(icar_hip_ctx *ctx, float dt, int ntiles, const int t
  * (src/physics/mp_thompson.f90:2870-2887).  out may be NULL to query the element count. */
 int icar_hip_thompson_table(icar_hip_ctx *ctx, const char *name, double *out, size_t capacity, size_t *count);
 
+/* The decade index of the lookup tables (src/physics/mp_thompson.f90:1562-1574 for a REAL argument, :1620-1627 for a DOUBLE
+ * PRECISION one) for n values of r (exactly one of r4 / r8 given; n2 = the table's first decade), computed on the device by
+ * which = 0: the level code's form (decade from the hardware log2 + the same 10.**n and IEEE division, the reference's loop
+ * only near a power of ten), which = 1: the reference's loop alone.  A cross-check for tests: the two must agree everywhere. */
+int icar_hip_thompson_dec_index(icar_hip_ctx *ctx, const float *r4, const double *r8, int n, int n2, int which, int *out);
+
 /* ---- M0: tile bookkeeping of mp()/process_halo (src/physics/mp_driver.f90:609-772) -----------
  * Fills tiles[n][4] = {its,ite,jts,jte} for halo>0 (W,E,S,N strips; corners once) or for the
  * interior shrunk by subset; returns the number of tiles (integer-exact restatement). */

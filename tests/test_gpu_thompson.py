@@ -295,3 +295,40 @@ def test_non_default_mp_options(oracle):
     finally:
         po, fo = options_t().mp_options.as_arrays()
         oracle.thompson_init(po, fo)
+
+
+def test_decade_index_fast_form_equals_reference_loop():
+    """The table indices (mp_thompson.f90:1562-1627) are integer-exact rows: the level code takes the decade from the hardware log2
+    and one division by the tabulated 10.**n, and runs the reference's loop (nint(log10 r), 10.**n by repeated squaring, the
+    [1, 10) test) only near a power of ten.  Both forms, value by value: log-uniform random arguments over every decade the scheme
+    can produce, every REAL(4) within 200 ulps of a power of ten, and the table's own grid values."""
+    import ctypes
+    from icar_amd.capi import lib, check
+    c = ideal.make_case(12, 6, 12)
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    mp_init(opt, d)
+    rng = np.random.default_rng(5)
+    r4 = [10.0 ** rng.uniform(-13.5, 9.5, 2_000_000)]
+    for e in range(-13, 10):
+        p = np.float32(10.0) ** np.float32(e)
+        for base in (p, np.float32(float(10.0 ** e))):
+            bits = np.array([base], np.float32).view(np.int32)[0]
+            r4.append(np.arange(bits - 200, bits + 201, dtype=np.int32).view(np.float32).astype(np.float64))
+        r4.append(p * np.arange(1, 10, dtype=np.float64))                      # the decade's grid points 1e.., 2e.., ...
+        f = np.linspace(1.5e-4, 3.5e-4, 400)                                   # either side of where the fast form hands over to the loop
+        r4.append(10.0 ** (e + f)); r4.append(10.0 ** (e - f))
+    r4 = np.ascontiguousarray(np.concatenate(r4).astype(np.float32))
+    r8 = np.ascontiguousarray(np.concatenate([10.0 ** rng.uniform(0.5, 13.5, 1_000_000),
+                                              np.concatenate([np.nextafter(10.0 ** e, np.inf) * (1 + np.arange(-50, 51) * 2.0 ** -40) for e in range(1, 14)]),
+                                              np.concatenate([10.0 ** e * np.arange(1, 10) for e in range(1, 14)])]))
+    for arr, is4 in ((r4, True), (r8, False)):
+        for n2 in (-12, -6, 0, 2):
+            fast = np.zeros(arr.size, np.int32); slow = np.zeros(arr.size, np.int32)
+            p4 = arr.ctypes.data_as(ctypes.c_void_p) if is4 else None
+            p8 = None if is4 else arr.ctypes.data_as(ctypes.c_void_p)
+            check(lib().icar_hip_thompson_dec_index(d.ctx, p4, p8, arr.size, n2, 0, fast.ctypes.data_as(ctypes.c_void_p)), "dec_index")
+            check(lib().icar_hip_thompson_dec_index(d.ctx, p4, p8, arr.size, n2, 1, slow.ctypes.data_as(ctypes.c_void_p)), "dec_index")
+            bad = np.flatnonzero(fast != slow)
+            assert bad.size == 0, (is4, n2, bad.size, arr[bad[:5]], fast[bad[:5]], slow[bad[:5]])
+    d.close()
