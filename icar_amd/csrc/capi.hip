@@ -659,6 +659,13 @@ int icar_hip_enforce_limits(icar_hip_ctx *c, const int *fields, int n)
     return icar_enforce_limits_run(c, fields, n);
 }
 
+int icar_hip_wsm6_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte)
+{
+    if (!c || !tiles) { icar_set_error("wsm6_tiles: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_wsm6_run_tiles(c, dt, ntiles, tiles, kts, kte);
+}
+
 int icar_hip_winds_valid(icar_hip_ctx *c) { return (c && c->winds_valid) ? 1 : 0; }
 
 int icar_hip_wsm6_init(icar_hip_ctx *c)

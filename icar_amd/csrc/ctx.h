@@ -116,6 +116,7 @@ int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
 void icar_wsm6_free(icar_hip_ctx *c);
 int icar_wsm6_init_run(icar_hip_ctx *c);
 int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte);
+int icar_wsm6_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte);
 int icar_linwinds_setup_run(icar_hip_ctx *c, const icar_hip_lt_options *o, const float *terrain, int nxg, int nyg, int ids, int jds, float dx);
 int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, float zb, float zt, float minimum_step, double *u_out, double *v_out);
 int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *zt, int nlev);

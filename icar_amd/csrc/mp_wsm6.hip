@@ -424,18 +424,32 @@ __device__ __forceinline__ void w6_fall_wave(const W6Consts &C, int km, int lane
     if (MODE == 2) qn2 = w6w_remap(km, lane, zi, za, dza, qa2, precip[1]);
 }
 
-// thread -> cell / column of the tile, flattened with i fastest: full waves whatever the tile's shape (the strips of
-// process_halo are one column wide), coalesced rows for ordinary tiles.  `nrow` = number of j rows of the tile.
+// Up to 4 tiles per launch (the strips of process_halo, mp_driver.f90:609-658, or the one tile of a plain call).  Threads map to the
+// cells / columns of the tiles flattened tile after tile, i fastest: full waves whatever a tile's shape (the strips are one
+// column wide), coalesced rows for ordinary tiles.
+struct W6Tiles { int n, i0[4], i1[4], j0[4], nrow[4], coff[5], boff[5]; };       // coff: prefix of columns, boff: of fall-tile blocks
+struct W6Box { int i0, i1, j0, nrow; long long local; };
+// tile of flat index t (in units of `unit` per column): constant indices only, so the table stays in SGPRs
+__device__ __forceinline__ W6Box w6_box(const W6Tiles &tl, long long t, long long unit, const int *off)
+{
+    W6Box b = {tl.i0[0], tl.i1[0], tl.j0[0], tl.nrow[0], t};
+#pragma unroll
+    for (int tt = 1; tt < 4; ++tt)
+        if (tt < tl.n && t >= (long long)off[tt] * unit) { b.i0 = tl.i0[tt]; b.i1 = tl.i1[tt]; b.j0 = tl.j0[tt]; b.nrow = tl.nrow[tt]; b.local = t - (long long)off[tt] * unit; }
+    return b;
+}
 #define W6_CELL_INDEX                                                                                   \
-    const int w_ = i1 - i0 + 1;                                                                         \
     const long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;                               \
-    if (t_ >= (long long)w_ * km * nrow) return;                                                        \
-    const int i = i0 + (int)(t_ % w_), k = k0 + (int)((t_ / w_) % km), j = j0 + (int)(t_ / ((long long)w_ * km));
+    if (t_ >= (long long)tl.coff[tl.n] * km) return;                                                    \
+    const W6Box bx_ = w6_box(tl, t_, km, tl.coff);                                                      \
+    const int w_ = bx_.i1 - bx_.i0 + 1;                                                                 \
+    const int i = bx_.i0 + (int)(bx_.local % w_), k = k0 + (int)((bx_.local / w_) % km), j = bx_.j0 + (int)(bx_.local / ((long long)w_ * km));
 #define W6_COLUMN_INDEX                                                                                 \
-    const int w_ = i1 - i0 + 1;                                                                         \
     const long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;                               \
-    if (t_ >= (long long)w_ * nrow) return;                                                             \
-    const int i = i0 + (int)(t_ % w_), j = j0 + (int)(t_ / w_);
+    if (t_ >= tl.coff[tl.n]) return;                                                                    \
+    const W6Box bx_ = w6_box(tl, t_, 1, tl.coff);                                                       \
+    const int w_ = bx_.i1 - bx_.i0 + 1;                                                                 \
+    const int i = bx_.i0 + (int)(bx_.local % w_), j = bx_.j0 + (int)(bx_.local / w_);
 
 // ---------------- work fields ----------------
 struct W6Work {
@@ -454,7 +468,7 @@ namespace {
 
 // zi(k+1) = zi(k) + dz(k) (:1747-1750), the reference's running sum, once per call and column
 __global__ void __launch_bounds__(64)
-k_w6_zi(Dims d, const float *__restrict__ delz, float *__restrict__ zi, int i0, int i1, int j0, int k0, int km, int nrow)
+k_w6_zi(Dims d, const float *__restrict__ delz, float *__restrict__ zi, W6Tiles tl, int k0, int km)
 {
     W6_COLUMN_INDEX
     float run = 0.0f;
@@ -471,11 +485,14 @@ k_w6_zi(Dims d, const float *__restrict__ delz, float *__restrict__ zi, int i0, 
 #define W6_NT 256
 __global__ void __launch_bounds__(W6_NT)
 k_w6_fall_tile(Dims d, W6Consts C, W6Work W, const float *__restrict__ den_, const float *__restrict__ delz, float dt,
-               int i0, int i1, int j0, int k0, int km, int zbase)
+               W6Tiles tl, int k0, int km, int zbase)
 {
     extern __shared__ float w6_lds[];                                // [8][km][W6_TC + 1]
     const int fall = zbase + blockIdx.z;                             // 0 rain, 1 snow + graupel, 2 cloud ice
-    const int ib = i0 + blockIdx.x * W6_TC, j = j0 + blockIdx.y;
+    const W6Box bx_ = w6_box(tl, blockIdx.x, 1, tl.boff);            // blocks are numbered tile after tile, x-tile fastest
+    const int nxt = (bx_.i1 - bx_.i0 + W6_TC) / W6_TC;
+    const int ib = bx_.i0 + (int)(bx_.local % nxt) * W6_TC, j = bx_.j0 + (int)(bx_.local / nxt);
+    const int i1 = bx_.i1;
     const int ncol = min(W6_TC, i1 - ib + 1);
     const int LS = W6_TC + 1, plane = km * LS;
     float *__restrict__ dq = fall == 0 ? W.dq1 : fall == 1 ? W.dq2 : W.dqi;
@@ -524,7 +541,7 @@ k_w6_fall_tile(Dims d, W6Consts C, W6Work W, const float *__restrict__ den_, con
 
 // per column: the surface sums of this minor loop from the four fall integrals (:586-588, :666, :672-697)
 __global__ void __launch_bounds__(64)
-k_w6_surface(Dims d, W6Args A, W6Work W, const float *__restrict__ delz, float dtcld, int i0, int i1, int j0, int k0, int nrow)
+k_w6_surface(Dims d, W6Args A, W6Work W, const float *__restrict__ delz, float dtcld, W6Tiles tl, int k0)
 {
     W6_COLUMN_INDEX
     const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
@@ -545,7 +562,7 @@ template <bool FIRST>
 __global__ void __launch_bounds__(256)
 k_w6_prep(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ q,
           float *__restrict__ qc, float *__restrict__ qi, float *__restrict__ qr, float *__restrict__ qs, float *__restrict__ qg,
-          const float *__restrict__ den, const float *__restrict__ p, int i0, int i1, int j0, int k0, int km, int nrow)
+          const float *__restrict__ den, const float *__restrict__ p, W6Tiles tl, int k0, int km)
 {
     W6_CELL_INDEX
     const int c = d.idx(i, k, j);
@@ -579,7 +596,7 @@ k_w6_prep(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ th, 
 
 // per column: blockIdx.y = 0 rain, 1 snow + graupel
 __global__ void __launch_bounds__(64)
-k_w6_fall(Dims d, W6Consts C, W6Work W, const float *__restrict__ den, const float *__restrict__ delz, float dtcld, int i0, int i1, int j0, int k0, int km, int nrow)
+k_w6_fall(Dims d, W6Consts C, W6Work W, const float *__restrict__ den, const float *__restrict__ delz, float dtcld, W6Tiles tl, int k0, int km)
 {
     W6_COLUMN_INDEX
     const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
@@ -597,7 +614,7 @@ k_w6_fall(Dims d, W6Consts C, W6Work W, const float *__restrict__ den, const flo
 // per cell, between the falls
 __global__ void __launch_bounds__(256)
 k_w6_melt(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ qi, float *__restrict__ qr, float *__restrict__ qs, float *__restrict__ qg,
-          const float *__restrict__ den, const float *__restrict__ p, float dtcld, int i0, int i1, int j0, int k0, int km, int nrow)
+          const float *__restrict__ den, const float *__restrict__ p, float dtcld, W6Tiles tl, int k0, int km)
 {
     W6_CELL_INDEX
     const int c = d.idx(i, k, j);
@@ -643,7 +660,7 @@ k_w6_melt(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ qi, 
 // per column: the fall of cloud ice and the surface sums of this minor loop (:659-697)
 __global__ void __launch_bounds__(64)
 k_w6_icefall(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ den, const float *__restrict__ delz, float dtcld,
-             int i0, int i1, int j0, int k0, int km, int nrow)
+             W6Tiles tl, int k0, int km)
 {
     W6_COLUMN_INDEX
     const int c0 = d.idx(i, k0, j), c2 = i + d.nx * j;
@@ -666,7 +683,7 @@ template <bool LAST>
 __global__ void __launch_bounds__(256)
 k_w6_rates(Dims d, W6Consts C, W6Args A, W6Work W, float *__restrict__ th, const float *__restrict__ pii, float *__restrict__ q,
            float *__restrict__ qc, float *__restrict__ qi, float *__restrict__ qr, float *__restrict__ qs, float *__restrict__ qg,
-           const float *__restrict__ den, const float *__restrict__ p, float dtcld, int i0, int i1, int j0, int k0, int km, int nrow)
+           const float *__restrict__ den, const float *__restrict__ p, float dtcld, W6Tiles tl, int k0, int km)
 {
     W6_CELL_INDEX
     const int c = d.idx(i, k, j);
@@ -909,7 +926,7 @@ k_w6_rates(Dims d, W6Consts C, W6Args A, W6Work W, float *__restrict__ th, const
 
 // mp_driver.f90:587-595: REAL(8) accumulators += this call's REAL(4) precipitation / snowfall / graupel
 __global__ void k_w6_accumulate(Dims d, W6Work W, double *__restrict__ precip_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
-                                int i0, int i1, int j0, int nrow)
+                                W6Tiles tl)
 {
     W6_COLUMN_INDEX
     const int c2 = i + d.nx * j;
@@ -988,9 +1005,31 @@ int icar_wsm6_init_run(icar_hip_ctx *c)
 
 int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte)
 {
+    const int tile[1][4] = {{its, ite, jts, jte}};
+    return icar_wsm6_run_tiles(c, dt, 1, tile, kts, kte);
+}
+
+// up to 4 non-overlapping tiles {its, ite, jts, jte} in ONE sequence of launches (process_halo's strips, mp_driver.f90:609-658)
+int icar_wsm6_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte)
+{
     if (!c->wsm6 || !c->wsm6->ready) { icar_set_error("wsm6: call icar_hip_wsm6_init first"); return 1; }
-    if (its < c->ims || ite > c->ime || jts < c->jms || jte > c->jme || kts < c->kms || kte > c->kme) { icar_set_error("wsm6: tile outside memory bounds"); return 1; }
-    if (ite < its || jte < jts) return 0;
+    if (ntiles < 0 || ntiles > 4) { icar_set_error("wsm6: 0..4 tiles per call"); return 1; }
+    if (kts < c->kms || kte > c->kme) { icar_set_error("wsm6: tile outside memory bounds"); return 1; }
+    W6Tiles tl; tl.n = 0; tl.coff[0] = 0; tl.boff[0] = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int its = tiles[t][0], ite = tiles[t][1], jts = tiles[t][2], jte = tiles[t][3];
+        if (its < c->ims || ite > c->ime || jts < c->jms || jte > c->jme) { icar_set_error("wsm6: tile outside memory bounds"); return 1; }
+        if (ite < its || jte < jts) continue;
+        const int n = tl.n, i0 = its - c->ims, i1 = ite - c->ims, j0 = jts - c->jms, nrow = jte - jts + 1;
+        for (int o = 0; o < n; ++o)                                   // columns are updated in place: two tiles on one column would race
+            if (i0 <= tl.i1[o] && i1 >= tl.i0[o] && j0 < tl.j0[o] + tl.nrow[o] && j0 + nrow > tl.j0[o]) { icar_set_error("wsm6: tiles of one call must not overlap"); return 1; }
+        tl.i0[n] = i0; tl.i1[n] = i1; tl.j0[n] = j0; tl.nrow[n] = nrow;
+        tl.coff[n + 1] = tl.coff[n] + (i1 - i0 + 1) * nrow;
+        tl.boff[n + 1] = tl.boff[n] + ((i1 - i0 + W6_TC) / W6_TC) * nrow;
+        ++tl.n;
+    }
+    if (tl.n == 0) return 0;
+    for (int t = tl.n; t < 4; ++t) { tl.i0[t] = tl.i1[t] = tl.j0[t] = 0; tl.nrow[t] = 0; tl.coff[t + 1] = tl.coff[tl.n]; tl.boff[t + 1] = tl.boff[tl.n]; }
     const int km = kte - kts + 1;
     if (km < 4 || km > W6_MAXK) { icar_set_error("wsm6: 4..64 levels in this build"); return 1; }
     float *th = icar_field_f(c, ICAR_F_POTENTIAL_TEMPERATURE), *q = icar_field_f(c, ICAR_F_WATER_VAPOR);
@@ -1024,29 +1063,29 @@ int icar_wsm6_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     HIPCHK(hipMemsetAsync(W.rain, 0, n2 * sizeof(float), c->stream));          // process_subdomain: precipitation = 0, snowfall = 0, graupel = 0
     HIPCHK(hipMemsetAsync(W.snow, 0, n2 * sizeof(float), c->stream));
     HIPCHK(hipMemsetAsync(W.graupel, 0, n2 * sizeof(float), c->stream));
-    const int i0 = its - c->ims, i1 = ite - c->ims, j0 = jts - c->jms, k0 = kts - c->kms, nyt = jte - jts + 1;
-    const long long ncol = (long long)(ite - its + 1) * nyt, ncell = ncol * km;
+    const int k0 = kts - c->kms;
+    const long long ncol = tl.coff[tl.n], ncell = ncol * km;
     const dim3 gc((unsigned)((ncell + 255) / 256)), bc(256), g2((unsigned)((ncol + 63) / 64)), b2(64);
     const bool wave_falls = km + 1 <= 64;                       // lane = level; taller columns: one thread per column
-    const dim3 gt((ite - its + 1 + W6_TC - 1) / W6_TC, nyt, 1);
+    const dim3 gt(tl.boff[tl.n], 1, 1);
     const size_t tile_lds = 8 * (size_t)km * (W6_TC + 1) * sizeof(float);
     if (wave_falls && tile_lds > 64 * 1024)                     // more than 61 levels: above HIP's default dynamic-LDS limit (160 kB per CU on gfx950)
         HIPCHK(hipFuncSetAttribute((const void *)k_w6_fall_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
-    if (wave_falls) hipLaunchKernelGGL(k_w6_zi, g2, b2, 0, c->stream, c->d, dz, W.zi, i0, i1, j0, k0, km, nyt);
+    if (wave_falls) hipLaunchKernelGGL(k_w6_zi, g2, b2, 0, c->stream, c->d, dz, W.zi, tl, k0, km);
     for (int loop = 1; loop <= loops; ++loop) {
-        if (loop == 1) hipLaunchKernelGGL((k_w6_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
-        else           hipLaunchKernelGGL((k_w6_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, i0, i1, j0, k0, km, nyt);
-        if (wave_falls) hipLaunchKernelGGL(k_w6_fall_tile, dim3(gt.x, gt.y, 2), dim3(W6_NT), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 0);
-        else hipLaunchKernelGGL(k_w6_fall, dim3(g2.x, 2), b2, 0, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
-        hipLaunchKernelGGL(k_w6_melt, gc, bc, 0, c->stream, c->d, S->c, A, W, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
+        if (loop == 1) hipLaunchKernelGGL((k_w6_prep<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, tl, k0, km);
+        else           hipLaunchKernelGGL((k_w6_prep<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, tl, k0, km);
+        if (wave_falls) hipLaunchKernelGGL(k_w6_fall_tile, dim3(gt.x, 1, 2), dim3(W6_NT), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, tl, k0, km, 0);
+        else hipLaunchKernelGGL(k_w6_fall, dim3(g2.x, 2), b2, 0, c->stream, c->d, S->c, W, den, dz, dtcld, tl, k0, km);
+        hipLaunchKernelGGL(k_w6_melt, gc, bc, 0, c->stream, c->d, S->c, A, W, qi, qr, qs, qg, den, p, dtcld, tl, k0, km);
         if (wave_falls) {
-            hipLaunchKernelGGL(k_w6_fall_tile, gt, dim3(W6_NT), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, i0, i1, j0, k0, km, 2);
-            hipLaunchKernelGGL(k_w6_surface, g2, b2, 0, c->stream, c->d, A, W, dz, dtcld, i0, i1, j0, k0, nyt);
-        } else hipLaunchKernelGGL(k_w6_icefall, g2, b2, 0, c->stream, c->d, S->c, A, W, den, dz, dtcld, i0, i1, j0, k0, km, nyt);
-        if (loop == loops) hipLaunchKernelGGL((k_w6_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
-        else               hipLaunchKernelGGL((k_w6_rates<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, i0, i1, j0, k0, km, nyt);
+            hipLaunchKernelGGL(k_w6_fall_tile, gt, dim3(W6_NT), tile_lds, c->stream, c->d, S->c, W, den, dz, dtcld, tl, k0, km, 2);
+            hipLaunchKernelGGL(k_w6_surface, g2, b2, 0, c->stream, c->d, A, W, dz, dtcld, tl, k0);
+        } else hipLaunchKernelGGL(k_w6_icefall, g2, b2, 0, c->stream, c->d, S->c, A, W, den, dz, dtcld, tl, k0, km);
+        if (loop == loops) hipLaunchKernelGGL((k_w6_rates<true>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, tl, k0, km);
+        else               hipLaunchKernelGGL((k_w6_rates<false>), gc, bc, 0, c->stream, c->d, S->c, A, W, th, pii, q, qc, qi, qr, qs, qg, den, p, dtcld, tl, k0, km);
     }
-    hipLaunchKernelGGL(k_w6_accumulate, g2, b2, 0, c->stream, c->d, W, pa, sa, ga, i0, i1, j0, nyt);
+    hipLaunchKernelGGL(k_w6_accumulate, g2, b2, 0, c->stream, c->d, W, pa, sa, ga, tl);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -15,7 +15,7 @@ module icar_hip
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
             hip_diagnostic_update, hip_diagnostic_update_parts, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
-            hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_winds_valid, hip_max_courant_prefetch, &
+            hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_wsm6_tiles, hip_winds_valid, hip_max_courant_prefetch, &
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
@@ -117,6 +117,10 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_wsm6(ctx, dt, its, ite, jts, jte, kts, kte) bind(C, name="icar_hip_wsm6")
        import; type(c_ptr), value :: ctx; real(c_float), value :: dt; integer(c_int), value :: its, ite, jts, jte, kts, kte
+     end function
+     integer(c_int) function icar_hip_wsm6_tiles(ctx, dt, ntiles, tiles, kts, kte) bind(C, name="icar_hip_wsm6_tiles")
+       import; type(c_ptr), value :: ctx; real(c_float), value :: dt; integer(c_int), value :: ntiles, kts, kte
+       integer(c_int), intent(in) :: tiles(4,*)
      end function
      integer(c_int) function icar_hip_wsm3_init(ctx) bind(C, name="icar_hip_wsm3_init")
        import; type(c_ptr), value :: ctx
@@ -357,6 +361,15 @@ contains
     real, intent(in) :: dx
     real(c_float), intent(in) :: dz_levels(:)
     call check(icar_hip_max_courant_prefetch(ctx%p, real(dx,c_float), dz_levels), "max_courant_prefetch")
+  end subroutine
+
+  !> process_halo's strips for WSM6 in one sequence of launches: tiles(1:4, t) = its, ite, jts, jte of strip t
+  subroutine hip_wsm6_tiles(ctx, dt, tiles, kts, kte)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dt
+    integer(c_int), intent(in) :: tiles(:,:)
+    integer, intent(in) :: kts, kte
+    call check(icar_hip_wsm6_tiles(ctx%p, real(dt,c_float), int(size(tiles,2),c_int), tiles, int(kts,c_int), int(kte,c_int)), "wsm6_tiles")
   end subroutine
 
   !> .true. while the Courant winds of the last hip_setup_winds still belong to the state

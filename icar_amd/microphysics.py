@@ -109,13 +109,15 @@ def mp(domain, options, dt_in, halo=None, subset=None):
             # a tile narrower than 2*halo makes the west/east (or south/north) strips overlap: the reference then runs
             # those columns once per strip, one strip after the other -- a single batched launch would race on them
             overlapping = (g.ite - g.its + 1 < 2 * h) or (g.jte - g.jts + 1 < 2 * h)
-            if options.physics.microphysics in (kMP_THOMPSON, kMP_SB04) and not overlapping:
-                # process_halo's four strips in one launch (icar_hip_thompson_tiles / icar_hip_mp_simple_tiles)
+            if options.physics.microphysics in (kMP_THOMPSON, kMP_SB04, kMP_WSM6) and not overlapping:
+                # process_halo's four strips in one launch (icar_hip_thompson_tiles / icar_hip_mp_simple_tiles / icar_hip_wsm6_tiles)
                 tiles = [t for t in tiles if t[1] >= t[0] and t[3] >= t[2]]
                 arr = ((ctypes.c_int * 4) * len(tiles))(*[(ctypes.c_int * 4)(*t) for t in tiles])
                 if tiles and options.physics.microphysics == kMP_THOMPSON:
                     check(lib().icar_hip_thompson_tiles(domain.ctx, ctypes.c_float(mp_dt), len(tiles), arr, g.kts, kte,
                                                         g.ids, g.ide, g.jds, g.jde, g.kds, g.kde), "icar_hip_thompson_tiles")
+                elif tiles and options.physics.microphysics == kMP_WSM6:
+                    check(lib().icar_hip_wsm6_tiles(domain.ctx, ctypes.c_float(mp_dt), len(tiles), arr, g.kts, kte), "icar_hip_wsm6_tiles")
                 elif tiles:
                     check(lib().icar_hip_mp_simple_tiles(domain.ctx, ctypes.c_float(mp_dt), len(tiles), arr, g.kts, kte, None),
                           "icar_hip_mp_simple_tiles")

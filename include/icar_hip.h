@@ -196,6 +196,9 @@ int icar_hip_wsm3(icar_hip_ctx *ctx, float dt, int its, int ite, int jts, int jt
  * GRAUPEL_ACC as mp_driver.f90:587-595 does.  4..64 levels. */
 int icar_hip_wsm6_init(icar_hip_ctx *ctx);
 int icar_hip_wsm6(icar_hip_ctx *ctx, float dt, int its, int ite, int jts, int jte, int kts, int kte);
+/* process_halo's strips (src/physics/mp_driver.f90:609-658) in ONE sequence of launches over up to 4 non-overlapping tiles
+ * {its,ite,jts,jte} (as icar_hip_mp_tiles returns them), like icar_hip_thompson_tiles / icar_hip_mp_simple_tiles */
+int icar_hip_wsm6_tiles(icar_hip_ctx *ctx, float dt, int ntiles, const int tiles[][4], int kts, int kte);
 
 /* ---- T2: CFL reduction for compute_dt (src/main/time_step.f90:217-330, cfl_strictness 3) -----
  * out = max over the tile of max(|u_i|,|u_i+1|)/dx + max(|v_j|,|v_j+1|)/dx + max(|w_k|,|w_k-1|)/dz_levels(k) */
