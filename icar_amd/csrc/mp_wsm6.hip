@@ -573,6 +573,7 @@ k_w6_prep(Dims d, W6Consts C, W6Args A, W6Work W, const float *__restrict__ th, 
         float qc_ = qc[c];
         qc_ = mx(qc_, 0.0f); qr_ = mx(qr_, 0.0f); qi_ = mx(qi_, 0.0f); qs_ = mx(qs_, 0.0f); qg_ = mx(qg_, 0.0f);        // :373-381
         qc[c] = qc_; qr[c] = qr_; qi[c] = qi_; qs[c] = qs_; qg[c] = qg_;
+        if (k == k0) { const int c2 = i + d.nx * j; W.rain[c2] = 0.f; W.snow[c2] = 0.f; W.graupel[c2] = 0.f; }   // process_subdomain: precipitation = 0 ...
         W.cpm[c] = A.cpd * (1.f - mx(q_, A.qmin)) + mx(q_, A.qmin) * A.cpv;   // cpmcal :353
         W.xl[c] = A.xlv0 - C.xlv1 * (t - A.t0c);                               // xlcal :354
         W.t[c] = t;
@@ -1060,9 +1061,8 @@ int icar_wsm6_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[]
     float dtcld = A.delt / (float)loops;
     if (A.delt <= W6_dtcldcr) dtcld = A.delt;
     ScopedTimer tm(c, "mp");
-    HIPCHK(hipMemsetAsync(W.rain, 0, n2 * sizeof(float), c->stream));          // process_subdomain: precipitation = 0, snowfall = 0, graupel = 0
-    HIPCHK(hipMemsetAsync(W.snow, 0, n2 * sizeof(float), c->stream));
-    HIPCHK(hipMemsetAsync(W.graupel, 0, n2 * sizeof(float), c->stream));
+    // (the call's REAL(4) surface sums are zeroed per column by k_w6_prep: calls on disjoint tiles -- the strips and the interior on
+    // the context's two streams -- share no scratch)
     const int k0 = kts - c->kms;
     const long long ncol = tl.coff[tl.n], ncell = ncol * km;
     const dim3 gc((unsigned)((ncell + 255) / 256)), bc(256), g2((unsigned)((ncol + 63) / 64)), b2(64);
