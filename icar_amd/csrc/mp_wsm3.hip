@@ -75,6 +75,7 @@ k_wsm3_prep(Dims d, wsm3_consts C, wsm3_args A, W3Work W, const float *__restric
     const w3_sat S = wsm3_sat_coeffs(&A);
     float t, qci_ = qci[c], qrs_ = qrs[c];
     if (FIRST) {
+        if (k == k0) { const int c2 = i + d.nx * j; W.rain[c2] = 0.f; W.snow[c2] = 0.f; }      // process_subdomain: precipitation = 0, snowfall = 0
         t = th[c] * pii[c];
         float cpm, xl;
         wsm3_level_init(&C, &A, q[c], t, &qci_, &qrs_, &cpm, &xl);
@@ -380,8 +381,8 @@ int icar_wsm3_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte,
     int loops; const float dtcld = wsm3_dtcld(&A, &loops);
     W3Work W = {S->t, S->cpm, S->xl, S->denfac, S->qs, S->rh, S->vt, S->denqrs, S->vti, S->denqci, S->rain, S->snow, S->zi};
     ScopedTimer tm(c, "mp");
-    HIPCHK(hipMemsetAsync(S->rain, 0, (size_t)c->d.nx * c->d.ny * sizeof(float), c->stream));     // process_subdomain: precipitation = 0
-    HIPCHK(hipMemsetAsync(S->snow, 0, (size_t)c->d.nx * c->d.ny * sizeof(float), c->stream));
+    // (the call's REAL(4) surface sums are zeroed per column by k_wsm3_prep: calls on disjoint tiles -- the strips and the interior on
+    // the context's two streams -- share no scratch)
     const int i0 = its - c->ims, i1 = ite - c->ims, j0 = jts - c->jms, k0 = kts - c->kms, nxb = (ite - its + 1 + 63) / 64, nyt = jte - jts + 1;
     const dim3 gc(nxb, (km + 3) / 4, nyt), bc(64, 4), g2(nxb, nyt), b2(64);
     hipLaunchKernelGGL(k_wsm3_zi, g2, b2, 0, c->stream, c->d, dz, S->zi, i0, i1, j0, k0, km);

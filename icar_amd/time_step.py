@@ -85,8 +85,8 @@ def mp_and_halo(domain, options, dt, overlap=True, prepare_advection=True, besid
     prepare_advection: also launch the wind setup of the advect() that follows, on the main stream beside the interior.
     beside_interior: further callables whose launches neither read what the microphysics writes nor write what it reads
     (the w_real part of diagnostic_update); they go out on the main stream beside the interior too, or right away without overlap."""
-    from .constants import kMP_THOMPSON, kMP_SB04, kMP_WSM6, kADV_UPWIND, kADV_MPDATA
-    overlap = overlap and options.physics.microphysics in (kMP_THOMPSON, kMP_SB04, kMP_WSM6)   # WSM3 re-zeroes whole-tile scratch per call
+    from .constants import kADV_UPWIND, kADV_MPDATA
+    overlap = overlap and options.physics.microphysics != 0    # every scheme's calls on disjoint tiles share no scratch
     if overlap:
         domain.aux_fork()
     mp(domain, options, dt, halo=1)                            # :512

@@ -44,7 +44,10 @@ def run(oracle, k, mode, split=False):
                                c["pressure"], c["dz_mass"], a18, *rb, 2, nx - 1, 2, ny - 1, 1, nz) == 0
             acc_r += rb[0]; acc_s += rb[2]
             B["potential_temperature"] -= np.float32(k["cool"])
-            if split:
+            if split == "two_streams":
+                from icar_amd.time_step import mp_and_halo
+                mp_and_halo(d, opt, dt, prepare_advection=False)      # strips on the main stream, interior on the second one
+            elif split:
                 mp(d, opt, dt, halo=1); mp(d, opt, dt, subset=1)      # strips + interior == whole tile
             else:
                 mp(d, opt, dt)
@@ -61,7 +64,7 @@ def run(oracle, k, mode, split=False):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_wsm3_bit_exact_vs_oracle_device_math(oracle, case):
-    got, want, pa, sa, acc_r, acc_s = run(oracle, CASES[case], mode=1, split=(case == "warm_rain"))
+    got, want, pa, sa, acc_r, acc_s = run(oracle, CASES[case], mode=1, split={"warm_rain": True, "snow_at_surface": "two_streams"}.get(case, False))
     for n in want:
         assert np.array_equal(got[n].view(np.int32), want[n].view(np.int32)), f"{n}: {(got[n] != want[n]).sum()} cells differ"
     assert np.array_equal(pa, acc_r) and np.array_equal(sa, acc_s) and acc_r.max() > (0.5 if "serial" not in case else 0.0)

@@ -59,7 +59,7 @@ def test_mp_and_halo_orders_strips_exchange_interior(monkeypatch):
     d = _FakeDomain()
     time_step.mp_and_halo(d, opt, 10.0, prepare_advection=False)
     assert d.log == ["aux_fork", "mp_halo", "halo_send", "aux_begin", "mp_subset", "aux_end", "aux_join", "halo_retrieve"]
-    opt.physics.microphysics = kMP_WSM3                     # WSM3 zeroes whole-tile scratch per call: stays on one stream
+    opt.physics.microphysics = 0                            # no microphysics: nothing to put on a second stream
     d = _FakeDomain()
     time_step.mp_and_halo(d, opt, 10.0)
     assert d.log == ["mp_halo", "halo_send", "mp_subset", "halo_retrieve"]
