@@ -26,7 +26,17 @@ const ThState *icar_thompson_host_state(icar_hip_ctx *c);
 namespace {
 // x**y for the positive bases the scheme uses: exp(y*log(x)) in FP64 (relative error ~1e-14, i.e. the
 // float result is the correctly rounded one with probability 1 - 1e-7).
-__device__ __forceinline__ double d_pow(double x, double y)
+// every kernel below holds `const DK K_ = d_consts();` (fp64_math.h): the log / exp coefficients stay in scalar registers
+#define d_exp(x) d_exp_k(K_, (x))
+#define d_log(x) d_log_k(K_, (x))
+#define d_pow(x, y) d_pow_k(K_, (x), (y))
+#define d_powf(x, y) d_powf_k(K_, (x), (y))
+#define d_pow_l(L, y) d_pow_l_k(K_, (L), (y))
+#define d_powf_l(L, y) d_powf_l_k(K_, (L), (y))
+#define d_pow10f(y) d_pow10f_k(K_, (y))
+#define d_expf(x) d_expf_k(K_, (x))
+#define d_log10f(x) d_log10f_k(K_, (x))
+__device__ __forceinline__ double d_pow_k(const DK &K_, double x, double y)
 {
     if (y == 0.0) return 1.0;
     if (x > 0.0) return d_exp(y * d_log(x));
@@ -35,18 +45,19 @@ __device__ __forceinline__ double d_pow(double x, double y)
     if (x == 0.0) return y > 0.0 ? 0.0 : __builtin_inf();
     return __builtin_nan("");
 }
-__device__ __forceinline__ float d_powf(float x, float y) { return (float)d_pow((double)x, (double)y); }
+__device__ __forceinline__ float d_powf_k(const DK &K_, float x, float y) { return (float)d_pow((double)x, (double)y); }
 // the same values from L = d_log(x) of a base x > 0 that several powers share (one logarithm instead of one per power)
-__device__ __forceinline__ double d_pow_l(double L, double y) { return (y == 0.0) ? 1.0 : d_exp(y * L); }
-__device__ __forceinline__ float d_powf_l(double L, float y) { return (float)d_pow_l(L, (double)y); }
+__device__ __forceinline__ double d_pow_l_k(const DK &K_, double L, double y) { return (y == 0.0) ? 1.0 : d_exp(y * L); }
+__device__ __forceinline__ float d_powf_l_k(const DK &K_, double L, float y) { return (float)d_pow_l(L, (double)y); }
 // 10.**y (REAL y): exp(y ln 10), the same evaluation d_pow makes with its log already folded
-__device__ __forceinline__ float d_pow10f(float y) { return y == 0.0f ? 1.0f : (float)d_exp((double)y * 2.30258509299404568402e+00); }
-__device__ __forceinline__ float d_expf(float x) { return (float)d_exp((double)x); }
-__device__ __forceinline__ float d_log10f(float x)
+__device__ __forceinline__ float d_pow10f_k(const DK &K_, float y) { return y == 0.0f ? 1.0f : (float)d_exp((double)y * 2.30258509299404568402e+00); }
+__device__ __forceinline__ float d_expf_k(const DK &K_, float x) { return (float)d_exp((double)x); }
+__device__ __forceinline__ float d_log10f_k(const DK &K_, float x)
 {
     if (x > 0.0f) return (float)(d_log((double)x) * 4.34294481903251816668e-01);   // log(x) / ln 10
     return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
 }
+
 
 /* 10.**nn with an INTEGER exponent: flang calls __powisf2 (repeated squaring) */
 __device__ __forceinline__ float powi10f(int b)
@@ -59,7 +70,7 @@ __device__ __forceinline__ float powi10f(int b)
 }
 
 /* decade-table index: :1562-1574 and siblings (REAL argument) */
-__device__ __forceinline__ int dec_index_f(float r, int n2)
+__device__ __forceinline__ int dec_index_f_slow(const DK &K_, float r, int n2)
 {
     const int nic = (int)lroundf(d_log10f(r));
     int n = nic - 1;
@@ -71,7 +82,7 @@ __device__ __forceinline__ int dec_index_f(float r, int n2)
 }
 
 /* same with a DOUBLE PRECISION argument (:1620-1627) */
-__device__ __forceinline__ int dec_index_d(double r, int n2)
+__device__ __forceinline__ int dec_index_d_slow(const DK &K_, double r, int n2)
 {
     const int nic = (int)lround(log10(r));
     int n = nic - 1;
@@ -98,18 +109,21 @@ __device__ __forceinline__ bool dec_fast(const ThState *__restrict__ T, float rf
     p = T->p10[ok ? D + TH_P10_OFF : TH_P10_OFF];
     return ok;
 }
-__device__ __forceinline__ int dec_index_f(const ThState *__restrict__ T, float r, int n2)
+__device__ __forceinline__ int dec_index_f_k(const DK &K_, const ThState *__restrict__ T, float r, int n2)
 {
     int D; float p;
     if (dec_fast(T, r, D, p)) return (int)(r / p) + 10 * (D - n2) - (D - n2);
-    return dec_index_f(r, n2);
+    return dec_index_f_slow(K_, r, n2);
 }
-__device__ __forceinline__ int dec_index_d(const ThState *__restrict__ T, double r, int n2)
+__device__ __forceinline__ int dec_index_d_k(const DK &K_, const ThState *__restrict__ T, double r, int n2)
 {
     int D; float p;
     if (r < 1.e37 && dec_fast(T, (float)r, D, p)) return (int)(r / (double)p) + 10 * (D - n2) - (D - n2);
-    return dec_index_d(r, n2);
+    return dec_index_d_slow(K_, r, n2);
 }
+
+#define dec_index_f(T, r, n2) dec_index_f_k(K_, (T), (r), (n2))
+#define dec_index_d(T, r, n2) dec_index_d_k(K_, (T), (r), (n2))
 
 /* x**3.0 with a PARAMETER exponent is expanded to multiplications by flang (verified: the tables are
  * bit-identical to the reference only with x*x*x) */
@@ -243,6 +257,8 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 // arguments come from the host so that nothing is folded at compile time: the value must be what a level computes at run time
 __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
 {
+    const DK K_ = d_consts();
+
     T->N0_exp_default = th_graupel_N0_exp(rg, xslw1);
     T->pw_cgg_obmg = d_powf(T->cgg[2] * T->ogg2 * T->ogg1, T->obmg);
     T->pw_ccg_obmr = d_powf(T->ccg[2] * T->ocg2, T->obmr);
@@ -254,10 +270,12 @@ __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
 // reference's loop alone -- so that a test can compare them value by value (icar_hip_thompson_dec_index)
 __global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__ rf, const double *__restrict__ rd, int n, int n2, int which, int *__restrict__ out)
 {
+    const DK K_ = d_consts();
+
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    if (rf) out[t] = which ? dec_index_f(rf[t], n2) : dec_index_f(T, rf[t], n2);
-    else    out[t] = which ? dec_index_d(rd[t], n2) : dec_index_d(T, rd[t], n2);
+    if (rf) out[t] = which ? dec_index_f_slow(K_, rf[t], n2) : dec_index_f(T, rf[t], n2);
+    else    out[t] = which ? dec_index_d_slow(K_, rd[t], n2) : dec_index_d(T, rd[t], n2);
 }
 }  // namespace
 
