@@ -38,12 +38,18 @@ namespace {
 #define d_log10f(x) d_log10f_k(K_, (x))
 __device__ __forceinline__ double d_pow_k(const DK &K_, double x, double y)
 {
-    if (y == 0.0) return 1.0;
-    if (x > 0.0) return d_exp(y * d_log(x));
-    // not reached by the scheme's positive bases; kept out of line of the hot code (ocml's pow is ~230 instructions per
-    // call site): 0**y = 0 / +inf like libm, a negative base gives NaN (Fortran: invalid for a REAL exponent)
-    if (x == 0.0) return y > 0.0 ? 0.0 : __builtin_inf();
-    return __builtin_nan("");
+    // every lane evaluates the positive-finite-base form (exp(0 * log x) is exactly 1, so y = 0 needs no case of its own);
+    // one never-taken branch then replaces the value where the base is not positive and finite -- not reached by the scheme's
+    // bases: 1 for y = 0, 0**y = 0 / +inf and (+inf)**y = +inf / 0 like libm, NaN for a negative base (Fortran: invalid for a
+    // REAL exponent) or a NaN.  (Written as if / else-if the special cases cost seven exec-mask instructions per call site.)
+    double r = d_exp(y * d_log(x));
+    if (!__builtin_amdgcn_class(x, 0x100 | 0x080)) {               // not (+normal or +subnormal)
+        if (y == 0.0) r = 1.0;
+        else if (x == 0.0) r = y > 0.0 ? 0.0 : __builtin_inf();
+        else if (x == __builtin_inf()) r = y > 0.0 ? __builtin_inf() : 0.0;
+        else r = __builtin_nan("");
+    }
+    return r;
 }
 __device__ __forceinline__ float d_powf_k(const DK &K_, float x, float y) { return (float)d_pow((double)x, (double)y); }
 // the same values from L = d_log(x) of a base x > 0 that several powers share (one logarithm instead of one per power)
