@@ -571,6 +571,13 @@ int icar_hip_thompson_dec_index(icar_hip_ctx *c, const float *r4, const double *
     return icar_thompson_dec_index_run(c, r4, r8, n, n2, which ? 1 : 0, out);
 }
 
+int icar_hip_thompson_math_probe(icar_hip_ctx *c, int op, int n, const double *x, const double *y, double *out)
+{
+    if (!c || !x || !out) { icar_set_error("thompson_math_probe: ctx, x and out are required"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_thompson_math_probe_run(c, op, n, x, y, out);
+}
+
 int icar_hip_thompson_table(icar_hip_ctx *c, const char *name, double *out, size_t capacity, size_t *count)
 {
     if (!c || !name) { icar_set_error("thompson_table: null argument"); return 1; }

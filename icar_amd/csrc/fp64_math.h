@@ -105,7 +105,7 @@ __device__ __forceinline__ double d_log_k(const DK &K, double x)
         : "+v"(ta), "+v"(tb) : "v"(w), "s"(K.lg[1]), "s"(K.lg[2]), "s"(K.lg[0]));
     const double t1 = w * ta, t2 = z * tb;
     const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
-    return dk * K.ln2_hi - ((hfsq - fma(s, hfsq + R, dk * K.ln2_lo)) - f);
+    return fma(dk, K.ln2_hi, -((hfsq - fma(s, hfsq + R, dk * K.ln2_lo)) - f));   // k ln2_hi is exact (32 trailing zero bits): the value of d_log's mul + sub
 }
 __device__ __forceinline__ double d_exp_k(const DK &K, double x)
 {

@@ -283,7 +283,37 @@ __global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__
     if (rf) out[t] = which ? dec_index_f_slow(K_, rf[t], n2) : dec_index_f(T, rf[t], n2);
     else    out[t] = which ? dec_index_d_slow(K_, rd[t], n2) : dec_index_d(T, rd[t], n2);
 }
+// The FP64 functions of the level code on n arguments: op 0 d_log(x), 1 d_exp(x), 2 d_pow(x, y), 3 d_powf((float)x, (float)y)
+// widened.  (x, y) come from the host so that nothing is folded at compile time.
+__global__ void k_thompson_math_probe(int op, int n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
+{
+    const DK K_ = d_consts();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double r;
+    if (op == 0) r = d_log(x[t]);
+    else if (op == 1) r = d_exp(x[t]);
+    else if (op == 2) r = d_pow(x[t], y[t]);
+    else r = (double)d_powf((float)x[t], (float)y[t]);
+    out[t] = r;
+}
 }  // namespace
+
+int icar_thompson_math_probe_run(icar_hip_ctx *c, int op, int n, const double *x, const double *y, double *out)
+{
+    if (op < 0 || op > 3 || (op >= 2 && !y)) { icar_set_error("math_probe: op must be 0..3 (y required for 2, 3)"); return 1; }
+    if (n <= 0) return 0;
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&dx, sizeof(double) * n)); HIPCHK(hipMalloc(&dout, sizeof(double) * n));
+    HIPCHK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    if (y) { HIPCHK(hipMalloc(&dy, sizeof(double) * n)); HIPCHK(hipMemcpy(dy, y, sizeof(double) * n, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_thompson_math_probe, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, n, dx, dy, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dout); if (dy) (void)hipFree(dy);
+    return 0;
+}
 
 int icar_thompson_dec_index_run(icar_hip_ctx *c, const float *rf, const double *rd, int n, int n2, int which, int *out)
 {

@@ -332,3 +332,86 @@ def test_decade_index_fast_form_equals_reference_loop():
             bad = np.flatnonzero(fast != slow)
             assert bad.size == 0, (is4, n2, bad.size, arr[bad[:5]], fast[bad[:5]], slow[bad[:5]])
     d.close()
+
+
+def test_fp64_transcendentals_of_the_level_code():
+    """DESIGN.md section 4's claim about the device's exp / log / x**y, measured: the level code evaluates them in FP64 (d_log_k,
+    d_exp_k: fp64_math.h) and rounds once to REAL(4).  Against x87 extended precision (64-bit significand): log and exp stay
+    within 1 ulp OF THE DOUBLE on 2e6 arguments each (so the REAL(4) they round to is the exactly rounded one except when
+    the exact value lies within 2^-29 relative of a rounding boundary), x**y = exp(y log x) within 2e-14 relative; the REAL(4)
+    results equal those of the oracle's definition -- libm's double function rounded once -- on all but <= 1e-5 of the
+    arguments; the special cases of x**y (y = 0, base 0 / inf / negative / NaN) are libm's."""
+    import ctypes
+    from icar_amd.capi import lib, check
+    if np.finfo(np.longdouble).nmant < 63:
+        pytest.skip("no extended-precision long double on this host")
+    c = ideal.make_case(12, 6, 12)
+    d = single_image_domain(c)
+    rng = np.random.default_rng(11)
+
+    def probe(op, x, y=None):
+        x = np.ascontiguousarray(x, np.float64); out = np.zeros(x.size, np.float64)
+        yp = None if y is None else np.ascontiguousarray(y, np.float64).ctypes.data_as(ctypes.c_void_p)
+        check(lib().icar_hip_thompson_math_probe(d.ctx, op, x.size, x.ctypes.data_as(ctypes.c_void_p), yp,
+                                                 out.ctypes.data_as(ctypes.c_void_p)), "math_probe")
+        return out
+
+    def ulps(dev, ref):                                        # error in units of the last place of the double nearest to ref
+        r64 = ref.astype(np.float64)
+        return np.abs((dev.astype(np.longdouble) - ref) / np.spacing(np.abs(r64)).astype(np.longdouble)).astype(np.float64)
+
+    n = 2_000_000
+    stats = {}
+    import warnings
+    warnings.filterwarnings("ignore", category=RuntimeWarning)     # over / underflow of the extended-precision references at the range ends
+    try:
+        # log: every binade of REAL(4), arguments next to 1 (cancellation), doubles that are not REAL(4) values
+        x = np.concatenate([(10.0 ** rng.uniform(-37.5, 38.0, n)).astype(np.float32).astype(np.float64),
+                            (1.0 + rng.uniform(-1e-3, 1e-3, 200_000)).astype(np.float32).astype(np.float64),
+                            np.array([1.0, np.nextafter(np.float32(1), np.float32(2)), np.nextafter(np.float32(1), np.float32(0)), 0.5, 2.0, 1e-38, 3e38]),
+                            10.0 ** rng.uniform(-300, 300, 200_000)])
+        dev = probe(0, x); ref = np.log(x.astype(np.longdouble))
+        e = ulps(dev, ref)
+        assert e.max() < 1.0, f"d_log: {e.max():.3f} ulp at x = {x[e.argmax()]!r}"
+        f_dev, f_lib = dev.astype(np.float32), np.log(x).astype(np.float32)
+        assert (f_dev != f_lib).mean() <= 1e-5 and (f_dev != ref.astype(np.float32)).mean() <= 1e-5
+        stats["log"] = {"n": int(x.size), "max_ulp_of_double": float(e.max()), "real4_differs_from_libm_double_rounded": int((f_dev != f_lib).sum()),
+                        "real4_differs_from_exactly_rounded": int((f_dev != ref.astype(np.float32)).sum())}
+        # exp: the REAL(4) range, and the products y * log x that x**y feeds it
+        x = np.concatenate([rng.uniform(-87.3, 88.7, n).astype(np.float32).astype(np.float64), rng.uniform(-700.0, 700.0, 500_000),
+                            np.array([0.0, -0.0, 1.0, -1.0, 1e-20, -1e-20, 709.0, -745.0])])
+        dev = probe(1, x); ref = np.exp(x.astype(np.longdouble))
+        ok = ref > np.longdouble(1e-300)                       # (below: the double itself is subnormal, ldexp rounds twice)
+        e = ulps(dev[ok], ref[ok])
+        assert e.max() < 1.0, f"d_exp: {e.max():.3f} ulp at x = {x[ok][e.argmax()]!r}"
+        assert dev[x == 0.0].tolist() == [1.0, 1.0]            # exp(+-0) is exactly 1: x**0 needs no case of its own
+        inr = np.abs(x) < 87.0
+        assert (dev[inr].astype(np.float32) != np.exp(x[inr]).astype(np.float32)).mean() <= 1e-5
+        stats["exp"] = {"n": int(x.size), "max_ulp_of_double": float(e.max()),
+                        "real4_differs_from_libm_double_rounded": int((dev[inr].astype(np.float32) != np.exp(x[inr]).astype(np.float32)).sum())}
+        # x**y with REAL(4) operands, in double (op 2) and rounded (op 3)
+        xb = (10.0 ** rng.uniform(-12.0, 12.0, n)).astype(np.float32).astype(np.float64)
+        yb = rng.uniform(-6.0, 6.0, n).astype(np.float32).astype(np.float64)
+        ref = np.power(xb.astype(np.longdouble), yb.astype(np.longdouble))
+        fin = (ref > np.longdouble(1e-37)) & (ref < np.longdouble(1e38))
+        dev = probe(2, xb, yb)
+        rel = np.abs((dev.astype(np.longdouble) - ref) / ref).astype(np.float64)[fin]
+        assert rel.max() < 2e-14, f"d_pow: relative error {rel.max():.2e}"
+        f_dev = probe(3, xb, yb).astype(np.float32)
+        assert np.array_equal(f_dev, dev.astype(np.float32))
+        assert (f_dev[fin] != np.power(xb, yb).astype(np.float32)[fin]).mean() <= 1e-5
+        assert (f_dev[fin] != ref.astype(np.float32)[fin]).mean() <= 1e-5
+        stats["pow"] = {"n": int(fin.sum()), "max_rel_err": float(rel.max()),
+                        "real4_differs_from_libm_double_rounded": int((f_dev[fin] != np.power(xb, yb).astype(np.float32)[fin]).sum()),
+                        "real4_differs_from_exactly_rounded": int((f_dev[fin] != ref.astype(np.float32)[fin]).sum())}
+        from util import parity_record
+        parity_record("thompson", "fp64 transcendentals of the level code vs x87 extended / libm double", stats)
+        # special cases: what libm's pow returns
+        xs = np.array([2.0, 0.0, np.inf, -1.5, np.nan, 0.0, 0.0, np.inf, np.inf, -2.0, 1.0, 3.0])
+        ys = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 2.5, -2.5, 1.5, -1.5, 0.5, 7.0, -0.0])
+        with np.errstate(all="ignore"):
+            want = np.power(xs, ys)
+        got = probe(2, xs, ys)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)]), (got, want)
+    finally:
+        d.close()
