@@ -47,17 +47,23 @@ def _setup(case, g, opt, comm):
 
 
 TH_NAMES = NAMES + ["cloud_ice_mass", "graupel_mass", "cloud_ice_number", "rain_number"]
+W6_NAMES = NAMES + ["cloud_ice_mass", "graupel_mass"]
+
+
+def _names(adv):
+    return TH_NAMES if adv.endswith("+thompson") else W6_NAMES if adv.endswith("+wsm6") else NAMES
 
 
 def _options(adv, case):
     from icar_amd.options import options_t
-    from icar_amd.constants import kADV_UPWIND, kADV_MPDATA, kMP_SB04, kMP_THOMPSON
+    from icar_amd.constants import kADV_UPWIND, kADV_MPDATA, kMP_SB04, kMP_THOMPSON, kMP_WSM6
     from icar_amd.microphysics import mp_var_request
     opt = options_t()
     thompson = adv.endswith("+thompson")
+    adv_full = adv
     adv = adv.split("+")[0]
     opt.physics.advection = kADV_UPWIND if adv == "upwind" else kADV_MPDATA
-    opt.physics.microphysics = kMP_THOMPSON if thompson else kMP_SB04
+    opt.physics.microphysics = kMP_THOMPSON if thompson else kMP_WSM6 if adv_full.endswith("+wsm6") else kMP_SB04
     opt.parameters.dz_levels = case["dz_levels"]; opt.parameters.dx = float(case["dx"])
     mp_var_request(opt)
     return opt
@@ -82,7 +88,7 @@ def _worker(rank, world, port, adv, q):
         d = _setup(case, g, opt, HaloComm(g, rank + 1))
         dt0 = update_dt(d, opt)                       # co_min over the tiles == the global CFL step
         n = step(d, NSTEPS * dt0 * 0.999, opt, diagnostics=False)
-        names = TH_NAMES if adv.endswith("+thompson") else NAMES
+        names = _names(adv)
         got = {k: d.get(k) for k in names}
         acc = d.get("accumulated_precipitation")
         d.close()
@@ -265,7 +271,7 @@ def test_tiled_iterative_winds_equals_tiled_oracle():
     _run(_worker_iw, 4, "upwind")
 
 
-@pytest.mark.parametrize("world,adv", [(2, "upwind"), (4, "upwind"), (4, "mpdata"), (2, "upwind+thompson"), (4, "upwind+thompson")])
+@pytest.mark.parametrize("world,adv", [(2, "upwind"), (4, "upwind"), (4, "mpdata"), (2, "upwind+thompson"), (4, "upwind+thompson"), (4, "upwind+wsm6")])
 def test_tiled_step_equals_single_tile_on_device(world, adv):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
