@@ -66,7 +66,12 @@ __device__ __forceinline__ void stb(rsrc_t r, int voff, int soff, float v) { __b
 // KB levels per thread (at most MP_NW waves per block), RHO: advect_density, FCT: limiter on,
 // PASS1: first corrective iteration (donor-cell pass inside); false: iord >= 3, where q2 == q (adv_mpdata.f90:393-402)
 template <int KB, bool RHO, bool FCT, bool PASS1>
-__global__ void __launch_bounds__(64 * MP_NW)
+// 248 VGPRs, not the 256 two waves per SIMD could have (the attribute counts half of gfx90a+'s unified file: 124 -> 248).  The
+// 248 blocks of a launch hold their CUs for the whole kernel, so whatever the host issues on the second stream beside the
+// advection (whole-field forcing, the CFL reduction of the next update_dt) can only run in what these waves leave: with 2 x 248
+// of a SIMD's 512 registers taken, one more wave of <= 16 VGPRs fits and those streaming kernels run concurrently; at 254 (what
+// the allocator takes if allowed) they wait for the launch to end -- the advection alone is then 5 % faster, the step 2 % slower.
+__global__ void __launch_bounds__(64 * MP_NW) __attribute__((amdgpu_num_vgpr(124)))
 k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                const float *__restrict__ Ug, const float *__restrict__ Vg, const float *__restrict__ Wg, const float *__restrict__ Wzg,
                const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dzg, int clen, int ntile, int nchunk, int nscal, int nkr, int kstore)
