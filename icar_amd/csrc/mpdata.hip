@@ -103,7 +103,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         int spin = 0;                                                                                                      \
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_flag[e][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < seq) { \
             __builtin_amdgcn_s_sleep(1);                  /* 0, 1, 3: the same time */                                                                            \
-            if (++spin > (1 << 22)) __builtin_trap();              /* a lost neighbour must not hang the device */          \
+            if (++spin > (1 << 26)) __builtin_trap();              /* a lost neighbour must not hang the device */          \
         }                                                                                                                  \
     }
 #define MP_WAIT(e, seq)                                                                                                    \
