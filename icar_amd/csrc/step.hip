@@ -65,23 +65,33 @@ k_diag_thermo(Dims d, const float *__restrict__ p, const float *__restrict__ th,
     if (v_mass) v_mass[c] = (v[c + d.sj] + v[c]) / 2;                                                       // :108
 }
 
-// w_real (:165-194): real vertical motion on interior cells, k-sequential through lastw
-__global__ void __launch_bounds__(64)
+// w_real (:165-194): real vertical motion on interior cells, k-sequential through lastw.
+// At most 16 VGPRs (the attribute counts half of gfx90a+'s unified file) and no unrolling: the host issues this kernel beside the
+// MPDATA launch, whose persistent blocks leave exactly one more wave of 16 registers per SIMD (mpdata.hip).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(8)))
 k_diag_wreal(Dims d, const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
              const float *__restrict__ dzdx, const float *__restrict__ dzdy, const float *__restrict__ jaco,
              float *__restrict__ w_real)
 {
     const int i = 1 + blockIdx.x * 64 + threadIdx.x, j = 1 + blockIdx.y;
     if (i >= d.nx - 1) return;
-    float lastw = 0.0f;
+    // raw buffer accesses: descriptor + per-lane byte offset (the column) + scalar byte offset (row and level), so that an
+    // address costs one VGPR, not two per array (fields of 2 GiB or more are refused by the host)
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    auto mk = [](const float *p) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, -1, 0x00020000); };
+    const rsrc_t ru = mk(u), rv = mk(v), rw = mk(w), rdx = mk(dzdx), rdy = mk(dzdy), rj = mk(jaco), ro = mk(w_real);
+    auto ld = [](rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); };
+    const int vi = 4 * i;
     const int nxu = d.nx + 1;
+    float lastw = 0.0f;
+#pragma unroll 1
     for (int k = 0; k < d.nz; ++k) {
-        const int c = d.idx(i, k, j);
-        const int cu = i + nxu * (k + d.nz * j);
-        const float uw0 = u[cu] * dzdx[cu], uw1 = u[cu + 1] * dzdx[cu + 1];          // uw(i), uw(i+1)
-        const float vw0 = v[c] * dzdy[c], vw1 = v[c + d.sj] * dzdy[c + d.sj];        // vw(j), vw(j+1)
-        const float currw = w[c];
-        w_real[c] = (uw0 + uw1) * 0.5f + (vw0 + vw1) * 0.5f + jaco[c] * (lastw + currw) * 0.5f;
+        const int sc = 4 * d.idx(0, k, j), scu = 4 * (nxu * (k + d.nz * j));     // wave-uniform
+        const float uw0 = ld(ru, vi, scu) * ld(rdx, vi, scu), uw1 = ld(ru, vi, scu + 4) * ld(rdx, vi, scu + 4);   // uw(i), uw(i+1)
+        const float vw0 = ld(rv, vi, sc) * ld(rdy, vi, sc), vw1 = ld(rv, vi, sc + 4 * d.sj) * ld(rdy, vi, sc + 4 * d.sj);   // vw(j), vw(j+1)
+        const float currw = ld(rw, vi, sc);
+        const float r = (uw0 + uw1) * 0.5f + (vw0 + vw1) * 0.5f + ld(rj, vi, sc) * (lastw + currw) * 0.5f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), ro, vi, sc, 0);
         lastw = currw;
     }
 }
@@ -211,6 +221,7 @@ int icar_diagnostic_update_run(icar_hip_ctx *c, int parts)
         float *wr = icar_field_f(c, ICAR_F_W_REAL, false);
         if (!wr) return 1;
         ScopedTimer t(c, "diag");
+        if ((size_t)(c->d.nx + 1) * c->d.nz * (c->d.ny + 1) * sizeof(float) >= ((size_t)1 << 31)) { icar_set_error("diagnostic_update: a field of 2 GiB or more is not supported (32-bit buffer offsets)"); return 1; }
         dim3 g2((c->d.nx - 2 + 63) / 64, c->d.ny - 2), b2(64);
         hipLaunchKernelGGL(k_diag_wreal, g2, b2, 0, c->stream, c->d, u, v, w, dzdx, dzdy, jaco, wr);
     }

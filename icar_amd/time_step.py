@@ -120,16 +120,21 @@ _FORCING_BESIDE_ADVECT = ("u", "v", "w", "pressure")
 def substep(domain, options, dt, forced=None, diagnostics=True, enforce=False, prefetch_dt=True):
     """One pass of time_step.f90:474-539: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve ->
     advect -> apply_forcing (-> enforce_limits), with the streaming kernels that do not depend on the two heavy ones issued
-    beside them: the w_real diagnostic (read by WSM3 and the output only) beside the interior microphysics, the whole-field
-    forcing of u, v, w, pressure on the second stream beside the advection (which works from the Courant winds set up
-    before), followed there by the CFL reduction of the next update_dt (the library discards it if anything writes u, v, w
-    before it is asked for).  Same launches, same operands, same results as the plain sequence."""
+    beside them: the wind setup of advect() beside the interior microphysics (mp_and_halo); on the second stream beside the
+    advection (which works from the Courant winds set up before, and whose blocks leave room for one small wave per SIMD) the
+    w_real diagnostic (read by WSM3 and the output only: winds, slopes, jacobian -- nothing the two heavy kernels write), then
+    the whole-field forcing of u, v, w, pressure, then the CFL reduction of the next update_dt (the library discards it if
+    anything writes u, v, w before it is asked for).  Same launches, same operands, same results as the plain sequence."""
     from .constants import ADVECTION_ORDER, kMP_WSM3
     beside = ()
+    wreal_later = False
     if diagnostics:
         if options.physics.microphysics != kMP_WSM3:           # WSM3 reads w_real
             domain.diagnostic_update(parts=1)                  # :474 (exner, density, ... before the microphysics)
-            beside = (lambda: domain.diagnostic_update(parts=2),)
+            if dt > 1e-3:
+                wreal_later = True                             # beside the advection, below
+            else:
+                beside = (lambda: domain.diagnostic_update(parts=2),)
         else:
             domain.diagnostic_update()
     if dt > 1e-3:                                              # :483
@@ -137,12 +142,14 @@ def substep(domain, options, dt, forced=None, diagnostics=True, enforce=False, p
         aside = [f for f in (forced or []) if not f[1] and f[0] in _FORCING_BESIDE_ADVECT]
         rest = [f for f in (forced or []) if f not in aside]
         cfl_ahead = prefetch_dt and int(options.parameters.cfl_strictness) in (3, 4)
-        if aside or cfl_ahead:
+        if aside or cfl_ahead or wreal_later:
             domain.aux_fork()                                  # the second stream starts from the state BEFORE the advection
         advect(domain, options, dt)                            # :529
-        if aside or cfl_ahead:
+        if aside or cfl_ahead or wreal_later:
             domain.aux_begin()
             try:
+                if wreal_later:
+                    domain.diagnostic_update(parts=2)          # :165-194, from the winds of this step (before their forcing)
                 if aside:
                     domain.apply_forcing(dt, aside)            # :534, the part that does not wait for the advection
                 if cfl_ahead:
