@@ -209,7 +209,7 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     }
 }
 
-struct ThTiles { int n, i0[4], i1[4], j0[4], ib0[4], nbx[4], off[5], xcd_run; };
+struct ThTiles { int n, i0[4], i1[4], j0[4], j1[4], tall[4], ib0[4], nbx[4], off[5], xcd_run; };
 
 // cpb whole columns per block (aligned to multiples of cpb in i), thread = level*cpb + column (thompson_lane.inc: BlockComm)
 // MAXT = largest block this instantiation is launched with.  Blocks of up to 512 threads (columns of up to 512 levels) get the
@@ -236,10 +236,13 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     while (t + 1 < tl.n && bid >= tl.off[t + 1]) ++t;
     const int local = bid - tl.off[t];
     const int i0 = tl.i0[t], i1 = tl.i1[t];
-    const int first = (tl.ib0[t] + local % tl.nbx[t]) * cpb;  // first column slot of this block (multiple of cpb)
-    BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nk, i0 - first, i1 - first);
-    const int j = tl.j0[t] + local / tl.nbx[t];
-    const int i = x.active ? first + x.col : max(i0, min(i1, first));
+    // a block's cpb column slots run along i (aligned to multiples of cpb), except in a tile ONE column wide (the west / east
+    // strips of process_halo), where they run along j: one busy column of six per block otherwise
+    const bool tall = tl.tall[t] != 0;
+    const int first = tall ? tl.j0[t] + local * cpb : (tl.ib0[t] + local % tl.nbx[t]) * cpb;
+    BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nk, tall ? 0 : i0 - first, tall ? tl.j1[t] - first : i1 - first);
+    const int j = tall ? (x.active ? first + x.col : first) : tl.j0[t] + local / tl.nbx[t];
+    const int i = tall ? i0 : (x.active ? first + x.col : max(i0, min(i1, first)));
     const int c = d.idx(i, k0 + x.k, j);
     const float pi_ = pii[c];
     float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
@@ -382,9 +385,11 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
         ThTiles tl; tl.n = nt_; tl.off[0] = 0;
         tl.xcd_run = 64;                 // consecutive column groups (and a few rows of them) per XCD turn
         for (int t = 0; t < nt_; ++t) {
-            tl.i0[t] = T4[t][0] - c->ims; tl.i1[t] = T4[t][1] - c->ims; tl.j0[t] = T4[t][2] - c->jms;
+            tl.i0[t] = T4[t][0] - c->ims; tl.i1[t] = T4[t][1] - c->ims; tl.j0[t] = T4[t][2] - c->jms; tl.j1[t] = T4[t][3] - c->jms;
             tl.ib0[t] = tl.i0[t] / cpb; tl.nbx[t] = tl.i1[t] / cpb - tl.ib0[t] + 1;
-            tl.off[t + 1] = tl.off[t] + tl.nbx[t] * (T4[t][3] - T4[t][2] + 1);
+            const int rows = T4[t][3] - T4[t][2] + 1;
+            tl.tall[t] = (tl.i0[t] == tl.i1[t] && rows > 1) ? 1 : 0;
+            tl.off[t + 1] = tl.off[t] + (tl.tall[t] ? (rows + cpb - 1) / cpb : tl.nbx[t] * rows);
         }
         if (nt <= 512)
             hipLaunchKernelGGL(k_thompson_pack<512>, dim3(tl.off[nt_]), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
