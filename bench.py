@@ -4,10 +4,13 @@
 A "step" is one pass of the hot path of time_step.f90:440-551 over the tile:
     update_dt (CFL reduction + co_min) -> diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1)
     -> halo_retrieve -> advect -> apply_forcing
-on the synthetic ideal case of SURVEY.md 8(d): 512x512x40 owned cells per GPU, MPDATA order 2 + FCT,
+on the synthetic ideal case of SURVEY.md 8(d): a 512x512x40 grid, MPDATA order 2 + FCT,
 Thompson microphysics (9 advected scalars) -- or mp_simple (5 scalars) with --mp simple.
-Inputs are resident in HBM before the timed region.  Scaling is weak: every rank owns a
-512x512x40 tile of a (512*ximages)x(512*yimages)x40 domain decomposed exactly like grid_obj.f90.
+Inputs are resident in HBM before the timed region.  Scaling is STRONG by default, as north_star asks ("cell-updates/sec on
+a synthetic 512x512x40 grid reported at 1, 2, 4 and 8 GPUs"): the global grid is fixed and decomposed over the N images exactly
+like grid_obj.f90:39-255 (BASELINE.json configs[2] is this grid as 2x2).  --scaling weak keeps a 512x512x40 tile per GPU
+instead (the global domain grows with the image grid).  One call per sub-step into the library (icar_hip_update_dt +
+icar_hip_substep): the launches, the second stream and the RCCL halo exchange are issued from C.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus "roofline" and "cpu_baseline".
 """
@@ -39,13 +42,22 @@ def build_tile(args, rank, world, device):
     from icar_amd.constants import kADV_MPDATA, kADV_UPWIND, kMP_THOMPSON, kMP_SB04, kMP_WSM3, kMP_WSM6, KVARS, ADVECTION_ORDER
 
     xs, ys = domain_decomposition(args.nx, args.ny, world) if world > 1 else (1, 1)
-    # weak scaling: the global domain grows with the image grid so each tile keeps nx x ny owned cells
-    gnx, gny = args.nx * xs, args.ny * ys
-    g = grid_t().set_grid_dimensions(gnx, gny, args.nz, world, rank + 1)
-    tnx, tny = g.ime - g.ims + 1, g.jme - g.jms + 1
-    case = ideal.make_case(tnx, tny, args.nz, hill_height=args.hill, noise=0.01, seed=1234 + rank, n_hydro=1)
-    # moisten + pre-cool so that the microphysics is active in a sizeable share of the columns
-    case["water_vapor"] = (case["water_vapor"] * np.float32(1.4)).astype(np.float32)
+    if args.scaling == "strong":
+        # the global nx x ny x nz grid is fixed; every image cuts its tile (halos included) out of the same case
+        gnx, gny = args.nx, args.ny
+        g = grid_t().set_grid_dimensions(gnx, gny, args.nz, world, rank + 1)
+        whole = ideal.make_case(gnx, gny, args.nz, hill_height=args.hill, noise=0.01, seed=1234, n_hydro=1)
+        # moisten so that the microphysics is active in (nearly) every column
+        whole["water_vapor"] = (whole["water_vapor"] * np.float32(1.4)).astype(np.float32)
+        case = ideal.cut_tile(whole, g) if world > 1 else whole
+        del whole
+    else:
+        # weak scaling: the global domain grows with the image grid so each tile keeps nx x ny owned cells
+        gnx, gny = args.nx * xs, args.ny * ys
+        g = grid_t().set_grid_dimensions(gnx, gny, args.nz, world, rank + 1)
+        tnx, tny = g.ime - g.ims + 1, g.jme - g.jms + 1
+        case = ideal.make_case(tnx, tny, args.nz, hill_height=args.hill, noise=0.01, seed=1234 + rank, n_hydro=1)
+        case["water_vapor"] = (case["water_vapor"] * np.float32(1.4)).astype(np.float32)
     opt = options_t()
     opt.physics.advection = kADV_UPWIND if args.adv == "upwind" else kADV_MPDATA
     opt.physics.microphysics = {"thompson": kMP_THOMPSON, "simple": kMP_SB04, "wsm3": kMP_WSM3, "wsm6": kMP_WSM6, "none": 0}[args.mp]
@@ -54,8 +66,7 @@ def build_tile(args, rank, world, device):
     opt.parameters.dz_levels = case["dz_levels"]
     mp_var_request(opt); adv_var_request(opt)
     comm = HaloComm(g, rank + 1, loopback=(world == 1))
-    d = domain_t(g, device=device, dx=float(case["dx"]), image=rank + 1, comm=comm)
-    d.bind_torch_stream()            # context kernels, torch ops and RCCL ordering all on one non-default stream
+    d = domain_t(g, device=device, dx=float(case["dx"]), image=rank + 1, comm=comm)      # comm.attach: icar_hip_comm_init (RCCL)
     d.load_case(case)
     d.exchange_vars = [n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0]
     mp_init(opt, d); adv_init(d, opt)
@@ -73,14 +84,14 @@ ADVECT_KERNELS = {"mpdata": "k_mpdata_fused", "upwind": "k_upwind_pass"}
 FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
 
 
-def one_step(d, opt, group=None, device=None, cool=0.0):
+def one_step(d, opt):
     from icar_amd.time_step import update_dt, substep
-    dt = update_dt(d, opt, group=group, device=device)
-    # time_step.substep: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect -> apply_forcing
-    # at EVERY world size: the strips + pack on the main stream, the interior on the second stream (with the wind setup and the
-    # w_real diagnostic beside it), the whole-field forcing of u, v, w, p beside the advection.  With one image the edges wrap
-    # around to the tile itself (HaloComm loopback: same pack / unpack kernels, no transport), so the N=1 line times the
-    # launches every rank of an N>1 run pays.
+    dt = update_dt(d, opt)                   # icar_hip_update_dt: CFL reduction (prefetched beside the last advection) + co_min over RCCL
+    # icar_hip_substep: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect -> apply_forcing
+    # at EVERY world size: the strips + pack (+ RCCL send/recv) on the main stream, the interior on the second stream (with the
+    # wind setup beside it), the w_real diagnostic, the whole-field forcing of u, v, w, p and the next CFL reduction beside the
+    # advection.  With one image the edges wrap around to the tile itself (ICAR_NEIGHBOR_SELF: same pack / unpack kernels, no
+    # transport), so the N=1 line times the launches every rank of an N>1 run pays.
     substep(d, opt, dt, forced=FORCED)
     d.model_time_seconds += dt
     return dt
@@ -272,6 +283,8 @@ def main():
     ap.add_argument("--hill", type=float, default=1000.0)
     ap.add_argument("--adv", default="mpdata", choices=["mpdata", "upwind"])
     ap.add_argument("--mp", default=os.environ.get("ICAR_BENCH_MP", "thompson"), choices=["thompson", "simple", "wsm3", "wsm6", "none"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default): the nx x ny x nz grid is global and split over the GPUs; weak: it is the tile of every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ref-child", default=None, help=argparse.SUPPRESS)      # internal: cpu_reference()'s child process
     ap.add_argument("--ref-nscal", type=int, default=9, help=argparse.SUPPRESS)
@@ -289,8 +302,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    # ICAR_BENCH_BACKEND=gloo lets several ranks share one GPU (halo buffers staged through host memory): a functional
-    # check of the N>1 path on a 1-GPU box, never a performance number.  The driver's launches use RCCL.
+    # ICAR_BENCH_BACKEND=gloo lets several ranks share one GPU (the library's host-staged transport, icar_hip_comm_init_host):
+    # a functional check of the N>1 path on a 1-GPU box, never a performance number.  The driver's launches use RCCL.
     backend = os.environ.get("ICAR_BENCH_BACKEND", "nccl")
     dev_index = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
@@ -319,12 +332,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(d, opt, device=red_device)
+        one_step(d, opt)
     barrier()
     lib.icar_hip_timing_enable(d.ctx, 1); lib.icar_hip_timing_reset(d.ctx)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dt = one_step(d, opt, device=red_device)
+        dt = one_step(d, opt)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -388,14 +401,16 @@ def main():
             "unit": "grid-cell updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.nx}x{args.ny}x{args.nz} owned cells per GPU, "
-                                   f"{'mpdata order-2+FCT' if args.adv == 'mpdata' else 'upwind'} advection of "
+            "config": {"workload": (f"{args.nx}x{args.ny}x{args.nz} global grid" if args.scaling == "strong" else
+                                    f"{args.nx}x{args.ny}x{args.nz} owned cells per GPU ({g.nx_global}x{g.ny_global}x{args.nz} global)") +
+                                   f", {'mpdata order-2+FCT' if args.adv == 'mpdata' else 'upwind'} advection of "
                                    f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
+                       "global_grid": [g.nx_global, g.ny_global, args.nz],
                        "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",
                        "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
-                       "halo": "RCCL send/recv per neighbour, strips+pack on the main stream, interior mp on the second stream" if world > 1
+                       "halo": "one ncclSend/ncclRecv group per step issued by the library (icar_hip_halo_send), strips+pack on the main stream, interior mp on the second stream" if world > 1
                                else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips on the main stream, interior mp on the second stream",
                        "dt_s": dt, "mp_active_column_fraction": active},
             "roofline": {"bound": "hbm", "kernel": f"advect ({ADVECT_KERNELS[args.adv]})",

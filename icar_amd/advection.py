@@ -24,31 +24,17 @@ def advected_field_ids(options):
 
 
 def setup_winds(domain, options, dt):
-    """setup_module_winds (advect.f90:306-351 / adv_mpdata.f90:496-506): U_m, V_m, W_m (, W_m/dz) of this step's dt."""
+    """setup_module_winds (advect.f90:306-351 / adv_mpdata.f90:496-506): U_m, V_m, W_m (, W_m/dz) of this step's dt.  The library
+    remembers what they were set up for; advect() redoes the setup only when that no longer matches (or the winds moved)."""
     scheme = options.physics.advection
     dens = int(bool(options.parameters.advect_density))
     check(lib().icar_hip_setup_winds(domain.ctx, scheme, ctypes.c_float(dt), ctypes.c_float(domain.dx), dens),
           "icar_hip_setup_winds")
-    domain._winds_prepared = (scheme, float(dt), dens)
-
-
-def _winds_prepared(domain, scheme, dt, dens):
-    # set by time_step.mp_and_halo, which launches setup_winds beside the interior microphysics; anything that rewrote u, v, w,
-    # density or a jacobian since has cleared the context's flag, and the setup is then simply redone
-    return getattr(domain, "_winds_prepared", None) == (scheme, float(dt), dens) and bool(lib().icar_hip_winds_valid(domain.ctx))
 
 
 def advect(domain, options, dt):
-    """advection_driver.f90:51-77: advect every scalar with vars_to_advect>0 over one step dt."""
-    scheme = options.physics.advection
-    if scheme not in (kADV_UPWIND, kADV_MPDATA):
+    """advection_driver.f90:51-77: advect every scalar with vars_to_advect>0 over one step dt (icar_hip_advect_step)."""
+    if options.physics.advection not in (kADV_UPWIND, kADV_MPDATA):
         return
-    dens = int(bool(options.parameters.advect_density))
-    if not _winds_prepared(domain, scheme, dt, dens):
-        setup_winds(domain, options, dt)
-    domain._winds_prepared = None
-    ids = advected_field_ids(options)
-    arr = (ctypes.c_int * len(ids))(*ids)
-    check(lib().icar_hip_advect(domain.ctx, scheme, int(options.adv_options.mpdata_order),
-                                int(bool(options.adv_options.flux_corrected_transport)), dens, arr, len(ids)),
-          "icar_hip_advect")
+    domain.configure(options)
+    check(lib().icar_hip_advect_step(domain.ctx, float(dt)), "icar_hip_advect_step")

@@ -23,6 +23,10 @@ SYMBOLS = [
     "icar_hip_apply_forcing", "icar_hip_enforce_limits", "icar_hip_halo_count", "icar_hip_halo_pack",
     "icar_hip_halo_unpack", "icar_hip_halo_pack_dirs", "icar_hip_halo_unpack_dirs", "icar_hip_timing_enable", "icar_hip_timing_read", "icar_hip_timing_reset",
     "icar_hip_last_error", "icar_hip_version",
+    "icar_hip_comm_unique_id", "icar_hip_comm_init", "icar_hip_comm_init_host", "icar_hip_comm_destroy", "icar_hip_comm_kind",
+    "icar_hip_halo_send", "icar_hip_halo_retrieve", "icar_hip_co_min", "icar_hip_co_max",
+    "icar_hip_step_configure", "icar_hip_model_time_set", "icar_hip_model_time", "icar_hip_mp_reset", "icar_hip_compute_dt",
+    "icar_hip_update_dt", "icar_hip_mp", "icar_hip_advect_step", "icar_hip_substep", "icar_hip_step",
     "icar_hip_linwinds_setup", "icar_hip_linwinds_terrain_frequency", "icar_hip_linear_perturbation",
     "icar_hip_linwinds_build_lut", "icar_hip_linwinds_build_lut_varying", "icar_hip_linwinds_lut_download", "icar_hip_linwinds_lut_upload",
     "icar_hip_linwinds_perturbation_download", "icar_hip_linwinds_perturbation_upload", "icar_hip_spatial_winds",
@@ -40,6 +44,26 @@ class lt_options_c(ctypes.Structure):          # struct icar_hip_lt_options (inc
                 ("minimum_layer_size", ctypes.c_float)]
 
 
+N_ADVECTABLE = 11
+NEIGHBOR_NONE, NEIGHBOR_SELF = -1, -2
+COMM_NONE, COMM_LOCAL, COMM_RCCL, COMM_HOST = 0, 1, 2, 3
+
+
+class step_config_c(ctypes.Structure):         # struct icar_hip_step_config (include/icar_hip.h)
+    _fields_ = [("advection", ctypes.c_int), ("microphysics", ctypes.c_int), ("mpdata_order", ctypes.c_int),
+                ("flux_corrected_transport", ctypes.c_int), ("advect_density", ctypes.c_int), ("cfl_strictness", ctypes.c_int),
+                ("cfl_reduction_factor", ctypes.c_float), ("dx", ctypes.c_float), ("mp_update_interval", ctypes.c_float),
+                ("top_mp_level", ctypes.c_int), ("halo_size", ctypes.c_int),
+                ("its", ctypes.c_int), ("ite", ctypes.c_int), ("jts", ctypes.c_int), ("jte", ctypes.c_int),
+                ("kts", ctypes.c_int), ("kte", ctypes.c_int), ("ids", ctypes.c_int), ("ide", ctypes.c_int),
+                ("jds", ctypes.c_int), ("jde", ctypes.c_int), ("kds", ctypes.c_int), ("kde", ctypes.c_int),
+                ("west_boundary", ctypes.c_int), ("east_boundary", ctypes.c_int), ("south_boundary", ctypes.c_int),
+                ("north_boundary", ctypes.c_int), ("diagnostics", ctypes.c_int), ("prefetch_dt", ctypes.c_int),
+                ("n_advect", ctypes.c_int), ("advect_fields", ctypes.c_int * N_ADVECTABLE),
+                ("n_exchange", ctypes.c_int), ("exchange_fields", ctypes.c_int * N_ADVECTABLE),
+                ("n_forced", ctypes.c_int), ("forced_fields", ctypes.c_int * 16), ("force_boundaries", ctypes.c_int * 16)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -54,6 +78,24 @@ def lib():
         L.icar_hip_halo_count.restype = ctypes.c_size_t
         L.icar_hip_field_count.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.icar_hip_halo_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        L.icar_hip_model_time.restype = cd
+        L.icar_hip_model_time.argtypes = [vp]
+        L.icar_hip_model_time_set.argtypes = [vp, cd]
+        L.icar_hip_mp.argtypes = [vp, cd, ci, ci]
+        L.icar_hip_advect_step.argtypes = [vp, cd]
+        L.icar_hip_substep.argtypes = [vp, cd, ci]
+        L.icar_hip_step.argtypes = [vp, cd, ctypes.POINTER(ci)]
+        L.icar_hip_update_dt.argtypes = [vp, ctypes.POINTER(cd)]
+        L.icar_hip_compute_dt.argtypes = [vp, ctypes.POINTER(cd)]
+        L.icar_hip_co_min.argtypes = [vp, ctypes.POINTER(cd)]
+        L.icar_hip_co_max.argtypes = [vp, ctypes.POINTER(cd)]
+        L.icar_hip_step_configure.argtypes = [vp, ctypes.POINTER(step_config_c), vp]
+        L.icar_hip_comm_init.argtypes = [vp, ci, ci, ctypes.c_char_p, ctypes.POINTER(ci)]
+        L.icar_hip_comm_init_host.argtypes = [vp, ci, ci, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ci)]
+        L.icar_hip_comm_unique_id.argtypes = [ctypes.c_char_p]
+        L.icar_hip_halo_send.argtypes = [vp, ci, ctypes.POINTER(ci), ci]
+        L.icar_hip_halo_retrieve.argtypes = [vp, ci, ctypes.POINTER(ci), ci]
         _lib = L
     return _lib
 

@@ -161,6 +161,7 @@ int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int
 #undef LAUNCH
     HIPCHK(hipGetLastError());
     c->winds_valid = true;
+    c->step.winds_scheme = scheme; c->step.winds_dt = dt; c->step.winds_dens = advect_density ? 1 : 0;   // what advect() of the step driver asks for
     return 0;
 }
 

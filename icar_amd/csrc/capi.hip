@@ -1,6 +1,7 @@
 // icar_amd/csrc/capi.hip -- extern "C" boundary (include/icar_hip.h), context and field registry,
 // plus the small streaming kernels of rows H1 (halo faces), T2 (CFL reduction), W1 (balance_uvw).
 #include "ctx.h"
+#include "comm.h"
 #include <cstring>
 #include <cstdio>
 #include <cmath>
@@ -429,6 +430,8 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     icar_wsm6_free(c);
     icar_thompson_free(c);
     icar_linwinds_free(c);
+    icar_comm_free(c);
+    if (c->step.h_val) hipHostFree(c->step.h_val);
     if (c->on_aux) c->stream = c->main_saved;
     if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);

@@ -25,6 +25,19 @@ struct ThompsonTables;   // mp_thompson.hip
 struct LinWinds;         // linear_winds.hip
 struct Wsm3State;        // mp_wsm3.hip
 struct Wsm6State;        // mp_wsm6.hip
+struct IcarComm;         // comm.hip
+
+// state of the step driver (timestep.hip): the options / grid members the sub-step loop reads, the model clock, and what
+// mp_driver.f90 keeps in SAVE variables (last_model_time)
+struct IcarStepState {
+    bool configured = false;
+    icar_hip_step_config cfg;
+    std::vector<float> dz_levels;
+    double model_time = 0.0;                 // domain%model_time%seconds()
+    double mp_last_model_time = -999.0;      // mp_driver.f90:44 last_model_time
+    int winds_scheme = 0, winds_dens = 0; float winds_dt = 0.f;   // what the Courant winds on the device were set up for
+    float *h_val = nullptr;                  // pinned: the reduced CFL maximum
+};
 
 struct icar_hip_ctx {
     int device = 0;
@@ -60,6 +73,8 @@ struct icar_hip_ctx {
     LinWinds *linwinds = nullptr;
     Wsm3State *wsm3 = nullptr;
     Wsm6State *wsm6 = nullptr;
+    IcarComm *comm = nullptr;            // halo transport + co_min (comm.hip)
+    IcarStepState step;                  // timestep.hip
     // timing
     bool timing = false;
     std::map<std::string, TimingGroup> timers;
@@ -86,6 +101,9 @@ int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int
 int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_density, const int *fields, int n);
 int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err);
 int icar_mp_simple_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte, int *err);
+int icar_mp_run(icar_hip_ctx *c, double dt_in, int halo, int subset);      // halo / subset < 0: argument not present
+int icar_update_dt(icar_hip_ctx *c, double *seconds);
+int icar_substep(icar_hip_ctx *c, double dt, bool enforce);
 int icar_halo_pack(icar_hip_ctx *c, int dir, int halo, const int *fields, int n, float *buf, bool unpack);
 int icar_halo_pack_dirs(icar_hip_ctx *c, int ndir, const int *dirs, int halo, const int *fields, int n, void *const *bufs, bool unpack);
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out, float *d_out);

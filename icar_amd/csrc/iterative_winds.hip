@@ -184,6 +184,7 @@ int icar_iterative_winds_correct_w(icar_hip_ctx *c, int update)
     ScopedTimer t(c, "iterative_winds");
     hipLaunchKernelGGL(k_iw_correct_w, dim3((c->d.nx + 63) / 64, c->d.ny), dim3(64), 0, c->stream, c->d, q.w, dz);
     HIPCHK(hipGetLastError());
+    if (!update) icar_winds_changed(c);          // domain w rewritten: Courant winds and a prefetched CFL maximum are stale
     return 0;
 }
 

@@ -1,0 +1,327 @@
+// icar_amd/csrc/timestep.hip -- rows T1 / T2 / M0 on the library side of the C ABI: the sub-step loop of
+// src/main/time_step.f90:440-551 (step), :375-423 (update_dt), :217-330 (compute_dt) and the tile bookkeeping of
+// src/physics/mp_driver.f90:673-772 (mp) issued from ONE entry point each, with the two-stream choreography inside the
+// library, so that a Fortran host gets exactly what the Python host gets and a small tile is not bound by per-launch host
+// overhead (12-25 ctypes / iso_c_binding round trips per sub-step before).
+//
+// What runs beside what (same launches, operands and results as the plain sequence):
+//   main stream                                           second stream
+//   diagnostic_update part 1 (exner, T, rho, ...)
+//   mp(halo=1) strips -> halo_send (pack + RCCL)          mp(subset=1) interior            time_step.f90:512-526
+//   setup_module_winds of the advect() that follows       |
+//   halo_retrieve (unpack)  <----------------------------- join
+//   advect                                                w_real diagnostic, forcing of u, v, w, p, CFL reduction of the next step
+//   forcing of the advected scalars (boundary ring) <----- join
+//   enforce_limits (last two sub-steps)
+#include "ctx.h"
+#include "comm.h"
+#include <cmath>
+#include <cstring>
+
+// physics selectors, src/constants/icar_constants.f90:341-374
+enum { kMP_THOMPSON = 1, kMP_SB04 = 2, kMP_WSM6 = 4, kMP_WSM3 = 6 };
+
+static bool cfg_ok(icar_hip_ctx *c, const char *who)
+{
+    if (c->step.configured) return true;
+    icar_set_error(std::string(who) + ": call icar_hip_step_configure first");
+    return false;
+}
+
+// ---- M0: mp(domain, options, dt, halo, subset) (mp_driver.f90:673-772) ------------------------------------------------
+static int process_subdomain(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    if (ite < its || jte < jts) return 0;
+    switch (g.microphysics) {
+    case kMP_SB04:     return icar_mp_simple_run(c, dt, its, ite, jts, jte, kts, kte, nullptr);
+    case kMP_WSM6:     return icar_wsm6_run(c, dt, its, ite, jts, jte, kts, kte);
+    case kMP_WSM3:     return icar_wsm3_run(c, dt, its, ite, jts, jte, kts, kte);
+    case kMP_THOMPSON: return icar_thompson_run(c, dt, its, ite, jts, jte, kts, kte, g.ids, g.ide, g.jds, g.jde, g.kds, g.kde);
+    }
+    icar_set_error("mp: microphysics option not built (1 Thompson, 2 mp_simple, 4 WSM6, 6 WSM3)");
+    return 1;
+}
+
+int icar_mp_run(icar_hip_ctx *c, double dt_in, int halo, int subset)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    if (g.microphysics == 0) return 0;
+    IcarStepState &st = c->step;
+    const double upd = (double)g.mp_update_interval, now = st.model_time;
+    if (st.mp_last_model_time == -999.0) st.mp_last_model_time = now - (upd > dt_in ? upd : dt_in);       // :698-702
+    if (((now + dt_in) - st.mp_last_model_time) < upd) return 0;                                          // :705
+    const float mp_dt = (float)(now - st.mp_last_model_time);                                             // :708
+    if (halo < 0) st.mp_last_model_time = now;                                                             // :711-713 (not on the halo pass)
+    int kte = g.kte;
+    if (g.top_mp_level > 0 && g.top_mp_level < kte) kte = g.top_mp_level;                                  // :716-718
+    int t[4][4];
+    if (subset >= 0) {                                                                                     // :728-737
+        icar_hip_mp_tiles(g.its, g.ite, g.jts, g.jte, 0, subset, t);
+        if (process_subdomain(c, mp_dt, t[0][0], t[0][1], t[0][2], t[0][3], g.kts, kte)) return 1;
+    }
+    if (halo >= 0) {                                                                                       // :721-726 -> process_halo :609-658
+        const int n = icar_hip_mp_tiles(g.its, g.ite, g.jts, g.jte, halo, 0, t);
+        // a tile narrower than 2*halo makes opposite strips overlap: the reference then runs those columns once per strip, one
+        // strip after the other -- a single batched launch would race on them
+        const bool overlapping = (g.ite - g.its + 1 < 2 * halo) || (g.jte - g.jts + 1 < 2 * halo);
+        int live[4][4], nl = 0;
+        for (int s = 0; s < n; ++s) if (t[s][1] >= t[s][0] && t[s][3] >= t[s][2]) { memcpy(live[nl], t[s], sizeof live[nl]); ++nl; }
+        const bool batched = !overlapping && (g.microphysics == kMP_THOMPSON || g.microphysics == kMP_SB04 || g.microphysics == kMP_WSM6);
+        if (batched && nl) {
+            int r = 0;
+            if (g.microphysics == kMP_THOMPSON) r = icar_thompson_run_tiles(c, mp_dt, nl, live, g.kts, kte, g.ids, g.ide, g.jds, g.jde, g.kds, g.kde);
+            else if (g.microphysics == kMP_WSM6) r = icar_wsm6_run_tiles(c, mp_dt, nl, live, g.kts, kte);
+            else r = icar_mp_simple_run_tiles(c, mp_dt, nl, live, g.kts, kte, nullptr);
+            if (r) return 1;
+        } else if (!batched) {
+            for (int s = 0; s < n; ++s) if (process_subdomain(c, mp_dt, t[s][0], t[s][1], t[s][2], t[s][3], g.kts, kte)) return 1;
+        }
+    }
+    if (halo < 0 && subset < 0)
+        if (process_subdomain(c, mp_dt, g.its, g.ite, g.jts, g.jte, g.kts, kte)) return 1;                 // :739-741
+    return 0;
+}
+
+// ---- A1 bookkeeping: the Courant winds belong to (scheme, dt, advect_density) and to the wind state they were made from --
+static bool winds_prepared(icar_hip_ctx *c, float dt)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    return c->winds_valid && c->step.winds_scheme == g.advection && c->step.winds_dt == dt && c->step.winds_dens == (g.advect_density ? 1 : 0);
+}
+
+static int setup_winds(icar_hip_ctx *c, float dt)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    return icar_advect_setup_winds(c, g.advection, dt, g.dx, g.advect_density);      // records (scheme, dt, density) in c->step
+}
+
+int icar_step_advect(icar_hip_ctx *c, float dt)
+{   // advection_driver.f90:51-77
+    const icar_hip_step_config &g = c->step.cfg;
+    if (g.advection != ICAR_ADV_UPWIND && g.advection != ICAR_ADV_MPDATA) return 0;
+    if (!winds_prepared(c, dt) && setup_winds(c, dt)) return 1;
+    return icar_advect_run(c, g.advection, g.mpdata_order, g.flux_corrected_transport, g.advect_density, g.advect_fields, g.n_advect);
+}
+
+// ---- T2: compute_dt + update_dt (time_step.f90:217-330, :375-423) ------------------------------------------------------
+static int compute_dt(icar_hip_ctx *c, float *dt_out, bool *on_device)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    const float *dzl = c->step.dz_levels.data();
+    const int strict = g.cfl_strictness;
+    float mu = 0, mv = 0, mw = 0, maxwind1d = 0, maxwind3d = 0;
+    *on_device = false;
+    if (strict == 1 || strict == 2 || strict == 5) {
+        float m3[3];
+        if (icar_max_abs_winds_run(c, m3)) return 1;
+        mu = m3[0]; mv = m3[1]; mw = m3[2];
+    }
+    const float sqrt3 = sqrtf(3.0f) * 1.001f;                                     // :229
+    if (strict == 1) { maxwind1d = fmaxf(fmaxf(mu, mv), mw); maxwind3d = maxwind1d * sqrt3; }              // :238-246
+    else if (strict == 5) maxwind3d = (mu + mv) + mw;                                                          // :248-259
+    else {
+        // strictness 2, 3, 4: the per-cell Courant sum (:264-289).  With RCCL and 3 / 4 the tile maximum stays on the device
+        // until it has been reduced over the images (dt = factor / max is monotone: min dt == factor / max, bit for bit)
+        float *d_val = c->d_red + 12;
+        if ((strict == 3 || strict == 4) && c->comm && icar_hip_comm_kind(c) == ICAR_COMM_RCCL) {
+            if (icar_max_courant_run(c, g.dx, dzl, nullptr, d_val)) return 1;
+            if (icar_comm_max_device(c, d_val) != 0) return 1;
+            if (!c->step.h_val) HIPCHK(hipHostMalloc((void **)&c->step.h_val, sizeof(float), hipHostMallocDefault));
+            HIPCHK(hipMemcpyAsync(c->step.h_val, d_val, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            maxwind3d = *c->step.h_val;
+            *on_device = true;
+        } else if (icar_max_courant_run(c, g.dx, dzl, &maxwind3d, nullptr)) return 1;
+        if (strict == 2) {                                                                                     // :291-300
+            maxwind3d = maxwind3d * 0.577350269f;
+            maxwind1d = fmaxf(fmaxf(mu, mv), mw);
+            maxwind3d = fmaxf(maxwind1d, maxwind3d);
+        } else if (strict == 4) maxwind3d = maxwind3d * sqrt3;                                                  // :302-305
+    }
+    const float dt = g.cfl_reduction_factor / maxwind3d;                                                       // :313
+    if (dt < 1e-1f) { icar_set_error("ERROR time step too small"); return 1; }                                 // :322-328 `stop`
+    *dt_out = dt;
+    return 0;
+}
+
+int icar_update_dt(icar_hip_ctx *c, double *seconds)
+{
+    float dt; bool reduced;
+    if (compute_dt(c, &dt, &reduced)) return 1;
+    double s = (double)dt;
+    if (!reduced && icar_comm_co_reduce(c, &s, true)) return 1;                   // :413 co_min(seconds)
+    *seconds = s < 120.0 ? s : 120.0;                                             // :417
+    return 0;
+}
+
+// ---- T1: one pass of time_step.f90:474-539 ----------------------------------------------------------------------------
+static int halo_send(icar_hip_ctx *c) { const icar_hip_step_config &g = c->step.cfg; return icar_comm_halo_send(c, g.halo_size, g.exchange_fields, g.n_exchange); }
+static int halo_retrieve(icar_hip_ctx *c) { const icar_hip_step_config &g = c->step.cfg; return icar_comm_halo_retrieve(c, g.halo_size, g.exchange_fields, g.n_exchange); }
+
+struct AuxScope {          // entry points called while this object lives launch on the second stream; leaves it on every return path
+    icar_hip_ctx *c; bool on = false;
+    explicit AuxScope(icar_hip_ctx *c_) : c(c_) {}
+    int begin() { if (icar_hip_aux_begin(c)) return 1; on = true; return 0; }
+    void end() { if (on) { icar_hip_aux_end(c); on = false; } }
+    ~AuxScope() { end(); }
+};
+
+int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    const float dtf = (float)dt;
+    const bool adv = (g.advection == ICAR_ADV_UPWIND || g.advection == ICAR_ADV_MPDATA);
+    const bool stepping = dt > 1e-3;                                              // :483
+    bool wreal_later = false;
+    if (g.diagnostics) {                                                          // :474
+        if (g.microphysics != kMP_WSM3) {                                         // WSM3 reads w_real
+            if (icar_diagnostic_update_run(c, 1)) return 1;
+            if (stepping) wreal_later = true;                                     // beside the advection, below
+            else if (icar_diagnostic_update_run(c, 2)) return 1;
+        } else if (icar_diagnostic_update_run(c, 3)) return 1;
+    }
+    if (!stepping) return 0;
+
+    // :512-526  mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
+    if (g.microphysics != 0) {
+        if (icar_hip_aux_fork(c)) return 1;
+        if (icar_mp_run(c, dt, 1, -1)) return 1;
+        if (halo_send(c)) return 1;
+        {
+            AuxScope aux(c);
+            if (aux.begin()) return 1;
+            if (icar_mp_run(c, dt, -1, 1)) return 1;
+        }
+        // the Courant winds of the advect() that follows read u, v, w, density and the jacobians, none of which the microphysics
+        // touches: a streaming kernel on the main stream beside the VALU-bound interior launch
+        if (adv && setup_winds(c, dtf)) return 1;
+        if (icar_hip_aux_join(c)) return 1;
+        // update_interval gating (:711): the halo pass leaves last_model_time alone, the subset pass is what moves it in the
+        // reference (`if (.not.present(halo))`); both passes above saw the same mp_dt
+        if (halo_retrieve(c)) return 1;
+    } else {
+        if (halo_send(c)) return 1;
+        if (halo_retrieve(c)) return 1;
+    }
+
+    // :529-534  advect, with the whole-field forcing that does not depend on it (and the next CFL reduction) beside it
+    int aside_f[16], aside_b[16], na = 0, rest_f[16], rest_b[16], nr = 0;
+    for (int m = 0; m < g.n_forced; ++m) {
+        const int f = g.forced_fields[m];
+        const bool whole = !g.force_boundaries[m] && (f == ICAR_F_U || f == ICAR_F_V || f == ICAR_F_W || f == ICAR_F_PRESSURE);
+        if (whole) { aside_f[na] = f; aside_b[na] = 0; ++na; } else { rest_f[nr] = f; rest_b[nr] = g.force_boundaries[m]; ++nr; }
+    }
+    const bool cfl_ahead = g.prefetch_dt && (g.cfl_strictness == 3 || g.cfl_strictness == 4);
+    const bool beside = na > 0 || cfl_ahead || wreal_later;
+    // the second stream starts from the state BEFORE the advection -- but after the wind setup, which reads the winds the
+    // forcing beside the advection rewrites
+    if (adv && !winds_prepared(c, dtf) && setup_winds(c, dtf)) return 1;
+    if (beside && icar_hip_aux_fork(c)) return 1;
+    if (icar_step_advect(c, dtf)) return 1;                                       // :529
+    if (beside) {
+        {
+            AuxScope aux(c);
+            if (aux.begin()) return 1;
+            if (wreal_later && icar_diagnostic_update_run(c, 2)) return 1;        // :165-194, from the winds of this step (before their forcing)
+            if (na && icar_apply_forcing_run(c, dt, aside_f, aside_b, na, g.west_boundary, g.east_boundary, g.south_boundary, g.north_boundary)) return 1;
+            if (cfl_ahead && icar_max_courant_prefetch_run(c, g.dx, c->step.dz_levels.data())) return 1;
+        }
+        if (icar_hip_aux_join(c)) return 1;
+    }
+    if (nr && icar_apply_forcing_run(c, dt, rest_f, rest_b, nr, g.west_boundary, g.east_boundary, g.south_boundary, g.north_boundary)) return 1;   // :534
+    if (enforce && icar_enforce_limits_run(c, g.advect_fields, g.n_advect)) return 1;                                                                // :537-539
+    return 0;
+}
+
+extern "C" {
+
+int icar_hip_step_configure(icar_hip_ctx *c, const icar_hip_step_config *cfg, const float *dz_levels)
+{
+    if (!c || !cfg || !dz_levels) { icar_set_error("step_configure: null argument"); return 1; }
+    if (cfg->n_advect < 0 || cfg->n_advect > ICAR_N_ADVECTABLE || cfg->n_exchange < 0 || cfg->n_exchange > ICAR_N_ADVECTABLE ||
+        cfg->n_forced < 0 || cfg->n_forced > 16) { icar_set_error("step_configure: bad list length"); return 1; }
+    for (int m = 0; m < cfg->n_advect; ++m) if (cfg->advect_fields[m] < 0 || cfg->advect_fields[m] >= ICAR_N_ADVECTABLE) { icar_set_error("step_configure: advect_fields holds advectable scalars"); return 1; }
+    for (int m = 0; m < cfg->n_exchange; ++m) if (cfg->exchange_fields[m] < 0 || cfg->exchange_fields[m] >= ICAR_N_ADVECTABLE) { icar_set_error("step_configure: exchange_fields holds advectable scalars"); return 1; }
+    if (cfg->cfl_strictness < 1 || cfg->cfl_strictness > 5) { icar_set_error("step_configure: cfl_strictness is 1..5"); return 1; }
+    if (cfg->halo_size < 1) { icar_set_error("step_configure: halo_size >= 1"); return 1; }
+    if (cfg->its < c->ims || cfg->ite > c->ime || cfg->jts < c->jms || cfg->jte > c->jme || cfg->kts < c->kms || cfg->kte > c->kme) {
+        icar_set_error("step_configure: its..kte outside the ims..kme of the context"); return 1;
+    }
+    c->step.cfg = *cfg;
+    c->step.dz_levels.assign(dz_levels, dz_levels + c->d.nz);
+    c->step.configured = true;
+    return 0;
+}
+
+int icar_hip_model_time_set(icar_hip_ctx *c, double seconds) { if (!c) { icar_set_error("null ctx"); return 1; } c->step.model_time = seconds; return 0; }
+double icar_hip_model_time(const icar_hip_ctx *c) { return c ? c->step.model_time : 0.0; }
+int icar_hip_mp_reset(icar_hip_ctx *c) { if (!c) { icar_set_error("null ctx"); return 1; } c->step.mp_last_model_time = -999.0; return 0; }
+
+int icar_hip_mp(icar_hip_ctx *c, double dt, int halo, int subset)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (!cfg_ok(c, "mp")) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    return icar_mp_run(c, dt, halo, subset);
+}
+
+int icar_hip_advect_step(icar_hip_ctx *c, double dt)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (!cfg_ok(c, "advect_step")) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    return icar_step_advect(c, (float)dt);
+}
+
+int icar_hip_compute_dt(icar_hip_ctx *c, double *dt_seconds)
+{
+    if (!c || !dt_seconds) { icar_set_error("compute_dt: null argument"); return 1; }
+    if (!cfg_ok(c, "compute_dt")) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    float dt; bool reduced;
+    IcarComm *keep = c->comm; c->comm = nullptr;          // this image alone: no reduction over the images
+    const int r = compute_dt(c, &dt, &reduced);
+    c->comm = keep;
+    if (r) return 1;
+    *dt_seconds = (double)dt;
+    return 0;
+}
+
+int icar_hip_update_dt(icar_hip_ctx *c, double *dt_seconds)
+{
+    if (!c || !dt_seconds) { icar_set_error("update_dt: null argument"); return 1; }
+    if (!cfg_ok(c, "update_dt")) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    return icar_update_dt(c, dt_seconds);
+}
+
+int icar_hip_substep(icar_hip_ctx *c, double dt_seconds, int enforce_limits)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (!cfg_ok(c, "substep")) return 1;
+    if (c->on_aux) { icar_set_error("substep: called between aux_begin and aux_end"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_substep(c, dt_seconds, enforce_limits != 0);
+}
+
+int icar_hip_step(icar_hip_ctx *c, double end_time_seconds, int *nsteps)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (!cfg_ok(c, "step")) return 1;
+    if (c->on_aux) { icar_set_error("step: called between aux_begin and aux_end"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    int n = 0;
+    while (c->step.model_time < end_time_seconds) {                              // :462
+        double dt;
+        if (icar_update_dt(c, &dt)) return 1;                                    // :465
+        if (c->step.model_time + dt > end_time_seconds) dt = end_time_seconds - c->step.model_time;       // :469-471
+        if (icar_substep(c, dt, (end_time_seconds - c->step.model_time) < dt * 2)) return 1;               // :474-539
+        c->step.model_time += dt;                                                // :547
+        ++n;
+    }
+    if (nsteps) *nsteps = n;
+    return 0;
+}
+
+}  // extern "C"

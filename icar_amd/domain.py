@@ -7,7 +7,7 @@ Device memory lives in libicar_hip's context; numpy arrays only cross at upload/
 import ctypes
 import numpy as np
 from . import _fields as F
-from .capi import lib, check, IcarHipError
+from .capi import lib, check, IcarHipError, step_config_c, NEIGHBOR_NONE, NEIGHBOR_SELF
 from .constants import ADVECTION_ORDER, KVARS
 from .grid import grid_t
 
@@ -28,9 +28,11 @@ class domain_t:
                                         grid.kme, grid.jms, grid.jme), "icar_hip_ctx_create")
         self.nx, self.nz, self.ny = grid.ime - grid.ims + 1, grid.kme - grid.kms + 1, grid.jme - grid.jms + 1
         self.device = int(device)
-        self.model_time_seconds = 0.0    # domain%model_time%seconds()
-        self.mp_state = dict(last_model_time=-999.0)   # mp_driver.f90's SAVE variables last_model_time / update_interval
         self.exchange_vars = []          # kVARS names with an associated exchangeable (halo_send order)
+        self._step_key = None            # what the library's step driver was last configured with (configure())
+        self._forced, self._diagnostics, self._prefetch_dt = (), True, True
+        if comm is not None:
+            comm.attach(self)            # icar_hip_comm_init[_host]: collective over the images of the communicator
 
     # ---- plumbing -------------------------------------------------------------------------
     @property
@@ -38,6 +40,60 @@ class domain_t:
         if not self._ctx:
             raise IcarHipError("domain context destroyed")
         return self._ctx
+
+    # domain%model_time%seconds(): the clock lives in the library (the step driver and mp()'s update_interval gating read it)
+    @property
+    def model_time_seconds(self):
+        return float(lib().icar_hip_model_time(self.ctx))
+
+    @model_time_seconds.setter
+    def model_time_seconds(self, seconds):
+        check(lib().icar_hip_model_time_set(self.ctx, float(seconds)), "icar_hip_model_time_set")
+
+    def configure(self, options, forced=None, diagnostics=None, prefetch_dt=None, advection=None):
+        """icar_hip_step_configure: hand the library the members of options_t / grid_t that step(), update_dt(), mp() and
+        advect() read (time_step.f90:440-551).  Cheap when nothing changed.  forced = [(member, force_boundaries), ...] (the
+        variables apply_forcing updates), diagnostics (diagnostic_update at the top of a sub-step) and prefetch_dt stay as last
+        given when omitted.  advection=0 overrides options%physics%advection (time_step.mp_and_halo: the microphysics + halo
+        block alone)."""
+        p, g = options.parameters, self.grid
+        adv = options.physics.advection if advection is None else advection
+        adv_ids = tuple(KVARS[n][0] for n in ADVECTION_ORDER if options.vars_to_advect.get(n, 0) > 0)
+        if forced is not None: self._forced = tuple((self.fid(n), int(bool(b))) for n, b in forced)
+        if diagnostics is not None: self._diagnostics = bool(diagnostics)
+        if prefetch_dt is not None: self._prefetch_dt = bool(prefetch_dt)
+        forced, diagnostics, prefetch_dt = self._forced, self._diagnostics, self._prefetch_dt
+        dzl = p.dz_levels
+        key = (adv, options.physics.microphysics, int(options.adv_options.mpdata_order), bool(options.adv_options.flux_corrected_transport),
+               bool(p.advect_density), int(p.cfl_strictness), float(p.cfl_reduction_factor), float(options.mp_options.update_interval),
+               int(options.mp_options.top_mp_level), adv_ids, tuple(self._exchange_fields()), forced, bool(diagnostics), bool(prefetch_dt),
+               id(dzl), None if dzl is None else float(np.asarray(dzl, np.float32).sum()))
+        if key == self._step_key:
+            return
+        c = step_config_c()
+        c.advection, c.microphysics = int(adv), int(options.physics.microphysics)
+        c.mpdata_order, c.flux_corrected_transport = int(options.adv_options.mpdata_order), int(bool(options.adv_options.flux_corrected_transport))
+        c.advect_density, c.cfl_strictness = int(bool(p.advect_density)), int(p.cfl_strictness)
+        c.cfl_reduction_factor, c.dx = float(p.cfl_reduction_factor), self.dx
+        c.mp_update_interval, c.top_mp_level = float(options.mp_options.update_interval), int(options.mp_options.top_mp_level)
+        c.halo_size = int(getattr(self.comm, "halo", None) or g.halo_size)
+        for n in ("its", "ite", "jts", "jte", "kts", "kte", "ids", "ide", "jds", "jde", "kds", "kde"):
+            setattr(c, n, int(getattr(g, n)))
+        for n in ("west_boundary", "east_boundary", "south_boundary", "north_boundary"):
+            setattr(c, n, int(bool(getattr(g, n))))
+        c.diagnostics, c.prefetch_dt = int(bool(diagnostics)), int(bool(prefetch_dt))
+        c.n_advect = len(adv_ids)
+        for m, f in enumerate(adv_ids): c.advect_fields[m] = f
+        ex = self._exchange_fields()
+        c.n_exchange = len(ex)
+        for m, f in enumerate(ex): c.exchange_fields[m] = f
+        c.n_forced = len(forced)
+        for m, (f, b) in enumerate(forced): c.forced_fields[m] = f; c.force_boundaries[m] = b
+        dz = np.ascontiguousarray(dzl if dzl is not None else np.ones(self.nz), np.float32)
+        if dz.shape != (self.nz,):
+            raise ValueError(f"options%parameters%dz_levels has {dz.shape[0]} levels, the tile {self.nz}")
+        check(lib().icar_hip_step_configure(self.ctx, ctypes.byref(c), dz.ctypes.data_as(ctypes.c_void_p)), "icar_hip_step_configure")
+        self._step_key = key
 
     def close(self):
         if self._ctx:
@@ -180,15 +236,26 @@ class domain_t:
         order = {n: i for i, n in enumerate(ADVECTION_ORDER)}
         return [KVARS[n][0] for n in sorted(self.exchange_vars, key=lambda n: order[n])]
 
+    def _halo_args(self):
+        ids = self._exchange_fields()
+        return int(self.comm.halo), (ctypes.c_int * len(ids))(*ids), len(ids)
+
     def halo_send(self):
-        """domain_obj.f90:109-128: put my edge planes of every exchangeable to the 4 neighbours."""
+        """domain_obj.f90:109-128: put my edge planes of every exchangeable to the 4 neighbours (icar_hip_halo_send: one pack
+        launch + one RCCL send/recv group on the context's stream)."""
         if self.comm is not None:
-            self.comm.send(self, self._exchange_fields())
+            check(lib().icar_hip_halo_send(self.ctx, *self._halo_args()), "icar_hip_halo_send")
 
     def halo_retrieve(self):
-        """domain_obj.f90:130-143: sync with neighbours, then copy the inboxes into my halo planes."""
+        """domain_obj.f90:130-143: sync with neighbours, then copy the inboxes into my halo planes (icar_hip_halo_retrieve)."""
         if self.comm is not None:
-            self.comm.retrieve(self, self._exchange_fields())
+            check(lib().icar_hip_halo_retrieve(self.ctx, *self._halo_args()), "icar_hip_halo_retrieve")
+
+    def co_min(self, value):
+        """`call co_min(seconds)` (time_step.f90:413) over the images of this domain's communicator."""
+        v = ctypes.c_double(float(value))
+        check(lib().icar_hip_co_min(self.ctx, ctypes.byref(v)), "icar_hip_co_min")
+        return v.value
 
     def halo_exchange(self):
         self.halo_send()

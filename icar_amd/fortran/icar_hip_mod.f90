@@ -16,7 +16,10 @@ module icar_hip
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
             hip_diagnostic_update, hip_diagnostic_update_parts, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
             hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_wsm6_tiles, hip_winds_valid, hip_max_courant_prefetch, &
-            hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative
+            hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative, &
+            hip_step_config_t, hip_step_configure, hip_update_dt, hip_compute_dt, hip_substep, hip_step, hip_mp, hip_advect_step, hip_mp_reset, &
+            hip_model_time, hip_set_model_time, hip_comm_unique_id, hip_comm_init, hip_comm_init_local, hip_comm_init_host, hip_comm_destroy, &
+            hip_halo_send, hip_halo_retrieve, hip_co_min, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
@@ -34,6 +37,22 @@ module icar_hip
        ICAR_F_TEMPERATURE_INTERFACE=28, ICAR_F_U_MASS=29, ICAR_F_V_MASS=30, ICAR_F_W_REAL=31, ICAR_F_DZDX=32, ICAR_F_DZDY=33, &
        ICAR_F_SURFACE_PRESSURE=34, ICAR_F_Z=35, ICAR_F_NSQUARED=36, ICAR_F_IVT=37, ICAR_F_IWV=38, ICAR_F_IWL=39, ICAR_F_IWI=40, &
        ICAR_F_ZR_U=41, ICAR_F_ZR_V=42, ICAR_F_SINTHETA=43, ICAR_F_COSTHETA=44
+
+  integer(c_int), parameter :: ICAR_N_ADVECTABLE = 11, ICAR_NEIGHBOR_NONE = -1, ICAR_NEIGHBOR_SELF = -2
+
+  !> struct icar_hip_step_config == the members of options_t / grid_t the sub-step loop reads (time_step.f90:440-551)
+  type, bind(C) :: hip_step_config_t
+     integer(c_int) :: advection = 0, microphysics = 0, mpdata_order = 2, flux_corrected_transport = 1, advect_density = 0
+     integer(c_int) :: cfl_strictness = 3
+     real(c_float)  :: cfl_reduction_factor = 0.9, dx = 1000.0, mp_update_interval = 0.0
+     integer(c_int) :: top_mp_level = 0, halo_size = 1
+     integer(c_int) :: its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde
+     integer(c_int) :: west_boundary = 1, east_boundary = 1, south_boundary = 1, north_boundary = 1
+     integer(c_int) :: diagnostics = 1, prefetch_dt = 1
+     integer(c_int) :: n_advect = 0, advect_fields(ICAR_N_ADVECTABLE) = 0
+     integer(c_int) :: n_exchange = 0, exchange_fields(ICAR_N_ADVECTABLE) = 0
+     integer(c_int) :: n_forced = 0, forced_fields(16) = 0, force_boundaries(16) = 0
+  end type
 
   !> struct icar_hip_lt_options == the members of options%lt_options the linear-wind path reads
   type, bind(C) :: hip_lt_options_t
@@ -195,9 +214,194 @@ module icar_hip
      type(c_ptr) function icar_hip_last_error() bind(C, name="icar_hip_last_error")
        import
      end function
+     ! ---- H1 transport + co_min, and the sub-step loop itself (comm.hip, timestep.hip) ----
+     integer(c_int) function icar_hip_comm_unique_id(uid) bind(C, name="icar_hip_comm_unique_id")
+       import; character(kind=c_char) :: uid(128)
+     end function
+     integer(c_int) function icar_hip_comm_init(ctx, nranks, rank, uid, neighbors) bind(C, name="icar_hip_comm_init")
+       import; type(c_ptr), value :: ctx, uid; integer(c_int), value :: nranks, rank; integer(c_int), intent(in) :: neighbors(4)
+     end function
+     integer(c_int) function icar_hip_comm_init_host(ctx, nranks, rank, shm_name, slot_bytes, neighbors) bind(C, name="icar_hip_comm_init_host")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: nranks, rank; character(kind=c_char), intent(in) :: shm_name(*)
+       integer(c_size_t), value :: slot_bytes; integer(c_int), intent(in) :: neighbors(4)
+     end function
+     integer(c_int) function icar_hip_comm_destroy(ctx) bind(C, name="icar_hip_comm_destroy")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_halo_send(ctx, halo, fields, n) bind(C, name="icar_hip_halo_send")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: halo, n; integer(c_int), intent(in) :: fields(*)
+     end function
+     integer(c_int) function icar_hip_halo_retrieve(ctx, halo, fields, n) bind(C, name="icar_hip_halo_retrieve")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: halo, n; integer(c_int), intent(in) :: fields(*)
+     end function
+     integer(c_int) function icar_hip_co_min(ctx, v) bind(C, name="icar_hip_co_min")
+       import; type(c_ptr), value :: ctx; real(c_double), intent(inout) :: v
+     end function
+     integer(c_int) function icar_hip_step_configure(ctx, cfg, dz_levels) bind(C, name="icar_hip_step_configure")
+       import; type(c_ptr), value :: ctx; type(hip_step_config_t), intent(in) :: cfg; real(c_float), intent(in) :: dz_levels(*)
+     end function
+     integer(c_int) function icar_hip_model_time_set(ctx, seconds) bind(C, name="icar_hip_model_time_set")
+       import; type(c_ptr), value :: ctx; real(c_double), value :: seconds
+     end function
+     real(c_double) function icar_hip_model_time(ctx) bind(C, name="icar_hip_model_time")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_mp_reset(ctx) bind(C, name="icar_hip_mp_reset")
+       import; type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function icar_hip_compute_dt(ctx, dt) bind(C, name="icar_hip_compute_dt")
+       import; type(c_ptr), value :: ctx; real(c_double), intent(out) :: dt
+     end function
+     integer(c_int) function icar_hip_update_dt(ctx, dt) bind(C, name="icar_hip_update_dt")
+       import; type(c_ptr), value :: ctx; real(c_double), intent(out) :: dt
+     end function
+     integer(c_int) function icar_hip_mp(ctx, dt, halo, subset) bind(C, name="icar_hip_mp")
+       import; type(c_ptr), value :: ctx; real(c_double), value :: dt; integer(c_int), value :: halo, subset
+     end function
+     integer(c_int) function icar_hip_advect_step(ctx, dt) bind(C, name="icar_hip_advect_step")
+       import; type(c_ptr), value :: ctx; real(c_double), value :: dt
+     end function
+     integer(c_int) function icar_hip_substep(ctx, dt, enforce) bind(C, name="icar_hip_substep")
+       import; type(c_ptr), value :: ctx; real(c_double), value :: dt; integer(c_int), value :: enforce
+     end function
+     integer(c_int) function icar_hip_step(ctx, end_time, nsteps) bind(C, name="icar_hip_step")
+       import; type(c_ptr), value :: ctx; real(c_double), value :: end_time; integer(c_int), intent(out) :: nsteps
+     end function
   end interface
 
 contains
+
+  !> hand the library the options_t / grid_t members the loop reads; then hip_step == step(domain, end_time, options)
+  subroutine hip_step_configure(ctx, cfg, dz_levels)
+    type(hip_ctx_t), intent(in) :: ctx
+    type(hip_step_config_t), intent(in) :: cfg
+    real(c_float), intent(in) :: dz_levels(:)
+    call check(icar_hip_step_configure(ctx%p, cfg, dz_levels), "step_configure")
+  end subroutine
+
+  !> update_dt (time_step.f90:375-423): compute_dt + co_min over the images + the 120 s cap
+  function hip_update_dt(ctx) result(dt)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double) :: dt
+    call check(icar_hip_update_dt(ctx%p, dt), "update_dt")
+  end function
+
+  function hip_compute_dt(ctx) result(dt)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double) :: dt
+    call check(icar_hip_compute_dt(ctx%p, dt), "compute_dt")
+  end function
+
+  !> one pass of time_step.f90:474-539 (diagnostic_update ... enforce_limits), two streams inside the library
+  subroutine hip_substep(ctx, dt, enforce_limits)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double), intent(in) :: dt
+    logical, intent(in) :: enforce_limits
+    call check(icar_hip_substep(ctx%p, dt, merge(1_c_int,0_c_int,enforce_limits)), "substep")
+  end subroutine
+
+  !> step(domain, end_time, options) (time_step.f90:440-551); the model clock lives in the context (hip_model_time)
+  function hip_step(ctx, end_time) result(nsteps)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double), intent(in) :: end_time
+    integer :: nsteps
+    integer(c_int) :: n
+    call check(icar_hip_step(ctx%p, end_time, n), "step"); nsteps = n
+  end function
+
+  !> mp(domain, options, dt, halo, subset) (mp_driver.f90:673-772); absent halo / subset like the reference's optionals
+  subroutine hip_mp(ctx, dt, halo, subset)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double), intent(in) :: dt
+    integer, intent(in), optional :: halo, subset
+    integer(c_int) :: h, s
+    h = -1; s = -1
+    if (present(halo)) h = halo
+    if (present(subset)) s = subset
+    call check(icar_hip_mp(ctx%p, dt, h, s), "mp")
+  end subroutine
+
+  !> advect(domain, options, dt) (advection_driver.f90:51-77)
+  subroutine hip_advect_step(ctx, dt)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double), intent(in) :: dt
+    call check(icar_hip_advect_step(ctx%p, dt), "advect_step")
+  end subroutine
+
+  subroutine hip_mp_reset(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_mp_reset(ctx%p), "mp_reset")
+  end subroutine
+
+  function hip_model_time(ctx) result(t)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double) :: t
+    t = icar_hip_model_time(ctx%p)
+  end function
+
+  subroutine hip_set_model_time(ctx, seconds)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double), intent(in) :: seconds
+    call check(icar_hip_model_time_set(ctx%p, seconds), "model_time_set")
+  end subroutine
+
+  !> image 1 calls this and co_broadcasts the 128 bytes; every image then calls hip_comm_init (RCCL, one GPU per image)
+  subroutine hip_comm_unique_id(uid)
+    character(kind=c_char), intent(out) :: uid(128)
+    call check(icar_hip_comm_unique_id(uid), "comm_unique_id")
+  end subroutine
+
+  !> neighbors(1:4) = 0-based rank (= image - 1) of the north, south, east, west neighbour, ICAR_NEIGHBOR_NONE on a domain boundary
+  subroutine hip_comm_init(ctx, nranks, rank, uid, neighbors)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: nranks, rank
+    character(kind=c_char), intent(in), target :: uid(128)
+    integer(c_int), intent(in) :: neighbors(4)
+    call check(icar_hip_comm_init(ctx%p, int(nranks,c_int), int(rank,c_int), c_loc(uid), neighbors), "comm_init")
+  end subroutine
+
+  !> one image without peers (edges may wrap: ICAR_NEIGHBOR_SELF)
+  subroutine hip_comm_init_local(ctx, neighbors)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int), intent(in) :: neighbors(4)
+    call check(icar_hip_comm_init(ctx%p, 1_c_int, 0_c_int, c_null_ptr, neighbors), "comm_init")
+  end subroutine
+
+  !> the same entry points staged through POSIX shared memory: several images on one GPU (functional path)
+  subroutine hip_comm_init_host(ctx, nranks, rank, shm_name, slot_bytes, neighbors)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: nranks, rank
+    character(len=*), intent(in) :: shm_name
+    integer(c_size_t), intent(in) :: slot_bytes
+    integer(c_int), intent(in) :: neighbors(4)
+    call check(icar_hip_comm_init_host(ctx%p, int(nranks,c_int), int(rank,c_int), trim(shm_name)//c_null_char, slot_bytes, neighbors), "comm_init_host")
+  end subroutine
+
+  subroutine hip_comm_destroy(ctx)
+    type(hip_ctx_t), intent(in) :: ctx
+    call check(icar_hip_comm_destroy(ctx%p), "comm_destroy")
+  end subroutine
+
+  !> domain%halo_send / halo_retrieve (domain_obj.f90:109-143) for the listed exchangeables, one message per neighbour
+  subroutine hip_halo_send(ctx, halo, fields)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: halo
+    integer(c_int), intent(in) :: fields(:)
+    call check(icar_hip_halo_send(ctx%p, int(halo,c_int), fields, int(size(fields),c_int)), "halo_send")
+  end subroutine
+  subroutine hip_halo_retrieve(ctx, halo, fields)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: halo
+    integer(c_int), intent(in) :: fields(:)
+    call check(icar_hip_halo_retrieve(ctx%p, int(halo,c_int), fields, int(size(fields),c_int)), "halo_retrieve")
+  end subroutine
+
+  !> call co_min(seconds) (time_step.f90:413)
+  subroutine hip_co_min(ctx, v)
+    type(hip_ctx_t), intent(in) :: ctx
+    real(c_double), intent(inout) :: v
+    call check(icar_hip_co_min(ctx%p, v), "co_min")
+  end subroutine
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc

@@ -1,17 +1,19 @@
-"""Halo transport between tiles: the coarray PUT + `sync images` pattern of
-src/objects/exchangeable_obj.f90:138-356 re-expressed as batched neighbour send/recv.
+"""Halo topology of a tile and its transport: the coarray PUT + `sync images` pattern of
+src/objects/exchangeable_obj.f90:138-356 re-expressed as one batched message per neighbour.
 
-One message per neighbour per step carries ALL exchanged scalars (the reference issues one PUT per
-variable per direction; at 512x512x40 on 2x2 those are 41 kB each and latency-bound, SURVEY.md
-section 5).  Transport is torch.distributed P2P: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo"
-in the CPU tests.  RCCL runs the transfers on its own stream, so the interior microphysics issued
-between send() and retrieve() overlaps them exactly as time_step.f90:512-526 orders it.
+For a device tile (domain_t) the transport lives BEHIND THE C ABI (icar_amd/csrc/comm.hip): HaloComm.attach()
+hands the library the neighbour ranks and initialises its communicator -- RCCL over xGMI when torch.distributed runs on
+"nccl" (the unique id travels through one broadcast), the host-staged shared-memory path when it runs on "gloo" (several
+images sharing one GPU: a functional check) -- and domain_t.halo_send / halo_retrieve / update_dt call
+icar_hip_halo_send / icar_hip_halo_retrieve / icar_hip_update_dt.  torch.distributed is only the launcher's rendezvous.
 
+The send() / retrieve() methods below drive a HOST-array double of the tile (tests/host_tile.py) over torch.distributed
+P2P: the CPU-side statement of the same exchange, which the world-size-2/4 gloo tests and the tiled CPU oracle runs use.
 The tile object only has to provide
     halo_count(dir, halo) -> elements per field
     halo_pack(dir, halo, field_ids, buffer) / halo_unpack(dir, halo, field_ids, buffer)
-    new_buffer(n) -> 1-D float32 torch tensor on the tile's device
-domain_t implements them with the HIP pack/unpack kernels; tests use a host-array double.
+    new_buffer(n) -> 1-D float32 torch tensor
+exchange_uv() (iterative_winds' exchange_u / exchange_v, per forcing step, not on the sub-step path) serves both kinds of tile.
 """
 import torch
 import torch.distributed as dist
@@ -61,6 +63,35 @@ class HaloComm:
         self._reqs = []
         self._nf = None
         self._stage = False
+
+    def attach(self, domain):
+        """Initialise the library's communicator of a device tile (icar_hip_comm_init / _init_host): collective over the
+        images.  Edges that wrap (loopback) become ICAR_NEIGHBOR_SELF, boundaries ICAR_NEIGHBOR_NONE."""
+        import ctypes
+        from .capi import lib, check, NEIGHBOR_NONE, NEIGHBOR_SELF
+        nb = [self.peers[d] if d in self.peers else (NEIGHBOR_SELF if d in self.loop else NEIGHBOR_NONE) for d in (0, 1, 2, 3)]
+        arr = (ctypes.c_int * 4)(*nb)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not multi:
+            if self.peers:
+                raise RuntimeError("HaloComm: neighbouring images but no torch.distributed process group")
+            check(lib().icar_hip_comm_init(domain.ctx, 1, 0, None, arr), "icar_hip_comm_init")
+            return
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        if dist.get_backend(self.group) == "nccl":
+            uid = ctypes.create_string_buffer(128)
+            if rank == 0:
+                check(lib().icar_hip_comm_unique_id(uid), "icar_hip_comm_unique_id")
+            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).to(f"cuda:{domain.device}")
+            dist.broadcast(t, 0, group=self.group)                      # co_broadcast(uid, 1) in a coarray host
+            check(lib().icar_hip_comm_init(domain.ctx, world, rank, bytes(t.cpu().numpy().tobytes()), arr), "icar_hip_comm_init")
+        else:
+            import os
+            name = [f"icar_hip_{os.getpid()}_{id(self) & 0xffffff:x}" if rank == 0 else None]
+            dist.broadcast_object_list(name, 0, group=self.group)
+            need = torch.tensor([max(domain.halo_count(d, self.halo) for d in (0, 1, 2, 3)) * 4 * 11], dtype=torch.int64)
+            dist.all_reduce(need, op=dist.ReduceOp.MAX, group=self.group)
+            check(lib().icar_hip_comm_init_host(domain.ctx, world, rank, name[0].encode(), int(need.item()), arr), "icar_hip_comm_init_host")
 
     def _buffers(self, tile, nfields):
         if self._nf != nfields:

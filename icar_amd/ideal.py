@@ -167,3 +167,25 @@ def cfl_dt(case, cfl=0.9):
     wl = np.concatenate([w[:, :1, :], w[:, :-1, :]], axis=1)
     mw = np.maximum(np.abs(w), np.abs(wl)) / dzl[None, :, None]
     return float(cfl / (mu + mv + mw).max())
+
+
+def cut_tile(case, grid):
+    """The part of a whole-domain case a grid_t tile holds in memory (ims..ime, jms..jme, halos included): what every image
+    reads from the same input file in the reference (domain_obj.f90 read_domain_shape / setup).  Staggered members keep their
+    extra column / row; scalars and 1-D members pass through."""
+    g = grid
+    nxg, nyg = case["nx"], case["ny"]
+    tile = {}
+    for k, v in case.items():
+        if not isinstance(v, np.ndarray) or v.ndim < 2:
+            tile[k] = v
+        elif v.ndim == 2:
+            tile[k] = np.ascontiguousarray(v[g.jms - 1:g.jme, g.ims - 1:g.ime])
+        elif v.shape[2] == nxg + 1:
+            tile[k] = np.ascontiguousarray(v[g.jms - 1:g.jme, :, g.ims - 1:g.ime + 1])
+        elif v.shape[0] == nyg + 1:
+            tile[k] = np.ascontiguousarray(v[g.jms - 1:g.jme + 1, :, g.ims - 1:g.ime])
+        else:
+            tile[k] = np.ascontiguousarray(v[g.jms - 1:g.jme, :, g.ims - 1:g.ime])
+    tile["nx"], tile["ny"] = g.ime - g.ims + 1, g.jme - g.jms + 1
+    return tile

@@ -56,7 +56,7 @@ def mp_init(options, domain=None):
             raise ValueError("mp_init(options, domain): the WSM3 constants live in the domain's device context")
         check(lib().icar_hip_wsm3_init(domain.ctx), "icar_hip_wsm3_init")
     if domain is not None:
-        domain.mp_state = dict(last_model_time=-999.0)       # the module SAVE variables live on the domain object
+        check(lib().icar_hip_mp_reset(domain.ctx), "icar_hip_mp_reset")      # the module SAVE variable last_model_time lives in the context
 
 
 def mp_tiles(its, ite, jts, jte, halo=0, subset=0):
@@ -66,68 +66,16 @@ def mp_tiles(its, ite, jts, jte, halo=0, subset=0):
     return [tuple(t[i]) for i in range(n)]
 
 
-def _process_subdomain(domain, options, dt, its, ite, jts, jte, kts, kte):
-    g = domain.grid
-    mp_ = options.physics.microphysics
-    if ite < its or jte < jts:
-        return
-    if mp_ == kMP_SB04:
-        check(lib().icar_hip_mp_simple(domain.ctx, ctypes.c_float(dt), its, ite, jts, jte, kts, kte, None),
-              "icar_hip_mp_simple")
-    elif mp_ == kMP_WSM6:
-        check(lib().icar_hip_wsm6(domain.ctx, ctypes.c_float(dt), its, ite, jts, jte, kts, kte), "icar_hip_wsm6")
-    elif mp_ == kMP_WSM3:
-        check(lib().icar_hip_wsm3(domain.ctx, ctypes.c_float(dt), its, ite, jts, jte, kts, kte), "icar_hip_wsm3")
-    elif mp_ == kMP_THOMPSON:
-        check(lib().icar_hip_thompson(domain.ctx, ctypes.c_float(dt), its, ite, jts, jte, kts, kte,
-                                      g.ids, g.ide, g.jds, g.jde, g.kds, g.kde), "icar_hip_thompson")
-
-
 def mp(domain, options, dt_in, halo=None, subset=None):
-    """mp_driver.f90:673-772 including the update_interval gating (:698-713)."""
+    """mp(domain, options, dt_in, halo, subset) (mp_driver.f90:673-772) including the update_interval gating (:698-713) and
+    process_halo's strips (:609-658): icar_hip_mp, the same entry point a Fortran host calls."""
     if options.physics.microphysics == 0:
         return
-    st = domain.mp_state
-    upd = float(options.mp_options.update_interval)
-    now = domain.model_time_seconds
-    if st["last_model_time"] == -999.0:
-        st["last_model_time"] = now - max(upd, float(dt_in))
-    if ((now + dt_in) - st["last_model_time"]) >= upd:
-        mp_dt = now - st["last_model_time"]
-        if halo is None:
-            st["last_model_time"] = now
-        g = domain.grid
-        kte = g.kte
-        if options.mp_options.top_mp_level > 0:
-            kte = min(kte, options.mp_options.top_mp_level)
-        if subset is not None:
-            for (a, b, c, d) in mp_tiles(g.its, g.ite, g.jts, g.jte, subset=subset):
-                _process_subdomain(domain, options, mp_dt, a, b, c, d, g.kts, kte)
-        if halo is not None:
-            tiles = mp_tiles(g.its, g.ite, g.jts, g.jte, halo=halo)
-            h = int(halo)
-            # a tile narrower than 2*halo makes the west/east (or south/north) strips overlap: the reference then runs
-            # those columns once per strip, one strip after the other -- a single batched launch would race on them
-            overlapping = (g.ite - g.its + 1 < 2 * h) or (g.jte - g.jts + 1 < 2 * h)
-            if options.physics.microphysics in (kMP_THOMPSON, kMP_SB04, kMP_WSM6) and not overlapping:
-                # process_halo's four strips in one launch (icar_hip_thompson_tiles / icar_hip_mp_simple_tiles / icar_hip_wsm6_tiles)
-                tiles = [t for t in tiles if t[1] >= t[0] and t[3] >= t[2]]
-                arr = ((ctypes.c_int * 4) * len(tiles))(*[(ctypes.c_int * 4)(*t) for t in tiles])
-                if tiles and options.physics.microphysics == kMP_THOMPSON:
-                    check(lib().icar_hip_thompson_tiles(domain.ctx, ctypes.c_float(mp_dt), len(tiles), arr, g.kts, kte,
-                                                        g.ids, g.ide, g.jds, g.jde, g.kds, g.kde), "icar_hip_thompson_tiles")
-                elif tiles and options.physics.microphysics == kMP_WSM6:
-                    check(lib().icar_hip_wsm6_tiles(domain.ctx, ctypes.c_float(mp_dt), len(tiles), arr, g.kts, kte), "icar_hip_wsm6_tiles")
-                elif tiles:
-                    check(lib().icar_hip_mp_simple_tiles(domain.ctx, ctypes.c_float(mp_dt), len(tiles), arr, g.kts, kte, None),
-                          "icar_hip_mp_simple_tiles")
-            else:
-                for (a, b, c, d) in tiles:
-                    _process_subdomain(domain, options, mp_dt, a, b, c, d, g.kts, kte)
-        if halo is None and subset is None:
-            _process_subdomain(domain, options, mp_dt, g.its, g.ite, g.jts, g.jte, g.kts, kte)
+    domain.configure(options)
+    check(lib().icar_hip_mp(domain.ctx, float(dt_in), -1 if halo is None else int(halo), -1 if subset is None else int(subset)),
+          "icar_hip_mp")
 
 
 def mp_finish(options, domain=None):
     if domain is not None:
-        domain.mp_state = dict(last_model_time=-999.0)
+        check(lib().icar_hip_mp_reset(domain.ctx), "icar_hip_mp_reset")

@@ -337,6 +337,79 @@ int icar_hip_halo_unpack(icar_hip_ctx *ctx, int dir, int halo, const int *fields
 int icar_hip_halo_pack_dirs(icar_hip_ctx *ctx, int ndirs, const int *dirs, int halo, const int *fields, int nfields, void *const *dbufs);
 int icar_hip_halo_unpack_dirs(icar_hip_ctx *ctx, int ndirs, const int *dirs, int halo, const int *fields, int nfields, void *const *dbufs);
 
+/* ---- H1 transport + co_min: domain%halo_send / halo_retrieve (src/objects/domain_obj.f90:109-143 over
+ * src/objects/exchangeable_obj.f90:138-356) and `call co_min(seconds)` (src/main/time_step.f90:413) -------------------
+ * One message per neighbour carries every exchanged scalar (the reference PUTs once per variable and direction).
+ * neighbors[dir] (dir 0=north 1=south 2=east 3=west) is the 0-based rank of the image on that side (= image - 1 of
+ * grid_t's neighbour), ICAR_NEIGHBOR_NONE at a domain boundary, or ICAR_NEIGHBOR_SELF for an edge that wraps around to the
+ * tile's own opposite edge (periodic single image, what src/tests/test_mpdata.f90 does by hand; both edges of an axis).
+ *   icar_hip_comm_init       RCCL (ncclSend / ncclRecv over xGMI on the context's stream, nothing waits on the host).
+ *                            uid = the 128 bytes image 1 got from icar_hip_comm_unique_id and broadcast (co_broadcast in a
+ *                            coarray host); uid == NULL is allowed for one image without peers.
+ *                            One GPU per image: RCCL refuses two ranks on one device.
+ *   icar_hip_comm_init_host  the same entry points with the messages staged through POSIX shared memory `shm_name`
+ *                            (unique per run; slot_bytes >= the largest message = max halo_count * number of exchanged
+ *                            fields * 4, the same on every image): for boxes with fewer GPUs than images.  A functional
+ *                            path, not a fast one.
+ * halo_send packs (one launch) and posts the transfers; halo_retrieve is the `sync images` + unpack (one launch, the
+ * reference's N, S, E, W precedence at the corner cells).  Exactly one halo_retrieve per halo_send, same arguments. */
+enum { ICAR_NEIGHBOR_NONE = -1, ICAR_NEIGHBOR_SELF = -2 };
+enum { ICAR_COMM_NONE = 0, ICAR_COMM_LOCAL = 1, ICAR_COMM_RCCL = 2, ICAR_COMM_HOST = 3 };
+int icar_hip_comm_unique_id(char uid[128]);
+int icar_hip_comm_init(icar_hip_ctx *ctx, int nranks, int rank, const char uid[128], const int neighbors[4]);
+int icar_hip_comm_init_host(icar_hip_ctx *ctx, int nranks, int rank, const char *shm_name, size_t slot_bytes, const int neighbors[4]);
+int icar_hip_comm_destroy(icar_hip_ctx *ctx);
+int icar_hip_comm_kind(icar_hip_ctx *ctx);                      /* ICAR_COMM_* */
+int icar_hip_halo_send(icar_hip_ctx *ctx, int halo, const int *fields, int nfields);
+int icar_hip_halo_retrieve(icar_hip_ctx *ctx, int halo, const int *fields, int nfields);
+/* in/out: *value becomes the minimum (maximum) over the images; one image: unchanged */
+int icar_hip_co_min(icar_hip_ctx *ctx, double *value);
+int icar_hip_co_max(icar_hip_ctx *ctx, double *value);
+
+/* ---- T1 / T2 / M0: the sub-step loop itself (src/main/time_step.f90:440-551) ----------------------------------------
+ * icar_hip_step_configure hands the library the members of options_t / grid_t the loop reads; after that
+ *   icar_hip_compute_dt  == compute_dt (:217-330) on this image's tile
+ *   icar_hip_update_dt   == update_dt (:375-423): compute_dt (:217-330, every cfl_strictness) + co_min + the 120 s cap;
+ *                           fails with "ERROR time step too small" where the reference stops (:322-328)
+ *   icar_hip_mp          == mp(domain, options, dt, halo, subset) (src/physics/mp_driver.f90:673-772) incl. the
+ *                           update_interval gating (:698-713); halo / subset < 0 = argument not present
+ *   icar_hip_advect_step == advect(domain, options, dt) (src/physics/advection_driver.f90:51-77)
+ *   icar_hip_substep     == one pass of :474-539: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) ->
+ *                           halo_retrieve -> advect -> apply_forcing [-> enforce_limits], with the interior microphysics and
+ *                           the streaming kernels issued on the context's second stream beside the heavy ones
+ *   icar_hip_step        == step(domain, end_time, options) (:440-551); the model clock lives in the context
+ * The library keeps the model clock (domain%model_time) and mp_driver.f90's SAVE variable last_model_time. */
+typedef struct icar_hip_step_config {
+    int advection;                  /* options%physics%advection: 0, ICAR_ADV_UPWIND, ICAR_ADV_MPDATA            */
+    int microphysics;               /* options%physics%microphysics: 0, 1 Thompson, 2 mp_simple, 4 WSM6, 6 WSM3  */
+    int mpdata_order;               /* options%adv_options%mpdata_order                                           */
+    int flux_corrected_transport;   /* options%adv_options%flux_corrected_transport                               */
+    int advect_density;             /* options%parameters%advect_density                                          */
+    int cfl_strictness;             /* options%parameters%cfl_strictness (1..5)                                   */
+    float cfl_reduction_factor;     /* options%parameters%cfl_reduction_factor                                    */
+    float dx;                       /* domain%dx                                                                  */
+    float mp_update_interval;       /* options%mp_options%update_interval                                         */
+    int top_mp_level;               /* options%mp_options%top_mp_level                                            */
+    int halo_size;                  /* grid%halo_size                                                             */
+    int its, ite, jts, jte, kts, kte, ids, ide, jds, jde, kds, kde;                     /* grid_t                 */
+    int west_boundary, east_boundary, south_boundary, north_boundary;                   /* grid_t                 */
+    int diagnostics;                /* 1: diagnostic_update at the top of the sub-step (:474), as the reference   */
+    int prefetch_dt;                /* 1: take the CFL reduction of the next update_dt beside the advection       */
+    int n_advect, advect_fields[ICAR_N_ADVECTABLE];      /* options%vars_to_advect in the dispatch order of adv_mpdata.f90:512-522 */
+    int n_exchange, exchange_fields[ICAR_N_ADVECTABLE];  /* the exchangeable members, halo_send order               */
+    int n_forced, forced_fields[16], force_boundaries[16];   /* apply_forcing's variables (domain_obj.f90:2383-2448) */
+} icar_hip_step_config;
+int icar_hip_step_configure(icar_hip_ctx *ctx, const icar_hip_step_config *cfg, const float *dz_levels);
+int icar_hip_model_time_set(icar_hip_ctx *ctx, double seconds);
+double icar_hip_model_time(const icar_hip_ctx *ctx);
+int icar_hip_mp_reset(icar_hip_ctx *ctx);                       /* mp_init / mp_finish: last_model_time = -999 */
+int icar_hip_compute_dt(icar_hip_ctx *ctx, double *dt_seconds);   /* compute_dt alone: this image, no co_min, no cap */
+int icar_hip_update_dt(icar_hip_ctx *ctx, double *dt_seconds);
+int icar_hip_mp(icar_hip_ctx *ctx, double dt, int halo, int subset);
+int icar_hip_advect_step(icar_hip_ctx *ctx, double dt);
+int icar_hip_substep(icar_hip_ctx *ctx, double dt_seconds, int enforce_limits);
+int icar_hip_step(icar_hip_ctx *ctx, double end_time_seconds, int *nsteps);
+
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Average duration (ms) of the launches of a named kernel group since the last reset, measured
  * with HIP events on the context's stream (bench.py roofline block). group: "advect", "mp". */

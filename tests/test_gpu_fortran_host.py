@@ -122,3 +122,78 @@ def test_fortran_step_loop_matches_python_step(tmp_path):
     got = np.fromfile(tmp_path / "out_precip.bin", np.float64).reshape(ny, nx)
     assert np.array_equal(got, d.get("accumulated_precipitation")) and got.max() > 0
     d.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_fortran_images_exchange_halos_through_the_library(tmp_path, world):
+    """icar_hip_tiles_demo.f90: `world` OS processes, one image each, share the GPU of the box; each runs
+    step(domain, end_time, options) as ONE library call (hip_step) on its grid_t tile -- update_dt with co_min over the images,
+    mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect per sub-step, halos through icar_hip_comm_init_host
+    (the host-staged form of the library's transport: RCCL refuses two ranks on one device).  Upwind + mp_simple have radius-1
+    stencils / column physics, so every OWNED cell must equal the single-image run of the same library bit for bit, with the
+    same number of sub-steps."""
+    from icar_amd.grid import grid_t
+    from icar_amd.options import options_t
+    from icar_amd.time_step import step, update_dt
+    from icar_amd.microphysics import mp_init, mp_var_request
+    from icar_amd.advection import adv_init
+    from icar_amd.constants import kADV_UPWIND, kMP_SB04, ADVECTION_ORDER
+    from util import single_image_domain
+    b.build_fortran_host()
+    demo = b.TILES_DEMO
+    if not os.path.exists(demo):
+        pytest.skip("flang not available to build the Fortran host")
+    nxg, nyg, nz = 64, 48, 12
+    c = ideal.make_case(nxg, nyg, nz, hill_height=700.0, noise=0.02, n_hydro=1, exact=True)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(2.4)).astype(np.float32)
+    opt = options_t()
+    opt.physics.advection = kADV_UPWIND; opt.physics.microphysics = kMP_SB04
+    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"])
+    mp_var_request(opt)
+    d = single_image_domain(c)
+    mp_init(opt, d); adv_init(d, opt)
+    end_time = 3.6 * update_dt(d, opt)
+    nsteps = step(d, end_time, opt, diagnostics=False)
+    names = ["w", "pressure", "exner", "density", "dz_mass", "jacobian", "jacobian_w", "advection_dz", "water_vapor", "cloud_water",
+             "rain", "snow", "potential_temperature", "u", "v", "jacobian_u", "jacobian_v"]
+    procs, grids = [], []
+    shm = f"icar_hip_f90_{os.getpid()}_{world}"
+    slot = 0
+    for r in range(world):
+        g = grid_t().set_grid_dimensions(nxg, nyg, nz, world, r + 1)
+        grids.append(g)
+        slot = max(slot, 4 * 5 * nz * max(g.ime - g.ims + 1, g.jme - g.jms + 1))
+    for r, g in enumerate(grids):
+        t = ideal.cut_tile(c, g)
+        dr = tmp_path / f"image{r + 1}"; dr.mkdir()
+        for n in names:
+            t[n].tofile(dr / f"{n}.bin")
+        np.ascontiguousarray(c["dz_levels"], np.float32).tofile(dr / "dz_levels.bin")
+        nb = g.neighbors(r + 1)
+        nbr = [(-1 if nb[k] is None else nb[k] - 1) for k in ("north", "south", "east", "west")]
+        (dr / "meta.txt").write_text(
+            f"{g.ims} {g.ime} {g.jms} {g.jme} {nz}\n{g.its} {g.ite} {g.jts} {g.jte}\n{g.ids} {g.ide} {g.jds} {g.jde}\n"
+            f"{nbr[0]} {nbr[1]} {nbr[2]} {nbr[3]}\n{int(g.west_boundary)} {int(g.east_boundary)} {int(g.south_boundary)} {int(g.north_boundary)}\n"
+            f"{end_time!r} {float(c['dx'])!r} {slot}\n")
+    for r in range(world):
+        procs.append(subprocess.Popen([demo, str(tmp_path / f"image{r + 1}"), str(r), str(world), shm],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "icar_hip_tiles_demo: ok" in o, f"image {r + 1}: {o}"
+        assert int(o.split("ok")[1].split()[0]) == nsteps, (o, nsteps)
+    member = {"water_vapor": "water_vapor", "cloud_water": "cloud_water_mass", "rain": "rain_mass", "snow": "snow_mass",
+              "potential_temperature": "potential_temperature"}
+    whole = {n: d.get(m) for n, m in member.items()}
+    acc = d.get("accumulated_precipitation")
+    assert float(whole["cloud_water"].max()) > 1e-5 and acc.max() > 0, "the case must have active microphysics"
+    for r, g in enumerate(grids):
+        tnx, tny = g.ime - g.ims + 1, g.jme - g.jms + 1
+        oj = slice(g.jts - g.jms, g.jte - g.jms + 1); oi = slice(g.its - g.ims, g.ite - g.ims + 1)
+        gj = slice(g.jts - 1, g.jte); gi = slice(g.its - 1, g.ite)
+        for n in member:
+            got = np.fromfile(tmp_path / f"image{r + 1}" / f"out_{n}.bin", np.float32).reshape(tny, nz, tnx)
+            assert np.array_equal(got[oj, :, oi], whole[n][gj, :, gi]), f"image {r + 1} {n}: owned cells differ from the single-image run"
+        got = np.fromfile(tmp_path / f"image{r + 1}" / "out_precip.bin", np.float64).reshape(tny, tnx)
+        assert np.array_equal(got[oj, oi], acc[gj, gi]), f"image {r + 1}: precipitation"
+    d.close()

@@ -1,6 +1,7 @@
 """N>1 path with the REAL device tiles: `world` processes share cuda:0 (the GPU box has one GPU), each owns one tile
-of the grid_t decomposition, halos travel through HaloComm over gloo (device buffers staged through pinned host
-memory; on the 8-GPU node the same class hands the device buffers to RCCL).  The whole step() sequence of
+of the grid_t decomposition, halos travel through the library's own transport (icar_hip_halo_send / _retrieve, comm.hip) in its
+host-staged shared-memory form -- RCCL refuses two ranks on one device; on the 8-GPU node the same entry points post ncclSend /
+ncclRecv.  torch.distributed (gloo) is only the rendezvous.  The whole step() sequence of
 time_step.f90 runs per tile: update_dt (co_min) -> mp(halo) -> halo_send -> mp(subset) -> halo_retrieve -> advect.
 
 With upwind advection (radius-1 stencil) + column microphysics the tiled run must equal the single-tile run on every
@@ -75,7 +76,6 @@ def _worker(rank, world, port, adv, q):
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
-        solo = dist.new_group(ranks=[0])              # rank 0's single-tile reference run must not enter the world's co_min
         torch.cuda.set_device(0)
         from icar_amd import ideal
         from icar_amd.grid import grid_t
@@ -96,8 +96,8 @@ def _worker(rank, world, port, adv, q):
         if rank == 0:                                 # the same steps on ONE tile covering the whole domain
             g1 = grid_t().set_grid_dimensions(NXG, NYG, NZ, 1, 1)
             d1 = _setup(case, g1, opt, None)
-            dt1 = update_dt(d1, opt, group=solo)
-            n1 = step(d1, NSTEPS * dt1 * 0.999, opt, group=solo, diagnostics=False)
+            dt1 = update_dt(d1, opt)                   # no communicator: this image alone
+            n1 = step(d1, NSTEPS * dt1 * 0.999, opt, diagnostics=False)
             ref = {k: d1.get(k) for k in names}; ref["acc"] = d1.get("accumulated_precipitation"); ref["dt"] = dt1; ref["n"] = n1
             d1.close()
         obj = [ref]; dist.broadcast_object_list(obj, src=0); ref = obj[0]

@@ -46,7 +46,7 @@ def run(oracle, k, mode, split=False):
             B["potential_temperature"] -= np.float32(k["cool"])
             if split == "two_streams":
                 from icar_amd.time_step import mp_and_halo
-                mp_and_halo(d, opt, dt, prepare_advection=False)      # strips on the main stream, interior on the second one
+                mp_and_halo(d, opt, dt)      # strips on the main stream, interior on the second one
             elif split:
                 mp(d, opt, dt, halo=1); mp(d, opt, dt, subset=1)      # strips + interior == whole tile
             else:

@@ -31,35 +31,3 @@ def test_without_loopback_a_single_image_exchanges_nothing():
     comm = HaloComm(g, 1)
     comm.send(HostTile(g, {0: a}), [0]); comm.retrieve(HostTile(g, {0: a}), [0])
     assert np.array_equal(a, a0) and not comm.loop
-
-
-class _FakeDomain:
-    """records the order of the calls mp_and_halo makes (time_step.f90:512-526 + the second stream)"""
-    def __init__(self):
-        self.log = []; self.model_time_seconds = 0.0; self.mp_state = dict(last_model_time=-999.0)
-    def __getattr__(self, name):
-        if name in ("aux_fork", "aux_begin", "aux_end", "aux_join", "halo_send", "halo_retrieve"):
-            return lambda: self.log.append(name)
-        raise AttributeError(name)
-
-
-def test_mp_and_halo_orders_strips_exchange_interior(monkeypatch):
-    from icar_amd import time_step
-    from icar_amd.options import options_t
-    from icar_amd.constants import kMP_THOMPSON, kMP_WSM3
-    calls = []
-    from icar_amd import advection
-    monkeypatch.setattr(time_step, "mp", lambda d, o, dt, halo=None, subset=None: d.log.append("mp_halo" if halo else "mp_subset"))
-    monkeypatch.setattr(advection, "setup_winds", lambda d, o, dt: d.log.append("setup_winds"))
-    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
-    d = _FakeDomain()
-    time_step.mp_and_halo(d, opt, 10.0)
-    # the wind setup of the following advect() goes out on the main stream while the interior runs on the second one
-    assert d.log == ["aux_fork", "mp_halo", "halo_send", "aux_begin", "mp_subset", "aux_end", "setup_winds", "aux_join", "halo_retrieve"]
-    d = _FakeDomain()
-    time_step.mp_and_halo(d, opt, 10.0, prepare_advection=False)
-    assert d.log == ["aux_fork", "mp_halo", "halo_send", "aux_begin", "mp_subset", "aux_end", "aux_join", "halo_retrieve"]
-    opt.physics.microphysics = 0                            # no microphysics: nothing to put on a second stream
-    d = _FakeDomain()
-    time_step.mp_and_halo(d, opt, 10.0)
-    assert d.log == ["mp_halo", "halo_send", "mp_subset", "halo_retrieve"]
