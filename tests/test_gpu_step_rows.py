@@ -320,3 +320,54 @@ def test_prefetched_courant_is_used_only_while_the_winds_stand(oracle):
     m2 = np.float32(oracle.max_courant(u2, v2, c["w"], c["dz_levels"], float(c["dx"])))
     assert compute_dt(d, opt) == float(np.float32(0.9) / m2)
     d.close()
+
+
+@pytest.mark.parametrize("mpname", ["none", "simple"])
+def test_substep_equals_the_plain_sequence(mpname):
+    """icar_hip_substep issues the streaming kernels beside the heavy ones on a second stream (the interior microphysics and the
+    wind setup beside the strips + exchange; w_real, the whole-field forcing of u, v, w, p and the next CFL reduction beside the
+    advection).  It must give exactly what the plain sequence of time_step.f90:474-539 gives on one stream -- including without
+    a microphysics scheme, where the wind setup of advect() has to be issued BEFORE the second stream forks (it reads the
+    winds the forcing rewrites)."""
+    from icar_amd.time_step import substep, update_dt
+    from icar_amd.microphysics import mp, mp_init, mp_var_request
+    from icar_amd.advection import advect, adv_init
+    from icar_amd.constants import kADV_MPDATA, kMP_SB04, ADVECTION_ORDER
+    c = ideal.make_case(70, 44, 14, hill_height=800.0, noise=0.02, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(2.0)).astype(np.float32)
+    rng = np.random.default_rng(11)
+    c["dzdx"] = (0.05 * rng.standard_normal(c["u"].shape)).astype(np.float32)
+    c["dzdy"] = (0.05 * rng.standard_normal(c["v"].shape)).astype(np.float32)
+    dq = {"water_vapor": 1e-7, "potential_temperature": 1e-4, "u": 2e-3, "v": -2e-3, "pressure": 1e-3, "w": 1e-5}
+    dq = {k: (s * rng.standard_normal(c[k].shape)).astype(np.float32) for k, s in dq.items()}
+    forced = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
+    opt = options_t()
+    opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_SB04 if mpname == "simple" else 0
+    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"]); opt.parameters.ideal = True
+    mp_var_request(opt)
+
+    def fresh():
+        d = single_image_domain(c)
+        mp_init(opt, d); adv_init(d, opt)
+        for k, a in dq.items():
+            d.set_dqdt(k, a)
+        return d
+    a, b = fresh(), fresh()
+    names = [KV for KV in ("water_vapor", "cloud_water_mass", "rain_mass", "snow_mass", "potential_temperature", "u", "v", "w", "pressure",
+                           "w_real", "density", "exner")]
+    for it in range(4):
+        dta, dtb = update_dt(a, opt), update_dt(b, opt)
+        assert dta == dtb
+        substep(a, opt, dta, forced=forced, enforce=(it == 3))
+        a.model_time_seconds += dta
+        b.diagnostic_update()                                                # :474
+        mp(b, opt, dtb)                                                      # the whole tile at once, one stream
+        advect(b, opt, dtb)                                                  # :529
+        b.apply_forcing(dtb, forced)                                         # :534
+        if it == 3:
+            b.enforce_limits([n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0])
+        b.model_time_seconds += dtb
+        for n in names:
+            x, y = a.get(n), b.get(n)
+            assert np.array_equal(x, y), f"{mpname} step {it} {n}: {(x != y).sum()} cells differ"
+    a.close(); b.close()
