@@ -24,6 +24,7 @@
 //  * W2 is per forcing step, bandwidth/gather bound; running sums of smooth_array are kept sequential (one
 //    thread per line) so that the result is bit-identical to the reference's FP64 running sums.
 #include "ctx.h"
+#include "glibc_flt32.h"
 #include <rocfft/rocfft.h>
 #include <cmath>
 #include <vector>
@@ -644,9 +645,10 @@ struct LtDev {
     const float *dirv, *spdv, *nsqv;
 };
 
-__device__ __forceinline__ float w_logf(float x) { return (float)log((double)x); }
-__device__ __forceinline__ float w_expf(float x) { return (float)exp((double)x); }
-__device__ __forceinline__ float w_atanf(float x) { return (float)atan((double)x); }
+// REAL(4) log / exp / atan as the compiled reference evaluates them: the C library's logf / expf / atanf (glibc_flt32.h)
+__device__ __forceinline__ float w_logf(float x) { return gf_logf(x); }
+__device__ __forceinline__ float w_expf(float x) { return gf_expf(x); }
+__device__ __forceinline__ float w_atanf(float x) { return gf_atanf(x); }
 
 #define LW_PI 3.1415927f
 #define LW_LH 2260000.0f

@@ -12,7 +12,7 @@
 // exp() is evaluated in FP64 and rounded once so that it agrees with the host libm's correctly
 // rounded expf in all but ~1e-3 of evaluations (documented tolerance in tests/).
 #include "ctx.h"
-#include "fp64_math.h"
+#include "glibc_flt32.h"
 #include "column_comm.h"
 #include <cmath>
 #include <cstdlib>
@@ -23,7 +23,7 @@ constexpr float LH_vapor = 2.26E6f, dLHvdt = 2400.0f, LH_liquid = 3.34E5f, heat_
 constexpr float SMALL_VALUE = 1E-30f, freezing_threshold = 273.15f;
 constexpr float snow_fall_rate = 1.5f, rain_fall_rate = 10.0f, snow_cloud_init = 0.0001f, rain_cloud_init = 0.0001f;
 
-__device__ __forceinline__ float expf_cr(float x) { return (float)d_exp((double)x); }
+__device__ __forceinline__ float expf_cr(float x) { return gf_expf(x); }          // the C library's expf, bit for bit (glibc_flt32.h)
 
 __device__ __forceinline__ float sat_mr(float temperature, float pressure)
 {   // mp_simple.f90:146-182

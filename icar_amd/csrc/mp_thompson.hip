@@ -15,6 +15,7 @@
 #include "ctx.h"
 #include "thompson_state.h"
 #include "fp64_math.h"
+#include "glibc_flt32.h"
 #include "column_comm.h"
 #include <cmath>
 #include <cstdlib>
@@ -51,18 +52,33 @@ __device__ __forceinline__ double d_pow_k(const DK &K_, double x, double y)
     }
     return r;
 }
-__device__ __forceinline__ float d_powf_k(const DK &K_, float x, float y) { return (float)d_pow((double)x, (double)y); }
-// the same values from L = d_log(x) of a base x > 0 that several powers share (one logarithm instead of one per power)
+// the same values from L = d_log(x) of a DOUBLE PRECISION base x > 0 that several powers share (one logarithm instead of one per power)
 __device__ __forceinline__ double d_pow_l_k(const DK &K_, double L, double y) { return (y == 0.0) ? 1.0 : d_exp(y * L); }
-__device__ __forceinline__ float d_powf_l_k(const DK &K_, double L, float y) { return (float)d_pow_l(L, (double)y); }
-// 10.**y (REAL y): exp(y ln 10), the same evaluation d_pow makes with its log already folded
-__device__ __forceinline__ float d_pow10f_k(const DK &K_, float y) { return y == 0.0f ? 1.0f : (float)d_exp((double)y * 2.30258509299404568402e+00); }
-__device__ __forceinline__ float d_expf_k(const DK &K_, float x) { return (float)d_exp((double)x); }
-__device__ __forceinline__ float d_log10f_k(const DK &K_, float x)
+// REAL(4) x**y, exp, log10: the C library's powf / expf / log10f bit for bit (glibc_flt32.h), which is what the compiled
+// reference calls.  powf is exp2(y * log2 x) with the log2 part a function of the base alone: powers of one base share it
+// (PowBase; the same bits as separate powf calls, any base -- an unusual one takes powf itself).
+__device__ __forceinline__ float d_powf_k(const DK &, float x, float y) { return gf_powf(x, y); }
+struct PowBase { double l2; float x; };
+__device__ __forceinline__ PowBase d_powf_base(float x)
 {
-    if (x > 0.0f) return (float)(d_log((double)x) * 4.34294481903251816668e-01);   // log(x) / ln 10
-    return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+    PowBase b; b.x = x;
+    b.l2 = gf_powf_log2(gf_asuint(x));                 // meaningful for a positive normal x only; d_powf_l checks
+    return b;
 }
+__device__ __forceinline__ float d_powf_l_k(const DK &, const PowBase &b, float y)
+{
+    const uint32_t ix = gf_asuint(b.x), iy = gf_asuint(y);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2 * iy - 1 >= 2u * 0x7f800000u - 1) return gf_powf(b.x, y);
+    return gf_powf_finish((double)y * b.l2, 0);
+}
+// 10.**y (REAL y)
+__device__ __forceinline__ float d_pow10f_k(const DK &, float y)
+{
+    if (2 * gf_asuint(y) - 1 >= 2u * 0x7f800000u - 1) return gf_powf(10.0f, y);
+    return gf_powf_finish((double)y * gf_powf_log2(0x41200000u), 0);
+}
+__device__ __forceinline__ float d_expf_k(const DK &, float x) { return gf_expf(x); }
+__device__ __forceinline__ float d_log10f_k(const DK &, float x) { return gf_log10f(x); }
 
 
 /* 10.**nn with an INTEGER exponent: flang calls __powisf2 (repeated squaring) */
@@ -286,8 +302,10 @@ __global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__
     if (rf) out[t] = which ? dec_index_f_slow(K_, rf[t], n2) : dec_index_f(T, rf[t], n2);
     else    out[t] = which ? dec_index_d_slow(K_, rd[t], n2) : dec_index_d(T, rd[t], n2);
 }
-// The FP64 functions of the level code on n arguments: op 0 d_log(x), 1 d_exp(x), 2 d_pow(x, y), 3 d_powf((float)x, (float)y)
-// widened.  (x, y) come from the host so that nothing is folded at compile time.
+// The transcendentals of the level code on n arguments.  DOUBLE PRECISION sites: op 0 d_log(x), 1 d_exp(x), 2 d_pow(x, y).
+// REAL(4) sites (the C library's float functions restated, glibc_flt32.h; arguments narrowed, results widened): 3 powf(x, y),
+// 4 expf(x), 5 logf(x), 6 log10f(x), 7 atanf(x), 8 powf through the shared-base form (d_powf_base + d_powf_l), 9 10.**x.
+// (x, y) come from the host so that nothing is folded at compile time.
 __global__ void k_thompson_math_probe(int op, int n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
 {
     const DK K_ = d_consts();
@@ -297,14 +315,20 @@ __global__ void k_thompson_math_probe(int op, int n, const double *__restrict__ 
     if (op == 0) r = d_log(x[t]);
     else if (op == 1) r = d_exp(x[t]);
     else if (op == 2) r = d_pow(x[t], y[t]);
-    else r = (double)d_powf((float)x[t], (float)y[t]);
+    else if (op == 3) r = (double)d_powf((float)x[t], (float)y[t]);
+    else if (op == 4) r = (double)d_expf((float)x[t]);
+    else if (op == 5) r = (double)gf_logf((float)x[t]);
+    else if (op == 6) r = (double)d_log10f((float)x[t]);
+    else if (op == 7) r = (double)gf_atanf((float)x[t]);
+    else if (op == 8) { const PowBase b = d_powf_base((float)x[t]); r = (double)d_powf_l(b, (float)y[t]); }
+    else r = (double)d_pow10f((float)x[t]);
     out[t] = r;
 }
 }  // namespace
 
 int icar_thompson_math_probe_run(icar_hip_ctx *c, int op, int n, const double *x, const double *y, double *out)
 {
-    if (op < 0 || op > 3 || (op >= 2 && !y)) { icar_set_error("math_probe: op must be 0..3 (y required for 2, 3)"); return 1; }
+    if (op < 0 || op > 9 || ((op == 2 || op == 3 || op == 8) && !y)) { icar_set_error("math_probe: op must be 0..9 (y required for 2, 3, 8)"); return 1; }
     if (n <= 0) return 0;
     double *dx = nullptr, *dy = nullptr, *dout = nullptr;
     HIPCHK(hipMalloc(&dx, sizeof(double) * n)); HIPCHK(hipMalloc(&dout, sizeof(double) * n));

@@ -4,24 +4,16 @@
 // surface flux) one thread per column, between them.  REAL(4) exp / log / x**y are the FP64 function rounded once (fp64_math.h), sqrt and divide IEEE:
 // the oracle's math mode 1 evaluates the same column routine with the same definition of the transcendentals.
 #include "ctx.h"
-#include "fp64_math.h"
+#include "glibc_flt32.h"
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
 
 namespace {
-__device__ __forceinline__ float w3_expf(float x) { return (float)d_exp((double)x); }
-__device__ __forceinline__ float w3_logf(float x)
-{
-    if (x > 0.0f) return (float)d_log((double)x);
-    return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
-}
-__device__ __forceinline__ float w3_powf(float x, float y)
-{
-    if (y == 0.0f) return 1.0f;
-    if (x > 0.0f) return (float)d_exp((double)y * d_log((double)x));
-    return x == 0.0f ? (y > 0.0f ? 0.0f : __builtin_inff()) : __builtin_nanf("");
-}
+// REAL(4) exp / log / x**y as the compiled reference evaluates them: the C library's expf / logf / powf (glibc_flt32.h)
+__device__ __forceinline__ float w3_expf(float x) { return gf_expf(x); }
+__device__ __forceinline__ float w3_logf(float x) { return gf_logf(x); }
+__device__ __forceinline__ float w3_powf(float x, float y) { return gf_powf(x, y); }
 }  // namespace
 
 #define W3_FN __host__ __device__ static inline

@@ -14,7 +14,7 @@
 // oracle's math mode 1 evaluates oracle/wsm6_oracle.c (a separate restatement, pinned to the compiled reference) with the
 // same definition of the transcendentals, and tests/test_gpu_wsm6.py compares bit for bit.
 #include "ctx.h"
-#include "fp64_math.h"
+#include "glibc_flt32.h"
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -63,18 +63,10 @@ struct W6Args { float delt, g, cpd, cpv, rd, rv, t0c, ep1, ep2, qmin, xls, xlv0,
 // saturation coefficients of the inlined fpvs (:451-461)
 struct W6Sat { float ttp, xa, xb, xai, xbi; };
 
-__device__ __forceinline__ float e6(float x) { return (float)d_exp((double)x); }
-__device__ __forceinline__ float l6(float x)
-{
-    if (x > 0.0f) return (float)d_log((double)x);
-    return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
-}
-__device__ __forceinline__ float p6(float x, float y)
-{
-    if (y == 0.0f) return 1.0f;
-    if (x > 0.0f) return (float)d_exp((double)y * d_log((double)x));
-    return x == 0.0f ? (y > 0.0f ? 0.0f : __builtin_inff()) : __builtin_nanf("");
-}
+// REAL(4) exp / log / x**y as the compiled reference evaluates them: the C library's expf / logf / powf (glibc_flt32.h)
+__device__ __forceinline__ float e6(float x) { return gf_expf(x); }
+__device__ __forceinline__ float l6(float x) { return gf_logf(x); }
+__device__ __forceinline__ float p6(float x, float y) { return gf_powf(x, y); }
 __device__ __forceinline__ float mx(float a, float b) { return a > b ? a : b; }        // Fortran max / min of two reals
 __device__ __forceinline__ float mn(float a, float b) { return a < b ? a : b; }
 

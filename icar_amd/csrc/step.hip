@@ -2,21 +2,16 @@
 // rows T3 (diagnostic_update, src/main/time_step.f90:49-198) and F1 (apply_forcing / enforce_limits,
 // src/objects/domain_obj.f90:2383-2448, 2228-2243).  All HBM-bound, lanes along i.
 #include "ctx.h"
-#include "fp64_math.h"
+#include "glibc_flt32.h"
 #include <cmath>
 
 namespace {
 constexpr float Rd = 287.058f, cp = 1012.0f;     // src/constants/icar_constants.f90:391-393
 
-// (p/po)**(Rd/cp) evaluated in FP64 and rounded once ("Arithmetic")
+// (p/po)**(Rd/cp): the C library's powf, bit for bit what the compiled reference computes (glibc_flt32.h)
 __device__ __forceinline__ float exner_function(float pressure)
 {   // atm_utilities.f90:682-691 ; po = 100000 (integer in the reference => p/100000.)
-    // (p/1e5)**(Rd/cp), p > 0: exp(y log x) in FP64 (|y log x| < 1 => relative error 2^-52), a third of ocml's pow().
-    // d_log assumes a positive finite argument; a pressure <= 0 or NaN (an uninitialised halo cell) takes the library
-    // pow, which returns what the reference's would (0, Inf or NaN -- detectable, not a plausible wrong number).
-    const float x = pressure / 100000.0f;
-    if (!(x > 0.0f) || !(x < 3.0e38f)) return powf(x, Rd / cp);
-    return (float)d_exp((double)(Rd / cp) * d_log((double)x));
+    return gf_powf(pressure / 100000.0f, Rd / cp);
 }
 
 #define DIAG_BY 8

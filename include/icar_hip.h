@@ -177,9 +177,12 @@ int icar_hip_thompson_table(icar_hip_ctx *ctx, const char *name, double *out, si
  * only near a power of ten), which = 1: the reference's loop alone.  A cross-check for tests: the two must agree everywhere. */
 int icar_hip_thompson_dec_index(icar_hip_ctx *ctx, const float *r4, const double *r8, int n, int n2, int which, int *out);
 
-/* The device's evaluation of the scheme's transcendentals (mp_thompson.f90's exp / log / x**y on REAL arguments are computed
- * in FP64 and rounded once), for tests: out[i] = op 0: log(x[i]), 1: exp(x[i]), 2: x[i]**y[i] in FP64,
- * 3: REAL(x[i])**REAL(y[i]) rounded to REAL(4) (widened).  Host arrays of n doubles; y may be NULL for op 0, 1. */
+/* The device's evaluation of the scheme's transcendentals, for tests.  REAL(4) exp / log / log10 / x**y / atan are the C
+ * library's expf / logf / log10f / powf / atanf restated bit for bit (icar_amd/csrc/glibc_flt32.h: what the compiled reference
+ * calls); DOUBLE PRECISION log / exp / x**y are evaluated in FP64.  out[i] = op 0: log(x[i]), 1: exp(x[i]), 2: x[i]**y[i] in FP64;
+ * on REAL(x[i]), REAL(y[i]) with the REAL(4) result widened: 3: powf, 4: expf, 5: logf, 6: log10f, 7: atanf, 8: powf through the
+ * shared-base form the level code uses for several powers of one base, 9: 10.**x.  Host arrays of n doubles; y may be NULL
+ * unless op is 2, 3 or 8. */
 int icar_hip_thompson_math_probe(icar_hip_ctx *ctx, int op, int n, const double *x, const double *y, double *out);
 
 /* ---- M0: tile bookkeeping of mp()/process_halo (src/physics/mp_driver.f90:609-772) -----------

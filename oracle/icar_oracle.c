@@ -342,14 +342,22 @@ void orc_advect(int scheme, int nx, int nz, int ny, int nvars, float *q,
 
 typedef struct { float cloud2rain, cloud2snow; int err; } mps_consts;
 
-/* Transcendental mode.  0 (default): libm expf exactly as the flang-compiled reference calls it
- * => the oracle is bit-identical to oracle/_ref.  1: exp evaluated in FP64 and rounded once
- * (correctly rounded in all but ~1e-8 of cases) -- the same definition the HIP kernels use, so
- * HIP-vs-oracle(mode 1) is a bit-exact check of the device code, while oracle(0)-vs-oracle(1)
- * measures the scheme's own sensitivity to a 1-ulp change in exp (threshold flips in the
- * saturation adjustment, mp_simple.f90:217). */
+/* Transcendental mode.  0 (default): libm expf / logf / powf / log10f / atanf exactly as the flang-compiled reference
+ * calls them => the oracle is bit-identical to oracle/_ref, and it is what every HIP-vs-oracle test runs in: the device
+ * evaluates the same functions bit for bit (icar_amd/csrc/glibc_flt32.h).  1: the float function evaluated in FP64 and
+ * rounded once (correctly rounded in all but ~1e-8 of cases); oracle(0)-vs-oracle(1) measures the schemes' own sensitivity
+ * to a 1-ulp change of a transcendental (threshold flips, tests/test_oracle_modes.py) -- until round 3 it was also the device's
+ * definition. */
 int g_math_mode = 0;
 void orc_set_math_mode(int m) { g_math_mode = m; }
+/* the host C library's float functions on arrays (mode 0's transcendentals), for the device-vs-libm check of
+ * icar_amd/csrc/glibc_flt32.h: op 3 powf(x, y), 4 expf, 5 logf, 6 log10f, 7 atanf, 8 powf again, 9 powf(10, x) */
+void orc_libm_f(int op, int n, const float *x, const float *y, float *out)
+{
+    for (int i = 0; i < n; ++i)
+        out[i] = (op == 3 || op == 8) ? powf(x[i], y[i]) : op == 4 ? expf(x[i]) : op == 5 ? logf(x[i]) : op == 6 ? log10f(x[i])
+               : op == 7 ? atanf(x[i]) : powf(10.0f, x[i]);
+}
 static inline float orc_expf(float x) { return g_math_mode ? (float)exp((double)x) : expf(x); }
 
 static float sat_mr(float temperature, float pressure)

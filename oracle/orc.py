@@ -68,8 +68,17 @@ def mp_simple(pressure, th, pii, rho, qv, qc, qr, qs, rain, snow, dt, dz, its, i
 
 
 def set_math_mode(mode):
-    """0: libm expf (bit-identical to the compiled reference); 1: FP64 exp rounded once (what the HIP kernels do)."""
+    """0: libm float functions (bit-identical to the compiled reference, and what the HIP kernels evaluate: glibc_flt32.h);
+    1: the FP64 function rounded once (a sensitivity probe, tests/test_oracle_modes.py)."""
     lib().orc_set_math_mode(_i(mode))
+
+
+def libm_f(op, x, y=None):
+    """the host C library's float functions on arrays: op 3 / 8 powf(x, y), 4 expf, 5 logf, 6 log10f, 7 atanf, 9 powf(10, x)"""
+    x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
+    yy = None if y is None else np.ascontiguousarray(y, np.float32)
+    lib().orc_libm_f(_i(op), _i(x.size), _p(x), _p(yy), _p(out))
+    return out
 
 
 def num_threads():

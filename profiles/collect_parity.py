@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """gpurun_out/parity/*.jsonl (written by the -m gpu parity tests on the MI355X box, tests/util.py:parity_record) ->
-profiles/r02_parity.json: per test label and field the MEASURED deviation from the CPU oracle
+profiles/r03_parity.json: per test label and field the MEASURED deviation from the CPU oracle
 (bit-different fraction / cells, fraction beyond rtol 1e-5, max |d| / max|field|, max |d| / local scale), plus the worst
 value per label.  The bounds asserted in tests/ are <= 2.5x these.  usage: python profiles/collect_parity.py"""
 import glob, json, os
@@ -21,7 +21,7 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "parity", "*.jsonl"))
                     w[k] = max(w.get(k, 0), v)
         summary[lab] = w
     out[name] = {"worst_per_label": summary, "per_field": recs}
-json.dump(out, open(os.path.join(root, "profiles", "r02_parity.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(root, "profiles", "r03_parity.json"), "w"), indent=1, sort_keys=True)
 for name, v in out.items():
     for lab, w in v["worst_per_label"].items():
         print(f"{name:10s} {lab:70s} " + "  ".join(f"{k}={x:.3g}" for k, x in sorted(w.items())))

@@ -34,7 +34,7 @@ def test_fortran_host_matches_oracle(oracle, tmp_path, scheme):
     s = {k: c[k].copy() for k in ["pressure", "potential_temperature", "exner", "density", "water_vapor", "cloud_water", "rain", "snow", "dz_mass"]}
     acc = np.zeros((ny, nx), np.float64)
     order = ["water_vapor", "cloud_water", "rain", "snow", "potential_temperature"]
-    oracle.set_math_mode(1)
+    oracle.set_math_mode(0)
     try:
         for _ in range(nsteps):
             rain = np.zeros((ny, nx), np.float32); snow = rain.copy()

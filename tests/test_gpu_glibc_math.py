@@ -1,0 +1,58 @@
+"""The device's REAL(4) exp / log / log10 / x**y / atan (icar_amd/csrc/glibc_flt32.h: the C library's expf / logf / log10f /
+powf / atanf restated) against the HOST's libm, bit for bit, on millions of arguments per function -- including the shared-base
+form of powf the Thompson level code uses and its 10.**x.  The same header is checked on the CPU against every one of the 2^32
+REAL(4) arguments in tests/test_glibc_flt32_host.py; this is the run on the device (v_fma_f64, v_cvt, denormal handling)."""
+import ctypes
+import numpy as np
+import pytest
+from icar_amd import ideal
+from icar_amd.capi import lib, check
+from util import single_image_domain, parity_record
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_float_transcendentals_equal_the_hosts_libm(oracle):
+    d = single_image_domain(ideal.make_case(12, 6, 12))
+    rng = np.random.default_rng(2024)
+
+    def probe(op, x, y=None):
+        x = np.ascontiguousarray(x, np.float64); out = np.zeros(x.size, np.float64)
+        yp = None if y is None else np.ascontiguousarray(y, np.float64).ctypes.data_as(ctypes.c_void_p)
+        check(lib().icar_hip_thompson_math_probe(d.ctx, op, x.size, x.ctypes.data_as(ctypes.c_void_p), yp,
+                                                 out.ctypes.data_as(ctypes.c_void_p)), "math_probe")
+        return out.astype(np.float32)
+
+    def same(a, b):
+        return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+    n = 3_000_000
+    anybits = lambda m: rng.integers(0, 2 ** 32, m, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-40, 1.1754944e-38, 3.4028235e38, -3.4028235e38,
+                        88.0, 88.7, 88.73, -87.3, -87.4, -103.0, -103.5, -104.0, -110.0, 0.4375, 0.6875, 1.1875, 2.4375, 3e7, 4e7], np.float32)
+    stats = {}
+    try:
+        one_arg = {4: ("expf", np.concatenate([rng.uniform(-104.0, 89.0, n).astype(np.float32), anybits(n // 3), special])),
+                   5: ("logf", np.concatenate([np.abs(anybits(n)), (1.0 + rng.uniform(-1e-3, 1e-3, n // 3)).astype(np.float32), anybits(n // 10), special])),
+                   6: ("log10f", np.concatenate([np.abs(anybits(n)), (10.0 ** rng.uniform(-8, 8, n // 3)).astype(np.float32), special])),
+                   7: ("atanf", np.concatenate([anybits(n), rng.uniform(-4.0, 4.0, n).astype(np.float32), special])),
+                   9: ("10**x", np.concatenate([rng.uniform(-46.0, 39.0, n).astype(np.float32), special]))}
+        for op, (name, x) in one_arg.items():
+            got, want = probe(op, x), oracle.libm_f(op, x)
+            bad = ~same(got, want)
+            stats[name] = {"n": int(x.size), "differ": int(bad.sum())}
+            assert not bad.any(), f"{name}: {bad.sum()} of {x.size} differ from libm, first x = {x[bad][0]!r}: {got[bad][0]!r} vs {want[bad][0]!r}"
+        # powf: the scheme's use (positive base from any binade, moderate exponent), arbitrary bit patterns, special pairs
+        xb = np.concatenate([np.abs(anybits(n)), (10.0 ** rng.uniform(-12.0, 12.0, n)).astype(np.float32), anybits(n // 2)])
+        yb = np.concatenate([rng.uniform(-12.0, 12.0, n).astype(np.float32), rng.uniform(-6.0, 6.0, n).astype(np.float32), anybits(n // 2)])
+        sx, sy = np.meshgrid(special, special)
+        xb = np.concatenate([xb, sx.ravel()]); yb = np.concatenate([yb, sy.ravel()])
+        want = oracle.libm_f(3, xb, yb)
+        for op, name in ((3, "powf"), (8, "powf_shared_base")):
+            got = probe(op, xb, yb)
+            bad = ~same(got, want)
+            stats[name] = {"n": int(xb.size), "differ": int(bad.sum())}
+            assert not bad.any(), f"{name}: {bad.sum()} of {xb.size} differ from libm, first ({xb[bad][0]!r}, {yb[bad][0]!r}): {got[bad][0]!r} vs {want[bad][0]!r}"
+        parity_record("glibc_math", "device REAL(4) transcendentals vs the host libm (bit patterns)", stats)
+    finally:
+        d.close()

@@ -63,8 +63,8 @@ def run(oracle, k, mode, split=False):
 
 
 @pytest.mark.parametrize("case", list(CASES))
-def test_wsm3_bit_exact_vs_oracle_device_math(oracle, case):
-    got, want, pa, sa, acc_r, acc_s = run(oracle, CASES[case], mode=1, split={"warm_rain": True, "snow_at_surface": "two_streams"}.get(case, False))
+def test_wsm3_bit_exact_vs_reference_math(oracle, case):
+    got, want, pa, sa, acc_r, acc_s = run(oracle, CASES[case], mode=0, split={"warm_rain": True, "snow_at_surface": "two_streams"}.get(case, False))
     for n in want:
         assert np.array_equal(got[n].view(np.int32), want[n].view(np.int32)), f"{n}: {(got[n] != want[n]).sum()} cells differ"
     assert np.array_equal(pa, acc_r) and np.array_equal(sa, acc_s) and acc_r.max() > (0.5 if "serial" not in case else 0.0)
@@ -72,12 +72,3 @@ def test_wsm3_bit_exact_vs_oracle_device_math(oracle, case):
         assert acc_s.max() > (0.1 if case == "snow_at_surface" else 0.0)
 
 
-@pytest.mark.parametrize("case", list(CASES))
-def test_wsm3_within_tolerance_of_reference_math(oracle, case):
-    got, want, pa, sa, acc_r, acc_s = run(oracle, CASES[case], mode=0)
-    for n in want:
-        a, b = got[n].astype(np.float64), want[n].astype(np.float64)
-        scale = max(np.abs(b).max(), 1e-30)
-        bad = np.abs(a - b) > 1e-5 * np.maximum(np.abs(b), 1e-3 * scale)
-        assert bad.mean() <= 1e-2, f"{n}: {bad.mean():.2e} of cells beyond rtol 1e-5"
-    assert abs(pa.sum() - acc_r.sum()) <= 1e-4 * acc_r.sum() and abs(sa.sum() - acc_s.sum()) <= 1e-4 * max(acc_s.sum(), 1e-9) + 1e-9

@@ -41,8 +41,13 @@ def local_rel_err(got, ref, radius=2):
 MPDATA_RTOL = 1e-5      # BASELINE.json north_star: "output fields within 1e-5 relative of CPU reference"
 
 
-def assert_fields_close(got, ref, name="", rtol=MPDATA_RTOL):
+def assert_fields_close(got, ref, name="", rtol=MPDATA_RTOL, record=None):
+    """every cell within rtol of the local field scale; record = (test, label): also write the measured local-scale error and
+    the POINTWISE statistics (field_stats) to the parity record"""
     err, where = local_rel_err(got, ref)
+    if record is not None:
+        st = field_stats(got, ref, rtol); st["max_over_local_scale"] = err
+        parity_record(record[0], record[1], {name: st})
     assert err <= rtol, f"{name}: |got-ref| = {err:.3e} x the local field scale at {where} (allowed {rtol:g})"
     return err
 
@@ -62,7 +67,7 @@ def adv_args(c):
 
 def parity_record(test, label, stats):
     """Append the MEASURED deviation of a parity test to gpurun_out/parity/<test>.jsonl (merged back from the GPU box;
-    profiles/collect_parity.py turns the files into the tracked profiles/r02_parity.json).  Never raises."""
+    profiles/collect_parity.py turns the files into the tracked profiles/r03_parity.json).  Never raises."""
     import json, os
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,5 +83,8 @@ def field_stats(got, ref, rtol=1e-5):
     a = np.asarray(got, np.float64); b = np.asarray(ref, np.float64)
     scale = max(float(np.abs(b).max()), 1e-300)
     bad = np.abs(a - b) > rtol * np.maximum(np.abs(b), 1e-3 * scale)
+    big = np.abs(b) > 1e-3 * scale                      # pointwise relative error where the field is not small
+    pw = float((np.abs(a - b)[big] / np.abs(b)[big]).max()) if big.any() else 0.0
     return {"bitdiff_frac": float((np.asarray(got) != np.asarray(ref).astype(np.asarray(got).dtype)).mean()),
-            "beyond_rtol_frac": float(bad.mean()), "max_abs_over_max": float(np.abs(a - b).max() / scale), "cells": int(a.size)}
+            "beyond_rtol_frac": float(bad.mean()), "max_abs_over_max": float(np.abs(a - b).max() / scale),
+            "max_pointwise_rel": pw, "cells": int(a.size)}
