@@ -15,6 +15,7 @@
 #include "ctx.h"
 #include "thompson_state.h"
 #include "fp64_math.h"
+#define GF_LDS_TABLES          // the look-up tables of expf / logf / powf in LDS: every kernel below starts with gf_lds_init()
 #include "glibc_flt32.h"
 #include "column_comm.h"
 #include <cmath>
@@ -59,24 +60,10 @@ __device__ __forceinline__ double d_pow_l_k(const DK &K_, double L, double y) { 
 // (PowBase; the same bits as separate powf calls, any base -- an unusual one takes powf itself).
 __device__ __forceinline__ float d_powf_k(const DK &, float x, float y) { return gf_powf(x, y); }
 struct PowBase { double l2; float x; };
-__device__ __forceinline__ PowBase d_powf_base(float x)
-{
-    PowBase b; b.x = x;
-    b.l2 = gf_powf_log2(gf_asuint(x));                 // meaningful for a positive normal x only; d_powf_l checks
-    return b;
-}
-__device__ __forceinline__ float d_powf_l_k(const DK &, const PowBase &b, float y)
-{
-    const uint32_t ix = gf_asuint(b.x), iy = gf_asuint(y);
-    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2 * iy - 1 >= 2u * 0x7f800000u - 1) return gf_powf(b.x, y);
-    return gf_powf_finish((double)y * b.l2, 0);
-}
-// 10.**y (REAL y)
-__device__ __forceinline__ float d_pow10f_k(const DK &, float y)
-{
-    if (2 * gf_asuint(y) - 1 >= 2u * 0x7f800000u - 1) return gf_powf(10.0f, y);
-    return gf_powf_finish((double)y * gf_powf_log2(0x41200000u), 0);
-}
+__device__ __forceinline__ PowBase d_powf_base(float x) { PowBase b; b.x = x; b.l2 = gf_powf_log2(gf_asuint(x)); return b; }
+__device__ __forceinline__ float d_powf_l_k(const DK &, const PowBase &b, float y) { return gf_powf_from_log2(b.x, b.l2, y); }
+// 10.**y (REAL y): powf(10, y) with its log2 part, gf_powf_log2(bits of 10.0f), folded (tests/test_gpu_glibc_math.py op 9)
+__device__ __forceinline__ float d_pow10f_k(const DK &, float y) { return gf_powf_from_log2(10.0f, 0x1.a934f0979b22dp+1, y); }
 __device__ __forceinline__ float d_expf_k(const DK &, float x) { return gf_expf(x); }
 __device__ __forceinline__ float d_log10f_k(const DK &, float x) { return gf_log10f(x); }
 
@@ -197,6 +184,7 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
                 double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
                 float dt, int i0, int i1, int j0, int k0, int nk)
 {
+    gf_lds_init(threadIdx.x, blockDim.x);
     const int lane = threadIdx.x & 63;
     const int i = i0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int j = j0 + blockIdx.y;
@@ -240,6 +228,7 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
                 float dt, ThTiles tl, int k0, int nk, int cpb)
 {
     extern __shared__ double lds_pack[];
+    gf_lds_init(threadIdx.x, blockDim.x);
     // several (its..ite, jts..jte) tiles in one launch (process_halo's four strips): block -> tile by prefix offsets
     // XCD-aware order: workgroups go to the 8 XCDs round-robin; neighbouring column groups share 64-B lines (a group is
     // 24 B wide at nz = 40), so each XCD takes runs of XCD_RUN consecutive groups and the shared lines hit in its L2.
@@ -282,6 +271,7 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 // arguments come from the host so that nothing is folded at compile time: the value must be what a level computes at run time
 __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
 {
+    gf_lds_init(threadIdx.x, blockDim.x);
     const DK K_ = d_consts();
 
     T->N0_exp_default = th_graupel_N0_exp(rg, xslw1);
@@ -295,6 +285,7 @@ __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
 // reference's loop alone -- so that a test can compare them value by value (icar_hip_thompson_dec_index)
 __global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__ rf, const double *__restrict__ rd, int n, int n2, int which, int *__restrict__ out)
 {
+    gf_lds_init(threadIdx.x, blockDim.x);
     const DK K_ = d_consts();
 
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,6 +299,7 @@ __global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__
 // (x, y) come from the host so that nothing is folded at compile time.
 __global__ void k_thompson_math_probe(int op, int n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
 {
+    gf_lds_init(threadIdx.x, blockDim.x);
     const DK K_ = d_consts();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;

@@ -1,7 +1,8 @@
-"""`python bench.py --gpus N` must really run N ranks (round-1 finding: the flag was parsed and ignored).  The GPU box
-has ONE GPU, so the N ranks share it over gloo (ICAR_BENCH_BACKEND=gloo: halo buffers staged through host memory) -- a
-functional check of the spawn + decomposition + halo path of the bench, never a performance number; with RCCL the same
-command line needs N GPUs and says so."""
+"""`python bench.py --gpus N` must really run N ranks (round-1 finding: the flag was parsed and ignored) on the FIXED global
+grid (strong scaling, north_star; round-2 finding: the bench only scaled weakly).  The GPU box has ONE GPU, so the N ranks share
+it (ICAR_BENCH_BACKEND=gloo: the library's host-staged halo transport, icar_hip_comm_init_host) -- a functional check of the
+spawn + decomposition + halo path of the bench, never a performance number; with RCCL the same command line needs N GPUs and
+says so."""
 import json
 import os
 import subprocess
@@ -26,13 +27,31 @@ def _line(r):
     return json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("n,decomp", [(2, "2x1"), (4, "2x2")])
-def test_bench_gpus_n_spawns_n_ranks(n, decomp):
+@pytest.mark.parametrize("n,decomp", [(2, "2x1"), (4, "2x2"), (8, "2x4")])
+def test_bench_gpus_n_spawns_n_ranks_on_the_fixed_global_grid(n, decomp):
     r = _run(["--gpus", str(n)] + SMALL, {"ICAR_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
     out = _line(r)
     assert out["n_gpus"] == n and out["config"]["decomposition"] == decomp and out["config"]["backend"] == "gloo"
-    assert out["value"] > 0 and out["steps"] == 2
+    assert out["scaling"] == "strong" and out["config"]["global_grid"] == [64, 48, 12]
+    # value = cells all ranks own (the interior of the GLOBAL grid, whatever N) x steps / time
+    cells = out["value"] * out["ms_per_step"] * 1e-3
+    assert abs(cells - 62 * 46 * 12) < 1e-6 * 62 * 46 * 12 and out["steps"] == 2
+
+
+def test_bench_weak_scaling_keeps_the_tile():
+    out = _line(_run(["--gpus", "2", "--scaling", "weak"] + SMALL, {"ICAR_BENCH_BACKEND": "gloo"}))
+    assert out["scaling"] == "weak" and out["config"]["global_grid"] == [128, 48, 12] and out["config"]["decomposition"] == "2x1"
+
+
+def test_bench_north_star_grid_on_eight_images():
+    """the literal 512 x 512 x 40 of north_star split 2 x 4 (what the driver's 8-GPU run launches), 8 images sharing the GPU"""
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {"ICAR_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _line(r)
+    assert out["n_gpus"] == 8 and out["config"]["decomposition"] == "2x4" and out["config"]["global_grid"] == [512, 512, 40]
+    assert out["config"]["tile_memory"][0] in (257, 258) and out["config"]["tile_memory"][2] in (129, 130)
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 510 * 510 * 40) < 1.0
 
 
 def test_bench_single_rank_times_the_same_path():

@@ -271,7 +271,7 @@ def test_tiled_iterative_winds_equals_tiled_oracle():
     _run(_worker_iw, 4, "upwind")
 
 
-@pytest.mark.parametrize("world,adv", [(2, "upwind"), (4, "upwind"), (4, "mpdata"), (2, "upwind+thompson"), (4, "upwind+thompson"), (4, "upwind+wsm6")])
+@pytest.mark.parametrize("world,adv", [(2, "upwind"), (4, "upwind"), (8, "upwind"), (4, "mpdata"), (2, "upwind+thompson"), (4, "upwind+thompson"), (8, "upwind+thompson"), (4, "upwind+wsm6")])
 def test_tiled_step_equals_single_tile_on_device(world, adv):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

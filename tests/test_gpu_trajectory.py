@@ -117,3 +117,72 @@ def test_config1_256x256x40_mpdata_thompson_substep(th_oracle):
     for n in ADV_ORDER:
         assert_fields_close(d.get(MEMBER[n]), s[n], n, record=("trajectory", "config1/256x256x40/mpdata_after_thompson"))
     d.close()
+
+
+def test_config3_tile_update_winds_then_substep(th_oracle, oracle):
+    """The per-GPU workload of BASELINE configs[3] (1024 x 1024 x 40 on 2 x 4 images: a 512 x 256 x 40 tile): update_winds with
+    windtype kWIND_LINEAR -- spatial_winds interpolating a look-up table (uploaded, 2 x 4 x 3 entries: the build is the init-time
+    row W3, tests/test_gpu_winds.py) + balance_uvw -- then [Thompson -> MPDATA] with the new winds.  Winds and the microphysics
+    bit for bit against the oracle chain (the C library's float functions on both sides), MPDATA on every cell to 1e-5."""
+    from oracle import wind_oracle as W
+    from icar_amd import linear_winds as LW
+    from icar_amd.options import lt_options_type
+    from icar_amd.wind import update_winds, kWIND_LINEAR
+    from icar_amd.domain import domain_t
+    from icar_amd.grid import grid_t
+    from util import bits_equal
+    nx, ny, nz = 512, 256, 40
+    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.5)).astype(np.float32)
+    dxf = float(c["dx"])
+    rng = np.random.default_rng(77)
+    ndir, nspd, nnsq = 4, 3, 2
+    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON
+    opt.physics.windtype = kWIND_LINEAR
+    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = dxf
+    opt.lt_options = lt_options_type(buffer=4, n_dir_values=ndir, n_spd_values=nspd, n_nsq_values=nnsq, stability_window_size=3,
+                                     vert_smooth=2, variable_N=True, smooth_nsq=True, linear_contribution=0.5, linear_update_fraction=1.0)
+    lt = opt.lt_options
+    mp_var_request(opt)
+    d = domain_t(grid_t().set_grid_dimensions(nx, ny, nz, 1, 1), device=0, dx=dxf)
+    d.load_case(c)
+    zc = (np.cumsum(c["dz_levels"]) - c["dz_levels"] / 2).astype(np.float32)
+    z3 = np.ascontiguousarray(c["terrain"][:, None, :] + zc[None, :, None] * np.ones((ny, 1, nx), np.float32), np.float32)
+    d.set("z", z3)
+    mp_init(opt, d); adv_init(d, opt)
+    LW.setup_linwinds(d, opt, c["terrain"], build=False)
+    ulut = (0.5 * rng.standard_normal((ny, nz, nx + 1, nnsq, ndir, nspd))).astype(np.float32)
+    vlut = (0.5 * rng.standard_normal((ny + 1, nz, nx, nnsq, ndir, nspd))).astype(np.float32)
+    LW.lut_upload(d, opt, 0, ulut); LW.lut_upload(d, opt, 1, vlut)
+    lo, hi = lt.resolved()
+    dirv = W.linear_space(lt.dirmin, lt.dirmax, ndir); spdv = W.linear_space(lt.spdmin, lt.spdmax, nspd); nsqv = W.linear_space(lo, hi, nnsq)
+    o = dict(variable_N=True, smooth_nsq=True, N_squared=lt.N_squared, max_stability=lt.max_stability, min_stability=lt.min_stability,
+             linear_contribution=lt.linear_contribution, linear_update_fraction=lt.linear_update_fraction)
+    hyd = tuple(c[k] for k in ("cloud_water", "cloud_ice", "rain", "snow"))
+    oracle.set_math_mode(0)
+    u, v = c["u"].copy(), c["v"].copy()
+    up = np.zeros_like(u); vp = np.zeros_like(v)
+    oracle.make_winds_grid_relative(u, v, np.zeros((ny, nx)), np.ones((ny, nx)))
+    oracle.spatial_winds(u, v, c["potential_temperature"], c["exner"], z3, c["water_vapor"], hyd, ulut, vlut, up, vp, o, dirv, spdv, nsqv,
+                         lt.vert_smooth, lt.stability_window_size)
+    w = oracle.balance_uvw(u, v, c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], dxf)
+    del ulut, vlut
+    d.set("sintheta", np.zeros((ny, nx))); d.set("costheta", np.ones((ny, nx)))
+    update_winds(d, opt)
+    for n, want in (("u", u), ("v", v), ("w", w)):
+        g = d.get(n)
+        assert bits_equal(g, want), f"update_winds {n}: {(g != want).sum()} of {g.size} differ, max {abs(g - want).max()}"
+    assert abs(u - c["u"]).max() > 0.05
+    cw = dict(c); cw["u"], cw["v"], cw["w"] = u, v, w
+    dt = float(np.float32(min(ideal.cfl_dt(cw), 60.0)))
+    s = {n: c[n].copy() for n in ADV_ORDER}
+    mp(d, opt, dt); d.model_time_seconds += dt
+    _thompson_oracle_step(th_oracle, s, c, dt, nx, ny, nz)
+    for n in ADV_ORDER:
+        got = d.get(MEMBER[n])
+        assert np.array_equal(got, s[n]), f"Thompson {n}: {(got != s[n]).sum()} cells differ"
+    advect(d, opt, dt)
+    _advect_oracle(th_oracle, s, cw, dt, ADV_ORDER)
+    for n in ADV_ORDER:
+        assert_fields_close(d.get(MEMBER[n]), s[n], n, record=("trajectory", "config3_tile/512x256x40/mpdata_with_linear_winds"))
+    d.close()
