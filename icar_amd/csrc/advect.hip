@@ -131,8 +131,8 @@ k_upwind_pass(Dims d, CVarPtrs in, VarPtrs out, int nv,
 // ------------------------------------------------------------------------------------------------
 static dim3 grid3(const Dims &d) { return dim3((d.nx + BX - 1) / BX, (d.nz + BY - 1) / BY, d.ny); }
 
-int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
-                          const float *rho, const float *jaco, const float *dz);          // mpdata.hip
+int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv);   // mpdata.hip
+int icar_mpdata_coef_run(icar_hip_ctx *c, bool rho_on);                                                                       // mpdata.hip
 
 static int ensure_adv_scratch(icar_hip_ctx *c)
 {
@@ -160,6 +160,8 @@ int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int
     else             { if (advect_density) LAUNCH(2, true); else LAUNCH(2, false); }
 #undef LAUNCH
     HIPCHK(hipGetLastError());
+    // MPDATA: everything of the corrective iteration that does not depend on the scalar, once per step (mpdata.hip)
+    if (scheme == ICAR_ADV_MPDATA && icar_mpdata_coef_run(c, advect_density != 0)) return 1;
     c->winds_valid = true;
     c->step.winds_scheme = scheme; c->step.winds_dt = dt; c->step.winds_dens = advect_density ? 1 : 0;   // what advect() of the step driver asks for
     return 0;
@@ -209,7 +211,7 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     // iteration starts from q2 = q (:393-402) with the ORIGINAL U_m, V_m, W_m/dz (:379) and is the same launch without
     // the first donor-cell pass.
     for (int iord = 2; iord <= order; ++iord) {
-        if (icar_mpdata_fused_run(c, advect_density != 0, fct != 0, iord == 2, q, alt, n, rho, jaco, dz)) return 1;
+        if (icar_mpdata_fused_run(c, advect_density != 0, fct != 0, iord == 2, q, alt, n)) return 1;
         swap_fields();
     }
     return 0;

@@ -419,7 +419,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->field[f]) hipFree(c->field[f]);
     for (int f = 0; f < ICAR_N_ADVECTABLE; ++f) if (c->alt[f]) hipFree(c->alt[f]);
     for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->dqdt[f]) hipFree(c->dqdt[f]);
-    float *scr[] = {c->U, c->V, c->W, c->Wdz, c->d_red};
+    float *scr[] = {c->U, c->V, c->W, c->Wdz, c->d_red, c->mpc};
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
     if (c->h_cfl_pre) hipHostFree(c->h_cfl_pre);

@@ -54,6 +54,8 @@ struct icar_hip_ctx {
     float *dqdt[ICAR_N_FIELDS] = {nullptr};    // variable_t%dqdt_3d mirrors (apply_forcing)
     // advection scratch (A1-A5)
     float *U = nullptr, *V = nullptr, *W = nullptr, *Wdz = nullptr;
+    float *mpc = nullptr;                // MPDATA: the eleven scalar-independent coefficient arrays of this step's winds (mpdata.hip)
+    int mpc_dens = -1;
     float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
     bool winds_valid = false;
     // u / v / w bookkeeping for the prefetched CFL reduction (icar_hip_max_courant_prefetch): every entry point that writes a wind

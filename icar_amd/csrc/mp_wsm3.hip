@@ -29,7 +29,6 @@ __device__ __forceinline__ float w3_powf(float x, float y) { return gf_powf(x, y
 #define W3_SQRT(x) sqrtf(x)
 #endif
 #define W3_MAXK 64
-#define W3_HOST_INIT
 #include "wsm3_column.h"
 
 // work arrays of one call, all (nx, nz, ny) REAL(4): the level pieces run one thread per CELL (10 M threads at 512x512x40: the

@@ -9,10 +9,10 @@
 //     k_w6_icefall one thread per COLUMN nislfv_rain_plm (cloud ice, iter = 0) :659-667 and the surface sums :672-697
 //     k_w6_rates  one thread per CELL    instant melt / freeze :703-759, slopes, the warm and cold process rates :782-1128,
 //                                        conservation and update :1136-1318, saturation adjustment :1330-1385
-// with REAL(4) work fields in between (288 GB of HBM: 21 fields of the tile).  Every statement keeps the reference's
-// operation order.  REAL(4) exp / log / x**y are the FP64 function rounded once (fp64_math.h), sqrt and divide IEEE: the
-// oracle's math mode 1 evaluates oracle/wsm6_oracle.c (a separate restatement, pinned to the compiled reference) with the
-// same definition of the transcendentals, and tests/test_gpu_wsm6.py compares bit for bit.
+// with REAL(4) work fields in between (21 fields of the tile: 0.9 GB at 512 x 512 x 40).  Every statement keeps the reference's
+// operation order.  REAL(4) exp / log / x**y are the C library's expf / logf / powf bit for bit (glibc_flt32.h), sqrt and divide
+// IEEE: oracle/wsm6_oracle.c (a separate restatement, pinned to the compiled reference) calls the host's libm, and
+// tests/test_gpu_wsm6.py compares bit for bit.
 #include "ctx.h"
 #include "glibc_flt32.h"
 #include <cmath>

@@ -29,9 +29,13 @@
 //     scale; tests assert 1e-5 on every cell (north-star tolerance) -- the donor-cell kernel of the upwind scheme
 //     (advect.hip) stays bit-exact.
 //
-// Scalar-independent inputs (U_m, V_m, W_m, W_m/dz, jacobian, rho, dz) are re-read per scalar from L2; they are 16-24 B
-// per cell against the 8 B of the scalar itself, which is why blocks of the same (tile, chunk) and different scalars are
-// scheduled onto the same XCD.
+// Everything that does not depend on the scalar is computed ONCE per step by k_mpdata_coef (icar_hip_setup_winds) and loaded:
+// per face the antidiffusive coefficient |U|(1-|U|/Gbar)/2 and the two cross-term factors U Ubar_perp / (8 Gbar) (the six 4-point
+// transverse Courant averages, the 1/(G_i + G_i-1), the ground / top / x-ring zeros folded in, the z faces already times dz), and
+// per cell 1/(jaco rho), 1/(jaco rho dz) -- three float4 arrays (round 2 recomputed all of it for each of the 9 scalars:
+// ~50 of 252 VALU instructions per scalar-cell).  They and U_m, V_m, W_m are re-read per scalar from L2 (64 B per cell against
+// the 8 B of the scalar itself), which is why blocks of the same (tile, chunk) and different scalars are scheduled onto the
+// same XCD.
 #include "ctx.h"
 #include <algorithm>
 #include <cmath>
@@ -62,10 +66,62 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ rsrc_t mkrsrc(const float *p) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, -1, 0x00020000); }
 __device__ __forceinline__ float ldb(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
 __device__ __forceinline__ void stb(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0); }
+// ------------------------------------------------------------------------------------------------
+// scalar-independent coefficients of the corrective iteration (mpdata_fluxes, adv_mpdata.f90:107-255), once per step
+// eleven arrays of the tile's shape in one buffer (MPC_* = index of the array):
+//   x face (i-1/2) of cell (i,k,j):        au, cuv, cuw
+//   y face between j-1 and j:              av, cvu, cvw
+//   z face above level k:                  (aw, cwu, cwv) * dz(k) ; zero for the top level (w2(kme) = 0, :214)
+//   cell:                                  1 / (jaco rho), 1 / (jaco rho dz)
+// a? = |C| (1 - 2 |C| / (G + G')) / 2 ;  c?? = C (sum of the 4 transverse Courant numbers around the face) / (16 (G + G'))
+// with G = jaco [rho]; cross terms through the ground / column top (k-1, k+1 missing) and in the x ring are zero.
+// ------------------------------------------------------------------------------------------------
+enum { MPC_AU = 0, MPC_CUV, MPC_CUW, MPC_AV, MPC_CVU, MPC_CVW, MPC_AW, MPC_CWU, MPC_CWV, MPC_RDH, MPC_RDV, MPC_N };
+template <bool RHO>
+__global__ void __launch_bounds__(256)
+k_mpdata_coef(Dims d, const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ Wz, const float *__restrict__ rho,
+              const float *__restrict__ jaco, const float *__restrict__ dz, float *__restrict__ C)
+{
+    const size_t n3 = (size_t)d.nx * d.nz * d.ny;
+    const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
+    if (i >= d.nx || k >= d.nz) return;
+    const int nx = d.nx, nz = d.nz, ny = d.ny;
+    const int iL = max(i - 1, 0), iR = min(i + 1, nx - 1), jP = max(j - 1, 0), jN = min(j + 1, ny - 1), kB = max(k - 1, 0), kT = min(k + 1, nz - 1);
+    auto at = [&](int ii, int kk, int jj) { return ii + nx * (kk + nz * jj); };
+    auto G = [&](int ii, int kk, int jj) { const int c = at(ii, kk, jj); return RHO ? jaco[c] * rho[c] : jaco[c]; };
+    const int c = at(i, k, j);
+    const bool xin = (i > 0) && (i < nx - 1), kin = (k > 0) && (k < nz - 1);
+    const float g = G(i, k, j), dzc = dz[c];
+    // x face (i-1/2)
+    {
+        const float rG = frcp(g + G(iL, k, j));
+        const float evv = (V[c] + V[at(i, k, jN)]) + (V[at(iL, k, j)] + V[at(iL, k, jN)]);
+        const float evw = (Wz[c] + Wz[at(i, kB, j)]) + (Wz[at(iL, k, j)] + Wz[at(iL, kB, j)]);
+        const float Uc = U[c], aU = fabsf(Uc), c0 = 0.0625f * Uc * rG;
+        C[MPC_AU * n3 + c] = 0.5f * aU * (1.0f - 2.0f * aU * rG); C[MPC_CUV * n3 + c] = c0 * evv; C[MPC_CUW * n3 + c] = kin ? c0 * evw : 0.0f;
+    }
+    // y face between j-1 and j
+    {
+        const float rG = frcp(g + G(i, k, jP));
+        const float evu = (U[at(i, k, jP)] + U[c]) + (U[at(iR, k, jP)] + U[at(iR, k, j)]);
+        const float evw = (Wz[at(i, k, jP)] + Wz[at(i, kB, jP)]) + (Wz[c] + Wz[at(i, kB, j)]);
+        const float Vc = V[c], aV = fabsf(Vc), c0 = 0.0625f * Vc * rG;
+        C[MPC_AV * n3 + c] = 0.5f * aV * (1.0f - 2.0f * aV * rG); C[MPC_CVU * n3 + c] = xin ? c0 * evu : 0.0f; C[MPC_CVW * n3 + c] = kin ? c0 * evw : 0.0f;
+    }
+    // z face above level k
+    if (k < nz - 1) {
+        const float rG = frcp(g + G(i, kT, j));
+        const float evu = (U[c] + U[at(i, kT, j)]) + (U[at(iR, k, j)] + U[at(iR, kT, j)]);
+        const float evv = (V[c] + V[at(i, k, jN)]) + (V[at(i, kT, j)] + V[at(i, kT, jN)]);
+        const float Wc = Wz[c], aW = fabsf(Wc), c0 = 0.0625f * Wc * rG;
+        C[MPC_AW * n3 + c] = 0.5f * aW * (1.0f - 2.0f * aW * rG) * dzc; C[MPC_CWU * n3 + c] = xin ? c0 * evu * dzc : 0.0f; C[MPC_CWV * n3 + c] = c0 * evv * dzc;
+    } else { C[MPC_AW * n3 + c] = 0.f; C[MPC_CWU * n3 + c] = 0.f; C[MPC_CWV * n3 + c] = 0.f; }
+    C[MPC_RDH * n3 + c] = frcp(g); C[MPC_RDV * n3 + c] = frcp(dzc * g);
+}
 
-// KB levels per thread (at most MP_NW waves per block), RHO: advect_density, FCT: limiter on,
+// KB levels per thread (at most MP_NW waves per block), FCT: limiter on (advect_density lives in the coefficients),
 // PASS1: first corrective iteration (donor-cell pass inside); false: iord >= 3, where q2 == q (adv_mpdata.f90:393-402)
-template <int KB, bool RHO, bool FCT, bool PASS1>
+template <int KB, bool FCT, bool PASS1>
 // 248 VGPRs, not the 256 two waves per SIMD could have (the attribute counts half of gfx90a+'s unified file: 124 -> 248).  The
 // 248 blocks of a launch hold their CUs for the whole kernel, so whatever the host issues on the second stream beside the
 // advection (whole-field forcing, the CFL reduction of the next update_dt) can only run in what these waves leave: with 2 x 248
@@ -73,8 +129,8 @@ template <int KB, bool RHO, bool FCT, bool PASS1>
 // the allocator takes if allowed) they wait for the launch to end -- the advection alone is then 5 % faster, the step 2 % slower.
 __global__ void __launch_bounds__(64 * MP_NW) __attribute__((amdgpu_num_vgpr(124)))
 k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
-               const float *__restrict__ Ug, const float *__restrict__ Vg, const float *__restrict__ Wg, const float *__restrict__ Wzg,
-               const float *__restrict__ rho, const float *__restrict__ jaco, const float *__restrict__ dzg, int clen, int ntile, int nchunk, int nscal, int nkr, int kstore)
+               const float *__restrict__ Ug, const float *__restrict__ Vg, const float *__restrict__ Wg,
+               const float *__restrict__ Cg, int asz, int clen, int ntile, int nchunk, int nscal, int nkr, int kstore)
 {
     constexpr int H = KB + 2;                       // own levels + one halo level below and above
     // exchange slots, double-buffered by step parity (a step without plane-P work has only the first exchange)
@@ -114,7 +170,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     }
     constexpr bool PARK = true;
     constexpr int NA4 = (H + 3) / 4, NB4 = 2 * KB;  // float4 slots: q2M[H] | mM nM v2S FyS bYinM bYoutM acc rdhM [KB each]
-    __shared__ float4 s_park[PARK ? NA4 + NB4 : 1][PARK ? 64 * MP_NW : 1];
+    constexpr int NC4 = (2 * KB + 3) / 4;           // 1 / (jaco rho), 1 / (jaco rho dz) of plane N: loaded for the donor-cell pass, needed
+                                                    // again by the roll of the NEXT step (N has become P by then)
+    __shared__ float4 s_park[PARK ? NA4 + NB4 + NC4 : 1][PARK ? 64 * MP_NW : 1];
 
     const int lane = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y), nw = blockDim.y;
@@ -145,8 +203,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     float *__restrict__ outp = qout.p[0];
 #pragma unroll
     for (int mm = 1; mm < ICAR_MAX_ADV; ++mm) if (mm == m) { qp = qin.p[mm]; outp = qout.p[mm]; }   // (a dynamic index would put the tables in scratch)
-    const rsrc_t q = mkrsrc(qp), out = mkrsrc(outp), Ur = mkrsrc(Ug), Vr = mkrsrc(Vg), Wr = mkrsrc(Wg), Wzr = mkrsrc(Wzg),
-                 rhor = mkrsrc(rho), jacor = mkrsrc(jaco), dzr = mkrsrc(dzg);
+    const rsrc_t q = mkrsrc(qp), out = mkrsrc(outp), Ur = mkrsrc(Ug), Vr = mkrsrc(Vg), Wr = mkrsrc(Wg),
+                 cr = mkrsrc(Cg);                           // the eleven coefficient arrays, asz bytes each
 
     const int i = 1 - MP_HL + tile * MP_XOUT + lane;
     const int ic = min(max(i, 0), nx - 1);
@@ -162,6 +220,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     for (int h = 0; h < H; ++h) kc[h] = min(max(k0 - 1 + h, 0), nz - 1) * nx * 4;       // byte offset of the level
 
 #define LDP(arr, h, plane) ldb(arr, bx, (plane) * sj4 + kc[h])
+#define LDC(a, h, plane) ldb(cr, bx, (a) * asz + (plane) * sj4 + kc[h])                 /* coefficient array a (MPC_*) */
 #define CLAMPJ(p) min(max((p), 0), ny - 1)
 
     // ---- rolling state (planes relative to the step's in-plane index P; N = P+1, M = P-1) ----
@@ -179,7 +238,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     for (int t = 0; t < NB4 * 4; ++t) pkB[t] = 0.f;
     if (PARK) {
 #pragma unroll
-        for (int t = 0; t < NA4 + NB4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < NA4 + NB4 + NC4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) { mP[kk] = nP[kk] = 0.f; DxP[kk] = SxP[kk] = DzP[kk] = SzP[kk] = 0.f; }
@@ -192,25 +251,27 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     for (int h = 0; h < H; ++h) qN[h] = LDP(q, h, CLAMPJ(P0 + 1));
 
     // inputs of one step (plane indices relative to that step's P): see ISSUE_LOADS
-    float qNN[H], GP[H], GN[KB], WN[KB + 1], UN[KB], VN[H], VNN[KB], dzN[KB];
-    float VP[H], UP[H], WzP[KB + 1], WzN[KB + 1], dzP[KB + 1];
-    float rN[RHO ? KB : 1], rP[RHO ? H : 1];
-// group A: what the donor-cell pass (first half of a step) reads; group B: inputs of the pseudo-velocity coefficients
+    float qNN[H], WN[KB + 1], UN[KB], VN[KB], VNN[KB], rdhN[KB], rdvN[KB];
+    float avN[KB], cvuN[KB], cvwN[KB], auP[KB], cuvP[KB], cuwP[KB], awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1];
+// group A: what the donor-cell pass (first half of a step) reads; group B: the x / y face coefficients (plane P / face P | N),
+// requested at the top of the step; group Z: the z face coefficients of plane P, requested after the donor-cell pass
 #define ISSUE_LOADS_A(PP)                                                                                                \
     {                                                                                                                    \
         const int lN = CLAMPJ((PP) + 1), lNN = CLAMPJ((PP) + 2);                                                         \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) GN[kk] = LDP(jacor, kk + 1, lN);                                \
         _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = LDP(Wr, h, lN);                                          \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = LDP(Ur, kk + 1, lN); VNN[kk] = LDP(Vr, kk + 1, lNN); dzN[kk] = LDP(dzr, kk + 1, lN); } \
-        _Pragma("unroll") for (int h = 0; h < H; ++h) VN[h] = LDP(Vr, h, lN);                                            \
-        if (RHO) { _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) rN[kk] = LDP(rhor, kk + 1, lN); }                    \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = LDP(Ur, kk + 1, lN); VN[kk] = LDP(Vr, kk + 1, lN); VNN[kk] = LDP(Vr, kk + 1, lNN); } \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { rdhN[kk] = LDC(MPC_RDH, kk + 1, lN); rdvN[kk] = LDC(MPC_RDV, kk + 1, lN); } \
     }
 #define ISSUE_LOADS_B(PP)                                                                                                \
     {                                                                                                                    \
         const int lP = CLAMPJ(PP), lN = CLAMPJ((PP) + 1);                                                                \
-        _Pragma("unroll") for (int h = 0; h < H; ++h) { GP[h] = LDP(jacor, h, lP); VP[h] = LDP(Vr, h, lP); UP[h] = LDP(Ur, h, lP); } \
-        if (RHO) { _Pragma("unroll") for (int h = 0; h < H; ++h) rP[h] = LDP(rhor, h, lP); }                              \
-        _Pragma("unroll") for (int h = 0; h <= KB; ++h) { WzP[h] = LDP(Wzr, h, lP); WzN[h] = LDP(Wzr, h, lN); dzP[h] = LDP(dzr, h, lP); } \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { avN[kk] = LDC(MPC_AV, kk + 1, lN); cvuN[kk] = LDC(MPC_CVU, kk + 1, lN); cvwN[kk] = LDC(MPC_CVW, kk + 1, lN); } \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { auP[kk] = LDC(MPC_AU, kk + 1, lP); cuvP[kk] = LDC(MPC_CUV, kk + 1, lP); cuwP[kk] = LDC(MPC_CUW, kk + 1, lP); } \
+    }
+#define ISSUE_LOADS_Z(PP)                                                                                                \
+    {                                                                                                                    \
+        const int lP = CLAMPJ(PP);                                                                                       \
+        _Pragma("unroll") for (int h = 0; h <= KB; ++h) { awP[h] = LDC(MPC_AW, h, lP); cwuP[h] = LDC(MPC_CWU, h, lP); cwvP[h] = LDC(MPC_CWV, h, lP); } \
     }
 // the scalar itself: every plane of it comes from HBM exactly once, so its latency is the longest of all inputs
 #define ISSUE_LOADS_Q(DST, PLANE)                                                                                        \
@@ -250,10 +311,6 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         // L2 round trips per step.
         ISSUE_LOADS_B(P)                                           // land while the donor-cell pass runs
         __builtin_amdgcn_sched_barrier(0);
-        if (RHO) {
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) GN[kk] *= rN[kk];
-        }
 
         // ================= S1: donor-cell pass on plane N, its extrema and x/z differences =================
         float q2N[H], mN[KB], nN[KB], DxN[KB], SxN[KB], DzN[KB], SzN[KB];
@@ -272,8 +329,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 }
                 auto donor = [&](const int kk) {
                     const int h = kk + 1;
-                    const float Uc = UN[kk], Vs = VN[h], Vn = VNN[kk];
-                    const float rdh = frcp(GN[kk]), rdv = frcp(dzN[kk] * GN[kk]);
+                    const float Uc = UN[kk], Vs = VN[kk], Vn = VNN[kk];
+                    const float rdh = rdhN[kk], rdv = rdvN[kk];
                     const float FxL = upw(dpp_l(qN[h]), qN[h], Uc), FxR = dpp_r(FxL);
                     const float Fs = upw(qP[kk], qN[h], Vs), Fn = upw(qN[h], qNN[h], Vn);
                     const float v = qN[h] - ((FxR - FxL) + (Fn - Fs)) * rdh - (FzT[h] - FzT[h - 1]) * rdv;
@@ -321,35 +378,29 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         for (int h = 0; h < H; ++h) qN[h] = qNN[h];
         __builtin_amdgcn_sched_barrier(0);
         ISSUE_LOADS_Q(qNN, P + 3)
+        ISSUE_LOADS_Z(P)
         __builtin_amdgcn_sched_barrier(0);
+        // 1 / (jaco rho), 1 / (jaco rho dz) of plane N: parked for the roll of the next step; those of plane P come back
+        float rdhL[KB], rdvL[KB];
+        {
+            float pc[NC4 * 4];
+#pragma unroll
+            for (int t = 0; t < NC4; ++t) { const float4 v = s_park[NA4 + NB4 + t][tid]; pc[4 * t] = v.x; pc[4 * t + 1] = v.y; pc[4 * t + 2] = v.z; pc[4 * t + 3] = v.w; }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) { rdhL[kk] = pc[kk]; rdvL[kk] = pc[KB + kk]; pc[kk] = rdhN[kk]; pc[KB + kk] = rdvN[kk]; }
+#pragma unroll
+            for (int t = 0; t < NC4; ++t) s_park[NA4 + NB4 + t][tid] = make_float4(pc[4 * t], pc[4 * t + 1], pc[4 * t + 2], pc[4 * t + 3]);
+        }
 
         // ================= S2: y face between planes P and N =================
         float v2N[KB], FyN[KB];
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; }
-        // scalar-independent sums shared by S2 and S3
-        if (RHO) {
-#pragma unroll
-            for (int h = 0; h < H; ++h) GP[h] *= rP[h];
-        }
-        float Vsum[H];                                             // V(P) + V(N) per level
-#pragma unroll
-        for (int h = 0; h < H; ++h) Vsum[h] = VP[h] + VN[h];
-        float WzsP[KB];                                            // Wz(k) + Wz(k-1) on plane P
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) WzsP[kk] = WzP[kk + 1] + WzP[kk];
         if (STEADY || (P >= 0 && haveN)) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const int h = kk + 1;
-                const bool kin = !((kk == 0 && gnd) || (h >= htop));          // not the lowest / highest level
-                const float Vc = VN[h];
-                const float rG = frcp(GN[kk] + GP[h]);
-                const float Us = UP[h] + UN[kk];
-                const float evu = Us + dpp_r(Us);
-                const float evw = WzsP[kk] + (WzN[h] + WzN[h - 1]);
-                const float aV = fabsf(Vc), av = 0.5f * aV * (1.0f - 2.0f * aV * rG), c0 = 0.0625f * Vc * rG;
-                const float cvu = xin ? c0 * evu : 0.0f, cvw = kin ? c0 * evw : 0.0f;
+                const float av = avN[kk], cvu = cvuN[kk], cvw = cvwN[kk];          // k_mpdata_coef
                 const float t = av * (q2N[h] - q2P[h]) * frcp(q2N[h] + q2P[h] + EPSQ)
                               - cvu * (DxN[kk] + DxP[kk]) * frcp(SxN[kk] + SxP[kk] + EPSQ)
                               - cvw * (DzN[kk] + DzP[kk]) * frcp(SzN[kk] + SzP[kk] + EPSQ);
@@ -358,9 +409,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         }
 
         // ================= S3: x and z faces of plane P, their limiter, divergence =================
-        float xdiv[KB], zdiv[KB], rdhP[KB], rdvP[KB];
+        float xdiv[KB], zdiv[KB];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) { xdiv[kk] = zdiv[kk] = 0.f; rdhP[kk] = rdvP[kk] = 0.f; }
+        for (int kk = 0; kk < KB; ++kk) { xdiv[kk] = zdiv[kk] = 0.f; }
         float q2M[H];
         if (PARK) {
 #pragma unroll
@@ -378,13 +429,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const int h = kk + 1;
-                const bool kin = !((kk == 0 && gnd) || (h >= htop));
-                const float Uc = UP[h];
-                const float rG = frcp(GP[h] + dpp_l(GP[h]));
-                const float evv = Vsum[h] + dpp_l(Vsum[h]);
-                const float evw = WzsP[kk] + dpp_l(WzsP[kk]);
-                const float aU = fabsf(Uc), au = 0.5f * aU * (1.0f - 2.0f * aU * rG), c0 = 0.0625f * Uc * rG;
-                const float cuv = c0 * evv, cuw = kin ? c0 * evw : 0.0f;
+                const float au = auP[kk], cuv = cuvP[kk], cuw = cuwP[kk];
                 const float qL = dpp_l(q2P[h]);
                 const float t = au * (q2P[h] - qL) * frcp(q2P[h] + qL + EPSQ)
                               - cuv * (Dy[h] + dpp_l(Dy[h])) * frcp(Sy[h] + dpp_l(Sy[h]) + EPSQ)
@@ -400,18 +445,11 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             float Fz[KB + 1], w2[KB + 1];
 #pragma unroll
             for (int hf = 0; hf <= KB; ++hf) {
-                const float Wc = WzP[hf];
-                const float rG = frcp(GP[hf] + GP[hf + 1]);
-                const float Uk = UP[hf] + UP[hf + 1];
-                const float evu = Uk + dpp_r(Uk);
-                const float evv = Vsum[hf] + Vsum[hf + 1];
-                const float aW = fabsf(Wc), aw = 0.5f * aW * (1.0f - 2.0f * aW * rG), c0 = 0.0625f * Wc * rG;
-                const float cwu = xin ? c0 * evu : 0.0f, cwv = c0 * evv;
+                const float aw = awP[hf], cwu = cwuP[hf], cwv = cwvP[hf];         // already times dz (:383-385); zero for the top level (:214)
                 float t = aw * (q2P[hf + 1] - q2P[hf]) * frcp(q2P[hf + 1] + q2P[hf] + EPSQ)
                         - cwu * (DxA[hf] + DxA[hf + 1]) * frcp(SxA[hf] + SxA[hf + 1] + EPSQ)
                         - cwv * (Dy[hf] + Dy[hf + 1]) * frcp(Sy[hf] + Sy[hf + 1] + EPSQ);
-                t = t * dzP[hf];
-                if ((hf == 0 && gnd) || hf >= htop) t = 0.0f;    // no face below the ground; w2(top) = 0 (adv_mpdata.f90:214)
+                if (hf == 0 && gnd) t = 0.0f;                     // no face below the ground (slot 0 is a clamped load there)
                 w2[hf] = t; Fz[hf] = upw(q2P[hf], q2P[hf + 1], t);
             }
             // ---- limiter, x direction
@@ -475,7 +513,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 zdiv[kk] = FzLim[kk + 1] - FzLim[kk];
-                rdhP[kk] = frcp(GP[kk + 1]); rdvP[kk] = frcp(dzP[kk + 1] * GP[kk + 1]);
+
             }
         }
 
@@ -538,8 +576,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             const int h = kk + 1;
             pkB[kk] = mP[kk]; pkB[KB + kk] = nP[kk]; pkB[2 * KB + kk] = v2N[kk]; pkB[3 * KB + kk] = FyN[kk];
             pkB[4 * KB + kk] = bYin[kk]; pkB[5 * KB + kk] = bYout[kk];
-            pkB[6 * KB + kk] = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdhP[kk] - zdiv[kk] * rdvP[kk];
-            pkB[7 * KB + kk] = rdhP[kk];
+            pkB[6 * KB + kk] = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdhL[kk] - zdiv[kk] * rdvL[kk];
+            pkB[7 * KB + kk] = rdhL[kk];
             mP[kk] = mN[kk]; nP[kk] = nN[kk];
             DxP[kk] = DxN[kk]; SxP[kk] = SxN[kk]; DzP[kk] = DzN[kk]; SzP[kk] = SzN[kk];
         }
@@ -566,6 +604,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #undef ISSUE_LOADS_Q
 #undef ISSUE_LOADS_B
 #undef LDP
+#undef LDC
+#undef ISSUE_LOADS_Z
 #undef MP_POST
 #undef MP_WAIT
 #undef MP_WAIT1
@@ -576,22 +616,37 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 // host side
 // ------------------------------------------------------------------------------------------------
 template <int KB>
-static void launch_fused(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
-                         const float *rho, const float *jaco, const float *dz, int nw, int clen, int ntile, int nchunk, int nkr, int kstore)
+static void launch_fused(icar_hip_ctx *c, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
+                         int nw, int clen, int ntile, int nchunk, int nkr, int kstore)
 {
     const unsigned nitem = (unsigned)(ntile * nchunk * nkr * nv), cap = (nitem + 7u) / 8u;
     const dim3 g(8u * cap), b(64, nw);                      // block id = xcd + 8 * slot, slot < cap
-#define GO(R, F, P1) hipLaunchKernelGGL((k_mpdata_fused<KB, R, F, P1>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->Wdz, rho, jaco, dz, clen, ntile, nchunk, nv, nkr, kstore)
-    if (rho_on) { if (fct) { if (pass1) GO(true, true, true); else GO(true, true, false); } else { if (pass1) GO(true, false, true); else GO(true, false, false); } }
-    else        { if (fct) { if (pass1) GO(false, true, true); else GO(false, true, false); } else { if (pass1) GO(false, false, true); else GO(false, false, false); } }
+#define GO(F, P1) hipLaunchKernelGGL((k_mpdata_fused<KB, F, P1>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->mpc, (int)(c->n3 * sizeof(float)), clen, ntile, nchunk, nv, nkr, kstore)
+    if (fct) { if (pass1) GO(true, true); else GO(true, false); } else { if (pass1) GO(false, true); else GO(false, false); }
 #undef GO
 }
 
+// the scalar-independent coefficients of this step's Courant winds (c->U, c->V, c->Wdz), for icar_hip_setup_winds
+int icar_mpdata_coef_run(icar_hip_ctx *c, bool rho_on)
+{
+    const float *jaco = icar_field_f(c, ICAR_F_JACOBIAN), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
+    const float *rho = rho_on ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
+    if (!jaco || !dz || (rho_on && !rho)) return 1;
+    if (c->n3 * sizeof(float) * MPC_N >= ((size_t)1 << 31)) { icar_set_error("mpdata: a tile of more than 48 M cells is not supported (32-bit buffer offsets into the coefficient arrays)"); return 1; }
+    if (!c->mpc) HIPCHK(hipMalloc(&c->mpc, c->n3 * sizeof(float) * MPC_N));
+    const dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
+    if (rho_on) hipLaunchKernelGGL(k_mpdata_coef<true>, g, b, 0, c->stream, c->d, c->U, c->V, c->Wdz, rho, jaco, dz, c->mpc);
+    else        hipLaunchKernelGGL(k_mpdata_coef<false>, g, b, 0, c->stream, c->d, c->U, c->V, c->Wdz, rho, jaco, dz, c->mpc);
+    HIPCHK(hipGetLastError());
+    c->mpc_dens = rho_on ? 1 : 0;
+    return 0;
+}
+
 // one corrective iteration of MPDATA: in -> out (distinct buffers).  pass1: the donor-cell pass is part of it (iord == 2).
-int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
-                          const float *rho, const float *jaco, const float *dz)
+int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv)
 {
     const int nx = c->d.nx, nz = c->d.nz, ny = c->d.ny;
+    if (!c->mpc || c->mpc_dens != (rho_on ? 1 : 0)) { icar_set_error("mpdata: icar_hip_setup_winds(scheme 2) with the same advect_density must come first"); return 1; }
     if (nx < 3 || ny < 3) { icar_set_error("mpdata: tile must be at least 3 x 3 cells"); return 1; }
     if ((size_t)nx * nz * ny * sizeof(float) >= ((size_t)1 << 31)) { icar_set_error("mpdata: a field of 2 GiB or more is not supported (32-bit buffer offsets)"); return 1; }
     const int ntile = std::max(1, (nx - 2 + MP_XOUT - 1) / MP_XOUT);
@@ -614,7 +669,7 @@ int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, co
     }
     const int clen = (rows + nchunk - 1) / nchunk;
     nchunk = (rows + clen - 1) / clen;
-#define KBCASE(K) case K: launch_fused<K>(c, rho_on, fct, pass1, in, out, nv, rho, jaco, dz, nw, clen, ntile, nchunk, nkr, kstore); break;
+#define KBCASE(K) case K: launch_fused<K>(c, fct, pass1, in, out, nv, nw, clen, ntile, nchunk, nkr, kstore); break;
     switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) default: icar_set_error("mpdata: internal level-range error"); return 1; }
 #undef KBCASE
     HIPCHK(hipGetLastError());

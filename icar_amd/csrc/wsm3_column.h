@@ -437,7 +437,6 @@ W3_FN void wsm3_column(const wsm3_consts *C, const wsm3_args *A, int km, float *
     }
 }
 
-#ifdef W3_HOST_INIT
 /* wsm3init (:951-1006) with the arguments of mp_driver.f90:105: REAL(4) arithmetic in the reference's order, libm for
  * exp / atan / x**y (host side, once).  rgmma (:905-922) is the 10000-term product form of 1/Gamma. */
 static float w3_rgmma(float x)
@@ -479,6 +478,4 @@ static void wsm3_init_consts(wsm3_consts *C, float den0, float denr, float dens,
     C->rsloper2max = C->rslopermax * C->rslopermax; C->rslopes2max = C->rslopesmax * C->rslopesmax;
     C->rsloper3max = C->rsloper2max * C->rslopermax; C->rslopes3max = C->rslopes2max * C->rslopesmax;
 }
-#endif
-
 #endif

@@ -33,3 +33,12 @@ def oracle():
     from oracle import orc
     orc.build()
     return orc
+
+
+@pytest.fixture(scope="session")
+def th_oracle(oracle):
+    """the oracle with the Thompson tables of the default mp_options built (thompson_init)"""
+    from icar_amd.options import options_t
+    p, f = options_t().mp_options.as_arrays()
+    oracle.thompson_init(p, f)
+    return oracle

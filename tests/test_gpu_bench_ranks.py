@@ -27,7 +27,7 @@ def _line(r):
     return json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("n,decomp", [(2, "2x1"), (4, "2x2"), (8, "2x4")])
+@pytest.mark.parametrize("n,decomp", [(2, "2x1"), (4, "2x2"), (8, "4x2")])
 def test_bench_gpus_n_spawns_n_ranks_on_the_fixed_global_grid(n, decomp):
     r = _run(["--gpus", str(n)] + SMALL, {"ICAR_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]

@@ -28,14 +28,6 @@ FIELDS = {"water_vapor": "water_vapor", "cloud_water": "cloud_water_mass", "rain
           "potential_temperature": "potential_temperature"}
 
 
-@pytest.fixture(scope="module")
-def th_oracle(oracle):
-    opt = options_t()
-    p, f = opt.mp_options.as_arrays()
-    oracle.thompson_init(p, f)
-    return oracle
-
-
 def device_table(d, name):
     n = ctypes.c_size_t()
     check(lib().icar_hip_thompson_table(d.ctx, name.encode(), None, ctypes.c_size_t(0), ctypes.byref(n)), "table size")

@@ -38,8 +38,13 @@ def _advect_oracle(orc, s, c, dt, names):
         s[n] = q[m].copy()
 
 
-# measured on MI355X (profiles/r03_parity.json, trajectory/*): see the table in DESIGN.md section 4; bounds = 2x
-TRAJ_BOUNDS = {"thompson": dict(beyond=2e-2, pointwise=1.0, absmax=2e-2), "simple": dict(beyond=2e-2, pointwise=1.0, absmax=2e-2)}
+# measured on MI355X (profiles/r03_parity.json, trajectory/*), worst field, worst of the recorded sub-steps: Thompson 0.127 of the
+# cells beyond 1e-5 pointwise, max |d| 0.109 of the field maximum (ice number, sub-step 5); mp_simple 0.186 / 0.144 (rain).  After
+# ONE sub-step: <= 6.1e-6 of the cells, 2.7e-7 of the maximum.  The growth is the case's own sensitivity: the CPU oracle perturbed by
+# half an ulp (6e-8) of the local value after every advection diverges from itself by the same amounts
+# (tests/test_oracle_trajectory_sensitivity.py).  Bounds = 2x measured.
+TRAJ_BOUNDS = {"thompson": dict(beyond=0.26, absmax=0.22), "simple": dict(beyond=0.38, absmax=0.29)}
+FIRST_STEP_BOUNDS = dict(beyond=1.3e-5, absmax=6e-7)
 
 
 @pytest.mark.parametrize("scheme", ["thompson", "simple"])
@@ -85,8 +90,9 @@ def test_trajectory_ten_unsynchronised_substeps(th_oracle, oracle, scheme):
     parity_record("trajectory", f"{scheme}/128x96x40/precipitation", {"acc": {"sum_rel_diff": float(rel_p), "sum": float(acc.sum())}})
     assert acc.max() > 0 and float(s["cloud_water"].max()) > 1e-6, "the case must have active microphysics"
     b = TRAJ_BOUNDS[scheme]
-    w = worst[nsteps]
-    assert w["beyond_rtol_frac"] <= b["beyond"] and w["max_abs_over_max"] <= b["absmax"], (scheme, worst)
+    assert worst[1]["beyond_rtol_frac"] <= FIRST_STEP_BOUNDS["beyond"] and worst[1]["max_abs_over_max"] <= FIRST_STEP_BOUNDS["absmax"], (scheme, worst[1])
+    for it, w in worst.items():
+        assert w["beyond_rtol_frac"] <= b["beyond"] and w["max_abs_over_max"] <= b["absmax"], (scheme, it, w)
     assert rel_p <= 1e-3, rel_p
     d.close()
 
