@@ -8,7 +8,7 @@
 import csv, glob, io, json, os, shutil, subprocess, sys
 from collections import defaultdict
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
-RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 O = os.path.join(ROOT, "gpurun_out", RND)
 shutil.copy(os.path.join(O, "bench_line.json"), os.path.join(HERE, RND + "_bench_line.json"))
 if os.path.exists(os.path.join(O, "winds.json")):
@@ -34,7 +34,8 @@ line = json.loads(open(os.path.join(O, "bench_line.json")).read().strip().splitl
 tm = line["config"]["tile_memory"]
 json.dump({"hbm_bytes_per_advect_call": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernels": sorted(adv), "round": RND,
            # bench.py attaches this figure to its roofline only for exactly this configuration and kernel generation
-           "config": {"nx": tm[0], "ny": tm[2], "nz": tm[1], "adv": "mpdata", "nscalars": 9, "kernels": line["roofline"]["kernel"].split("(", 1)[1].rstrip(")")},
+           "config": {"nx": tm[0], "ny": tm[2], "nz": tm[1], "adv": "mpdata", "nscalars": 9, "kernels": line["roofline"]["kernel"].split("(", 1)[1].rstrip(")"),
+                      "generation": __import__("re").search(r'KERNEL_GENERATION = "([^"]*)"', open(os.path.join(ROOT, "bench.py")).read()).group(1)},
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B, "
                      "MI355X_MICROARCH.md); mean per dispatch, one dispatch of each kernel per advect() call; 512x512x40, 9 scalars"},
           open(os.path.join(HERE, "advect_traffic.json"), "w"), indent=1)

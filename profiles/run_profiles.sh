@@ -6,7 +6,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
-RND=${1:-r02}
+RND=${1:-r03}
 O=gpurun_out/$RND; rm -rf $O; mkdir -p $O
 timeout 400 python bench.py > $O/bench_line.json 2> $O/bench.err
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
