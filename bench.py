@@ -86,17 +86,16 @@ KERNEL_GENERATION = "r03: scalar-independent MPDATA coefficients precomputed (k_
 FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
 
 
-def one_step(d, opt):
-    from icar_amd.time_step import update_dt, substep
-    dt = update_dt(d, opt)                   # icar_hip_update_dt: CFL reduction (prefetched beside the last advection) + co_min over RCCL
-    # icar_hip_substep: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect -> apply_forcing
-    # at EVERY world size: the strips + pack (+ RCCL send/recv) on the main stream, the interior on the second stream (with the
-    # wind setup beside it), the w_real diagnostic, the whole-field forcing of u, v, w, p and the next CFL reduction beside the
-    # advection.  With one image the edges wrap around to the tile itself (ICAR_NEIGHBOR_SELF: same pack / unpack kernels, no
-    # transport), so the N=1 line times the launches every rank of an N>1 run pays.
-    substep(d, opt, dt, forced=FORCED)
-    d.model_time_seconds += dt
-    return dt
+def run_steps(d, opt, n):
+    """n steps in ONE library call (icar_hip_step_n): update_dt -> substep -> clock += dt, nothing of the host in between.
+    update_dt: the CFL reduction (prefetched beside the last advection) + co_min over RCCL.  substep: diagnostic_update ->
+    mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve -> advect -> apply_forcing at EVERY world size: the interior on the
+    main stream, the strips + pack (+ RCCL send / recv) + the wind setup beside it on the second stream; the w_real diagnostic,
+    the whole-field forcing of u, v, w, p and the next CFL reduction beside the advection.  With one image the edges wrap around
+    to the tile itself (ICAR_NEIGHBOR_SELF: same pack / unpack kernels, no transport), so the N=1 line times the launches every
+    rank of an N>1 run pays."""
+    from icar_amd.time_step import step_n
+    return step_n(d, n, opt, forced=FORCED)
 
 
 def cpu_reference(args, domain, nscalars):
@@ -333,13 +332,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step(d, opt)
+    if args.warmup > 0:
+        run_steps(d, opt, args.warmup)
     barrier()
     lib.icar_hip_timing_enable(d.ctx, 1); lib.icar_hip_timing_reset(d.ctx)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dt = one_step(d, opt)
+    dt = run_steps(d, opt, args.steps)       # exactly K steps: K x (icar_hip_update_dt + icar_hip_substep), issued from C
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -26,7 +26,7 @@ SYMBOLS = [
     "icar_hip_comm_unique_id", "icar_hip_comm_init", "icar_hip_comm_init_host", "icar_hip_comm_destroy", "icar_hip_comm_kind",
     "icar_hip_halo_send", "icar_hip_halo_retrieve", "icar_hip_co_min", "icar_hip_co_max",
     "icar_hip_step_configure", "icar_hip_model_time_set", "icar_hip_model_time", "icar_hip_mp_reset", "icar_hip_compute_dt",
-    "icar_hip_update_dt", "icar_hip_mp", "icar_hip_advect_step", "icar_hip_substep", "icar_hip_step",
+    "icar_hip_update_dt", "icar_hip_mp", "icar_hip_advect_step", "icar_hip_substep", "icar_hip_step", "icar_hip_step_n",
     "icar_hip_linwinds_setup", "icar_hip_linwinds_terrain_frequency", "icar_hip_linear_perturbation",
     "icar_hip_linwinds_build_lut", "icar_hip_linwinds_build_lut_varying", "icar_hip_linwinds_lut_download", "icar_hip_linwinds_lut_upload",
     "icar_hip_linwinds_perturbation_download", "icar_hip_linwinds_perturbation_upload", "icar_hip_spatial_winds",
@@ -86,6 +86,7 @@ def lib():
         L.icar_hip_advect_step.argtypes = [vp, cd]
         L.icar_hip_substep.argtypes = [vp, cd, ci]
         L.icar_hip_step.argtypes = [vp, cd, ctypes.POINTER(ci)]
+        L.icar_hip_step_n.argtypes = [vp, ci, ctypes.POINTER(cd)]
         L.icar_hip_update_dt.argtypes = [vp, ctypes.POINTER(cd)]
         L.icar_hip_compute_dt.argtypes = [vp, ctypes.POINTER(cd)]
         L.icar_hip_co_min.argtypes = [vp, ctypes.POINTER(cd)]

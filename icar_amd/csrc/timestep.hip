@@ -5,10 +5,10 @@
 // overhead (12-25 ctypes / iso_c_binding round trips per sub-step before).
 //
 // What runs beside what (same launches, operands and results as the plain sequence):
-//   main stream                                           second stream
+//   main stream (the critical path)                       second stream (side work, done before each join)
 //   diagnostic_update part 1 (exner, T, rho, ...)
-//   mp(halo=1) strips -> halo_send (pack + RCCL)          mp(subset=1) interior            time_step.f90:512-526
-//   setup_module_winds of the advect() that follows       |
+//   mp(subset=1) interior                                 mp(halo=1) strips -> halo_send (pack + RCCL)   time_step.f90:512-526
+//   |                                                     setup_module_winds (+ MPDATA coefficients) of the advect() that follows
 //   halo_retrieve (unpack)  <----------------------------- join
 //   advect                                                w_real diagnostic, forcing of u, v, w, p, CFL reduction of the next step
 //   forcing of the advected scalars (boundary ring) <----- join
@@ -185,21 +185,23 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
 
     // :512-526  mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
     if (g.microphysics != 0) {
+        // The interior launch is the critical path of this block, so IT stays on the main stream (diag -> interior -> unpack ->
+        // advect are then same-stream neighbours); the side work -- strips, pack + transfer, and the wind setup of the advect()
+        // that follows -- goes to the second stream and has finished long before the join.  (Rounds 1-2 had it the other way
+        // round: every edge of the critical path was then a cross-stream event, ~20 us each on this runtime.)
         if (icar_hip_aux_fork(c)) return 1;
-        if (icar_mp_run(c, dt, 1, -1)) return 1;
-        if (halo_send(c)) return 1;
         {
             AuxScope aux(c);
             if (aux.begin()) return 1;
-            if (icar_mp_run(c, dt, -1, 1)) return 1;
+            if (icar_mp_run(c, dt, 1, -1)) return 1;                              // :512 strips (the halo pass leaves last_model_time alone, :711)
+            if (halo_send(c)) return 1;                                           // :515 pack + RCCL send / recv
+            // the Courant winds (and MPDATA coefficients) read u, v, w, density and the jacobians, none of which the microphysics
+            // touches: streaming kernels beside the VALU-bound interior launch
+            if (adv && setup_winds(c, dtf)) return 1;
         }
-        // the Courant winds of the advect() that follows read u, v, w, density and the jacobians, none of which the microphysics
-        // touches: a streaming kernel on the main stream beside the VALU-bound interior launch
-        if (adv && setup_winds(c, dtf)) return 1;
+        if (icar_mp_run(c, dt, -1, 1)) return 1;                                  // :523 interior
         if (icar_hip_aux_join(c)) return 1;
-        // update_interval gating (:711): the halo pass leaves last_model_time alone, the subset pass is what moves it in the
-        // reference (`if (.not.present(halo))`); both passes above saw the same mp_dt
-        if (halo_retrieve(c)) return 1;
+        if (halo_retrieve(c)) return 1;                                           // :526
     } else {
         if (halo_send(c)) return 1;
         if (halo_retrieve(c)) return 1;
@@ -303,6 +305,24 @@ int icar_hip_substep(icar_hip_ctx *c, double dt_seconds, int enforce_limits)
     if (c->on_aux) { icar_set_error("substep: called between aux_begin and aux_end"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_substep(c, dt_seconds, enforce_limits != 0);
+}
+
+// nsteps sub-steps of the loop without an end time (a benchmark's "K passes of the hot path", a host that counts steps):
+// update_dt -> substep -> clock += dt, nothing of the host in between.  dt_last receives the last step's dt.
+int icar_hip_step_n(icar_hip_ctx *c, int nsteps, double *dt_last)
+{
+    if (!c) { icar_set_error("null ctx"); return 1; }
+    if (!cfg_ok(c, "step_n")) return 1;
+    if (c->on_aux) { icar_set_error("step_n: called between aux_begin and aux_end"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    double dt = 0.0;
+    for (int n = 0; n < nsteps; ++n) {
+        if (icar_update_dt(c, &dt)) return 1;
+        if (icar_substep(c, dt, false)) return 1;
+        c->step.model_time += dt;
+    }
+    if (dt_last) *dt_last = dt;
+    return 0;
 }
 
 int icar_hip_step(icar_hip_ctx *c, double end_time_seconds, int *nsteps)

@@ -17,7 +17,7 @@ module icar_hip
             hip_diagnostic_update, hip_diagnostic_update_parts, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
             hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_wsm6_tiles, hip_winds_valid, hip_max_courant_prefetch, &
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative, &
-            hip_step_config_t, hip_step_configure, hip_update_dt, hip_compute_dt, hip_substep, hip_step, hip_mp, hip_advect_step, hip_mp_reset, &
+            hip_step_config_t, hip_step_configure, hip_update_dt, hip_compute_dt, hip_substep, hip_step, hip_step_n, hip_mp, hip_advect_step, hip_mp_reset, &
             hip_model_time, hip_set_model_time, hip_comm_unique_id, hip_comm_init, hip_comm_init_local, hip_comm_init_host, hip_comm_destroy, &
             hip_halo_send, hip_halo_retrieve, hip_co_min, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
@@ -267,6 +267,9 @@ module icar_hip
      integer(c_int) function icar_hip_step(ctx, end_time, nsteps) bind(C, name="icar_hip_step")
        import; type(c_ptr), value :: ctx; real(c_double), value :: end_time; integer(c_int), intent(out) :: nsteps
      end function
+     integer(c_int) function icar_hip_step_n(ctx, nsteps, dt_last) bind(C, name="icar_hip_step_n")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: nsteps; real(c_double), intent(out) :: dt_last
+     end function
   end interface
 
 contains
@@ -307,6 +310,14 @@ contains
     integer :: nsteps
     integer(c_int) :: n
     call check(icar_hip_step(ctx%p, end_time, n), "step"); nsteps = n
+  end function
+
+  !> nsteps sub-steps (update_dt -> substep -> clock += dt) without an end time; returns the last dt
+  function hip_step_n(ctx, nsteps) result(dt)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: nsteps
+    real(c_double) :: dt
+    call check(icar_hip_step_n(ctx%p, int(nsteps,c_int), dt), "step_n")
   end function
 
   !> mp(domain, options, dt, halo, subset) (mp_driver.f90:673-772); absent halo / subset like the reference's optionals

@@ -61,3 +61,11 @@ def step(domain, end_time, options, forced=None, diagnostics=True):
     n = ctypes.c_int()
     check(lib().icar_hip_step(domain.ctx, float(end_time), ctypes.byref(n)), "icar_hip_step")
     return n.value
+
+
+def step_n(domain, nsteps, options, forced=None, diagnostics=True):
+    """nsteps passes of update_dt -> substep -> clock += dt in one library call (icar_hip_step_n); returns the last dt."""
+    domain.configure(options, forced=forced or (), diagnostics=diagnostics, prefetch_dt=True)
+    dt = ctypes.c_double()
+    check(lib().icar_hip_step_n(domain.ctx, int(nsteps), ctypes.byref(dt)), "icar_hip_step_n")
+    return dt.value

@@ -412,6 +412,9 @@ int icar_hip_mp(icar_hip_ctx *ctx, double dt, int halo, int subset);
 int icar_hip_advect_step(icar_hip_ctx *ctx, double dt);
 int icar_hip_substep(icar_hip_ctx *ctx, double dt_seconds, int enforce_limits);
 int icar_hip_step(icar_hip_ctx *ctx, double end_time_seconds, int *nsteps);
+/* the same loop for a given NUMBER of sub-steps (update_dt -> substep -> clock += dt each), no end-of-interval clamp and no
+ * enforce_limits: what a benchmark times as "K passes of the hot path".  dt_last (may be NULL) receives the last dt. */
+int icar_hip_step_n(icar_hip_ctx *ctx, int nsteps, double *dt_last);
 
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Average duration (ms) of the launches of a named kernel group since the last reset, measured
