@@ -22,12 +22,27 @@ NXG, NYG, NZ, NSTEPS = 64, 48, 12, 4
 NAMES = ["water_vapor", "cloud_water_mass", "rain_mass", "snow_mass", "potential_temperature"]
 
 
-def _setup(case, g, opt, comm):
+def _rendezvous(rank, world):
+    """One GPU per image over RCCL when the box has enough GPUs (the library's ncclSend / ncclRecv transport); otherwise all images
+    share cuda:0 and the library stages the messages through host memory (RCCL refuses two ranks on one device).  Returns the
+    device index of this image and the process group the HOST-array doubles of the tile exchange over (gloo; None = the default)."""
+    import datetime
+    multi = torch.cuda.device_count() >= world
+    dev = rank if multi else 0
+    torch.cuda.set_device(dev)
+    if multi:
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120), device_id=torch.device("cuda", dev))
+        return dev, dist.new_group(backend="gloo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    return dev, None
+
+
+def _setup(case, g, opt, comm, device=0):
     from icar_amd.domain import domain_t
     from icar_amd.microphysics import mp_init
     from icar_amd.advection import adv_init
     from icar_amd.constants import ADVECTION_ORDER
-    d = domain_t(g, device=0, dx=float(case["dx"]), comm=comm)
+    d = domain_t(g, device=device, dx=float(case["dx"]), comm=comm)
     sl = (slice(g.jms - 1, g.jme), slice(None), slice(g.ims - 1, g.ime))
     tile = {}
     for k, v in case.items():
@@ -73,10 +88,8 @@ def _options(adv, case):
 def _worker(rank, world, port, adv, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    dev, hgroup = _rendezvous(rank, world)
     try:
-        torch.cuda.set_device(0)
         from icar_amd import ideal
         from icar_amd.grid import grid_t
         from icar_amd.halo import HaloComm
@@ -85,7 +98,7 @@ def _worker(rank, world, port, adv, q):
         case["water_vapor"] = (case["water_vapor"] * np.float32(2.4)).astype(np.float32)
         opt = _options(adv, case)
         g = grid_t().set_grid_dimensions(NXG, NYG, NZ, world, rank + 1)
-        d = _setup(case, g, opt, HaloComm(g, rank + 1))
+        d = _setup(case, g, opt, HaloComm(g, rank + 1), dev)
         dt0 = update_dt(d, opt)                       # co_min over the tiles == the global CFL step
         n = step(d, NSTEPS * dt0 * 0.999, opt, diagnostics=False)
         names = _names(adv)
@@ -95,7 +108,7 @@ def _worker(rank, world, port, adv, q):
         ref = None
         if rank == 0:                                 # the same steps on ONE tile covering the whole domain
             g1 = grid_t().set_grid_dimensions(NXG, NYG, NZ, 1, 1)
-            d1 = _setup(case, g1, opt, None)
+            d1 = _setup(case, g1, opt, None, dev)
             dt1 = update_dt(d1, opt)                   # no communicator: this image alone
             n1 = step(d1, NSTEPS * dt1 * 0.999, opt, diagnostics=False)
             ref = {k: d1.get(k) for k in names}; ref["acc"] = d1.get("accumulated_precipitation"); ref["dt"] = dt1; ref["n"] = n1
@@ -140,10 +153,8 @@ def _worker_oracle(rank, world, port, adv, q):
     (1e-5 of the local field scale; the halo planes themselves are copies and must be exact)."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    dev, hgroup = _rendezvous(rank, world)
     try:
-        torch.cuda.set_device(0)
         from icar_amd import ideal
         from icar_amd.grid import grid_t
         from icar_amd.halo import HaloComm
@@ -154,7 +165,7 @@ def _worker_oracle(rank, world, port, adv, q):
         case = ideal.make_case(NXG, NYG, NZ, hill_height=700.0, noise=0.02, n_hydro=1, exact=True)
         opt = _options("mpdata", case)
         g = grid_t().set_grid_dimensions(NXG, NYG, NZ, world, rank + 1)
-        d = _setup(case, g, opt, HaloComm(g, rank + 1))
+        d = _setup(case, g, opt, HaloComm(g, rank + 1), dev)
         dt = 0.8 * ideal.cfl_dt(case)
         def tile_of(a):
             if a.ndim == 3 and a.shape[2] == NXG + 1: return np.ascontiguousarray(a[g.jms - 1:g.jme, :, g.ims - 1:g.ime + 1])
@@ -164,7 +175,7 @@ def _worker_oracle(rank, world, port, adv, q):
         kv = ["water_vapor", "cloud_water", "rain", "snow", "potential_temperature"]            # case keys, advection order
         fids = [F.WATER_VAPOR, F.CLOUD_WATER, F.RAIN, F.SNOW, F.POTENTIAL_TEMPERATURE]
         host = {fid: tile_of(case[n]) for fid, n in zip(fids, kv)}
-        ht = HostTile(g, host); hcomm = HaloComm(g, rank + 1)
+        ht = HostTile(g, host); hcomm = HaloComm(g, rank + 1, group=hgroup)
         from util import assert_fields_close
         for _ in range(3):
             d.halo_send(); d.halo_retrieve()
@@ -194,10 +205,8 @@ def _worker_iw(rank, world, port, adv, q):
     the same exchange, whole tile, bit-for-bit; both the winds form and the dqdt_3d (update) form."""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    dev, hgroup = _rendezvous(rank, world)
     try:
-        torch.cuda.set_device(0)
         from icar_amd import ideal
         from icar_amd.grid import grid_t
         from icar_amd.halo import HaloComm
@@ -211,7 +220,7 @@ def _worker_iw(rank, world, port, adv, q):
         opt = _options("upwind", case)
         opt.physics.windtype = kITERATIVE_WINDS; opt.parameters.wind_iterations = 5
         g = grid_t().set_grid_dimensions(NXG, NYG, NZ, world, rank + 1)
-        d = _setup(case, g, opt, HaloComm(g, rank + 1))
+        d = _setup(case, g, opt, HaloComm(g, rank + 1), dev)
         def cut(a):
             if a.shape[2] == NXG + 1: return np.ascontiguousarray(a[g.jms - 1:g.jme, :, g.ims - 1:g.ime + 1])
             if a.shape[0] == NYG + 1: return np.ascontiguousarray(a[g.jms - 1:g.jme + 1, :, g.ims - 1:g.ime])
@@ -227,7 +236,7 @@ def _worker_iw(rank, world, port, adv, q):
             u_l, v_l = cut(ug), cut(vg)
             orc.make_winds_grid_relative(u_l, v_l, np.zeros((g.jme - g.jms + 1, g.ime - g.ims + 1)), np.ones((g.jme - g.jms + 1, g.ime - g.ims + 1)))   # wind.f90:300/:338, per image
             store = {11: u_l, 12: v_l}
-            tile = HostTile(g, {} if which else store, store if which else None); hc = HaloComm(g, rank + 1)
+            tile = HostTile(g, {} if which else store, store if which else None); hc = HaloComm(g, rank + 1, group=hgroup)
             hc.exchange_uv(tile, 11, 12, which=which)
             w_l = orc.balance_uvw(u_l, v_l, *geo[:4], dxf)
             orc.iterative_winds_correct_w(w_l, geo[3])
