@@ -73,6 +73,39 @@ def test_rccl_self_ring_equals_periodic_wrap_and_device_side_update_dt():
             assert update_dt(a, opt) == want == update_dt(b, opt), strict
         check(L.icar_hip_comm_destroy(a.ctx), "comm_destroy")
         a.close(); b.close()
+        # the whole sub-step loop with the transfer inside it: icar_hip_step_n issues the strips, the pack, the RCCL send / recv group
+        # and the wind setup on the second stream beside the interior microphysics, joins, unpacks, advects.  Image a exchanges its
+        # north / south edges with itself THROUGH RCCL, image b wraps them without transport: every field bit for bit after 4 sub-steps.
+        from icar_amd.time_step import step_n
+        from icar_amd.microphysics import mp_init, mp_var_request
+        from icar_amd.advection import adv_init
+        from icar_amd.constants import kADV_MPDATA, kMP_THOMPSON, ADVECTION_ORDER
+        c2 = ideal.make_case(64, 40, 20, hill_height=900.0, noise=0.02, n_hydro=1)
+        c2["water_vapor"] = (c2["water_vapor"] * np.float32(1.8)).astype(np.float32)
+        opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON
+        opt.parameters.dz_levels = c2["dz_levels"]; opt.parameters.dx = float(c2["dx"])
+        mp_var_request(opt)
+        outs = []
+        for kind in ("rccl", "local"):
+            d = single_image_domain(c2)
+            d.exchange_vars = [n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0]
+            class _Halo: halo = 1
+            d.comm = _Halo()                      # domain_t.halo_send / configure only ask the comm for the halo width
+            if kind == "rccl":
+                check(L.icar_hip_comm_unique_id(uid), "unique_id")
+                check(L.icar_hip_comm_init(d.ctx, 1, 0, uid.raw, (ctypes.c_int * 4)(0, 0, NEIGHBOR_NONE, NEIGHBOR_NONE)), "comm_init rccl")
+            else:
+                check(L.icar_hip_comm_init(d.ctx, 1, 0, None, (ctypes.c_int * 4)(NEIGHBOR_SELF, NEIGHBOR_SELF, NEIGHBOR_NONE, NEIGHBOR_NONE)), "comm_init local")
+            mp_init(opt, d); adv_init(d, opt)
+            step_n(d, 4, opt)
+            outs.append({n: d.get(n) for n in ("water_vapor", "cloud_water_mass", "rain_mass", "snow_mass", "potential_temperature", "cloud_ice_mass",
+                                               "graupel_mass", "cloud_ice_number", "rain_number", "accumulated_precipitation")})
+            d.close()
+        for n in outs[0]:
+            assert np.array_equal(outs[0][n], outs[1][n]), n
+        assert float(outs[0]["cloud_water_mass"].max()) > 1e-6
+        x = outs[0]["water_vapor"]
+        assert np.array_equal(x[0], x[0]) and not np.array_equal(x[1], c2["water_vapor"][1])
         print("RCCL_COMM_OK")
     """) % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
