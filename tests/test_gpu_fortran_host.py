@@ -11,6 +11,11 @@ from icar_amd import ideal
 from icar_amd import build as b
 
 pytestmark = pytest.mark.gpu
+# MPDATA + mp_simple, three steps WITHOUT re-synchronising the oracle (mp_simple is bit-identical on equal inputs; MPDATA's 1-ulp
+# reciprocals leave ~2e-7 per step, which the saturation adjustment amplifies, tests/test_oracle_trajectory_sensitivity.py):
+# (fraction of cells beyond 1e-5 of the field maximum, max |d| / max, relative difference of the precipitation sum); measured on
+# MI355X: 7.8e-4 / 7.3e-3 / 1.9e-4 (profiles/r03_parity.json, fortran_host); bounds = 2x (round 2 allowed 5e-2 / 0.1 / 5e-2)
+FH_BOUND = (1.6e-3, 1.5e-2, 4e-4)
 
 
 @pytest.mark.parametrize("scheme", [1, 2])
@@ -56,13 +61,17 @@ def test_fortran_host_matches_oracle(oracle, tmp_path, scheme):
             # those cells differ by the converted amount (and so do the hydrometeors there, which are not compared); the
             # bulk of qv / theta stays within the advection tolerance.  The per-step MPDATA bound is test_gpu_advect.py's.
             rel = np.abs(got.astype(np.float64) - s[n]) / max(float(np.abs(s[n]).max()), 1e-30)
-            assert (rel > 1e-5).mean() < 5e-2 and rel.max() < 0.1, f"{n}: {(rel > 1e-5).mean():.2e} of the cells beyond 1e-5, max {rel.max():.2e}"
+            from util import parity_record
+            parity_record("fortran_host", "mpdata+mp_simple, 3 un-resynchronised steps", {n: {"beyond_1e-5_of_max_frac": float((rel > 1e-5).mean()), "max_abs_over_max": float(rel.max())}})
+            print(f"[fortran host, scheme 2] {n}: {(rel > 1e-5).mean():.3e} of the cells beyond 1e-5 of the maximum, max {rel.max():.3e}")
+            assert (rel > 1e-5).mean() < FH_BOUND[0] and rel.max() < FH_BOUND[1], f"{n}: {(rel > 1e-5).mean():.2e} of the cells beyond 1e-5, max {rel.max():.2e}"
     got = np.fromfile(tmp_path / "out_precip.bin", np.float64).reshape(ny, nx)
     assert acc.max() > 0
     if scheme == 1:
         assert np.array_equal(got, acc)
     else:
-        assert abs(got.sum() - acc.sum()) <= 5e-2 * acc.sum()
+        print(f"[fortran host, scheme 2] precipitation sum: relative difference {abs(got.sum() - acc.sum()) / acc.sum():.3e}")
+        assert abs(got.sum() - acc.sum()) <= FH_BOUND[2] * acc.sum()
 
 
 def test_fortran_step_loop_matches_python_step(tmp_path):
