@@ -252,7 +252,7 @@ static bool cfl_prefetched(icar_hip_ctx *c, float dx, const float *dz_levels)
 
 int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, float *out, float *d_out)
 {
-    if (cfl_prefetched(c, dx, dz_levels)) {
+    if (cfl_prefetched(c, dx, dz_levels) && !c->cfl_pre.reduced) {      // (a value already reduced over the images is not this tile's)
         c->cfl_pre.valid = false;
         if (out) { HIPCHK(hipEventSynchronize(c->cfl_ev)); *out = *c->h_cfl_pre; }
         else {
@@ -283,13 +283,29 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
     return 0;
 }
 
-int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels)
+// the prefetched maximum, if it is still valid AND was already reduced over the images on the device (allreduce = true below):
+// consumes it; the host waits for the second stream's copy only
+bool icar_cfl_prefetched_global(icar_hip_ctx *c, float dx, const float *dz_levels, float *value)
+{
+    if (!cfl_prefetched(c, dx, dz_levels) || !c->cfl_pre.reduced) return false;
+    c->cfl_pre.valid = false;
+    if (hipEventSynchronize(c->cfl_ev) != hipSuccess) return false;
+    *value = *c->h_cfl_pre;
+    return true;
+}
+
+// allreduce: with the RCCL transport the tile maximum is all-reduced (MAX) over the images right here, on the current (second)
+// stream in the advection's shadow, so that the next update_dt finds the GLOBAL maximum waiting instead of paying an
+// all-reduce + two copies on the critical path.  Every image takes the same decisions (SPMD), so the collective calls pair.
+int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels, bool allreduce)
 {
     c->cfl_pre.valid = false;
     if (!c->h_cfl_pre) { HIPCHK(hipHostMalloc((void **)&c->h_cfl_pre, sizeof(float), hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&c->cfl_ev, hipEventDisableTiming)); }
     if (icar_max_courant_run(c, dx, dz_levels, nullptr, c->d_red + 8)) return 1;             // on the current stream, nothing waits
+    if (allreduce && icar_comm_max_device(c, c->d_red + 8) != 0) return 1;
     HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
+    c->cfl_pre.reduced = allreduce;
     c->cfl_pre.valid = true; c->cfl_pre.ver = c->wind_version; c->cfl_pre.dx = dx; c->cfl_pre.dzl.assign(dz_levels, dz_levels + c->d.nz);
     return 0;
 }
@@ -625,7 +641,7 @@ int icar_hip_max_courant_prefetch(icar_hip_ctx *c, float dx, const float *dz_lev
     if (!c || !dz_levels) { icar_set_error("max_courant_prefetch: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     if (c->d.nz > 4096) { icar_set_error("max_courant_prefetch: nz too large"); return 1; }
-    return icar_max_courant_prefetch_run(c, dx, dz_levels);
+    return icar_max_courant_prefetch_run(c, dx, dz_levels, false);
 }
 
 int icar_hip_diagnostic_update(icar_hip_ctx *c)

@@ -62,7 +62,7 @@ struct icar_hip_ctx {
     // field bumps the version; a raw device pointer to one of them handed out (icar_hip_field_device_ptr) disables the cache
     unsigned long long wind_version = 0;
     bool wind_ptr_escaped = false;
-    struct { bool valid = false; unsigned long long ver = 0; float dx = 0.f; std::vector<float> dzl; } cfl_pre;
+    struct { bool valid = false, reduced = false; unsigned long long ver = 0; float dx = 0.f; std::vector<float> dzl; } cfl_pre;
     float *h_cfl_pre = nullptr;          // pinned host copy of the prefetched maximum (d_red[8] on the device)
     hipEvent_t cfl_ev = nullptr;
     float *iw_adj = nullptr;             // iterative_winds ADJ scratch (iterative_winds.hip)
@@ -119,7 +119,8 @@ int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0,
 int icar_diagnostic_update_run(icar_hip_ctx *c, int parts);
 int icar_thompson_math_probe_run(icar_hip_ctx *c, int op, int n, const double *x, const double *y, double *out);
 int icar_thompson_dec_index_run(icar_hip_ctx *c, const float *rf, const double *rd, int n, int n2, int which, int *out);
-int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels);
+int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels, bool allreduce);
+bool icar_cfl_prefetched_global(icar_hip_ctx *c, float dx, const float *dz_levels, float *value);
 inline void icar_winds_changed(icar_hip_ctx *c) { c->winds_valid = false; ++c->wind_version; }   // u, v, w (or density / jacobians) rewritten
 int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);
 int icar_enforce_limits_run(icar_hip_ctx *c, const int *fields, int n);

@@ -125,6 +125,8 @@ static int compute_dt(icar_hip_ctx *c, float *dt_out, bool *on_device)
         // until it has been reduced over the images (dt = factor / max is monotone: min dt == factor / max, bit for bit)
         float *d_val = c->d_red + 12;
         if ((strict == 3 || strict == 4) && c->comm && icar_hip_comm_kind(c) == ICAR_COMM_RCCL) {
+            // the last sub-step has usually left the GLOBAL maximum behind (reduced over the images beside its advection)
+            if (icar_cfl_prefetched_global(c, g.dx, dzl, &maxwind3d)) { *on_device = true; goto have_max; }
             if (icar_max_courant_run(c, g.dx, dzl, nullptr, d_val)) return 1;
             if (icar_comm_max_device(c, d_val) != 0) return 1;
             if (!c->step.h_val) HIPCHK(hipHostMalloc((void **)&c->step.h_val, sizeof(float), hipHostMallocDefault));
@@ -133,6 +135,7 @@ static int compute_dt(icar_hip_ctx *c, float *dt_out, bool *on_device)
             maxwind3d = *c->step.h_val;
             *on_device = true;
         } else if (icar_max_courant_run(c, g.dx, dzl, &maxwind3d, nullptr)) return 1;
+    have_max:
         if (strict == 2) {                                                                                     // :291-300
             maxwind3d = maxwind3d * 0.577350269f;
             maxwind1d = fmaxf(fmaxf(mu, mv), mw);
@@ -227,7 +230,8 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
             if (aux.begin()) return 1;
             if (wreal_later && icar_diagnostic_update_run(c, 2)) return 1;        // :165-194, from the winds of this step (before their forcing)
             if (na && icar_apply_forcing_run(c, dt, aside_f, aside_b, na, g.west_boundary, g.east_boundary, g.south_boundary, g.north_boundary)) return 1;
-            if (cfl_ahead && icar_max_courant_prefetch_run(c, g.dx, c->step.dz_levels.data())) return 1;
+            // (with RCCL the tile maximum is also all-reduced over the images here, in the advection's shadow)
+            if (cfl_ahead && icar_max_courant_prefetch_run(c, g.dx, c->step.dz_levels.data(), c->comm && icar_hip_comm_kind(c) == ICAR_COMM_RCCL)) return 1;
         }
         if (icar_hip_aux_join(c)) return 1;
     }
