@@ -310,7 +310,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     red_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:           # under a launcher even one rank joins the process group (and gets the RCCL communicator)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             if torch.cuda.device_count() < world:
@@ -320,6 +320,7 @@ def main():
         else:
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
+    in_group = dist.is_initialized()
 
     from icar_amd import capi
     d, opt, case, g = build_tile(args, rank, world, dev_index)
@@ -412,7 +413,7 @@ def main():
                                    f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
                        "global_grid": [g.nx_global, g.ny_global, args.nz],
                        "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",
-                       "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
+                       "backend": ("rccl" if backend == "nccl" else backend) if in_group else "none",
                        "halo": "one ncclSend/ncclRecv group per step issued by the library (icar_hip_halo_send), strips+pack on the main stream, interior mp on the second stream" if world > 1
                                else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips on the main stream, interior mp on the second stream",
                        "dt_s": dt, "mp_active_column_fraction": active},
@@ -440,7 +441,7 @@ def main():
                 out["cpu_reference"] = r
         print(json.dumps(out), flush=True)
     d.close()
-    if world > 1:
+    if in_group:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -71,7 +71,9 @@ class HaloComm:
         from .capi import lib, check, NEIGHBOR_NONE, NEIGHBOR_SELF
         nb = [self.peers[d] if d in self.peers else (NEIGHBOR_SELF if d in self.loop else NEIGHBOR_NONE) for d in (0, 1, 2, 3)]
         arr = (ctypes.c_int * 4)(*nb)
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        # a process group of ONE rank over "nccl" still gets the RCCL communicator (the same ncclCommInitRank / ncclAllReduce an
+        # N-rank run makes: tests/test_gpu_bench_ranks.py runs bench.py that way on the one-GPU box)
+        multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or dist.get_backend(self.group) == "nccl")
         if not multi:
             if self.peers:
                 raise RuntimeError("HaloComm: neighbouring images but no torch.distributed process group")

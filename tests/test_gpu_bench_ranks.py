@@ -64,3 +64,21 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ); env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_under_the_launcher_with_one_rank_initialises_rccl():
+    """The driver's N > 1 launch line with N = 1 (all the one-GPU box allows): torch.distributed.run -> the nccl process group ->
+    HaloComm.attach broadcasts the unique id and calls icar_hip_comm_init (ncclCommInitRank) -> update_dt all-reduces the CFL
+    maximum over RCCL on the device.  The same code path as 8 ranks, minus the peers."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _line(r)
+    assert out["n_gpus"] == 1 and out["config"]["backend"] == "rccl" and out["value"] > 0
