@@ -5,7 +5,8 @@
  *   W3_FN                    function qualifiers (static inline / __device__ __forceinline__)
  *   W3_EXP W3_LOG W3_POW W3_SQRT   REAL(4) exp, log, x**y, sqrt in the arithmetic of its side
  *   W3_MAXK                  largest number of levels
- * Included by icar_amd/csrc/mp_wsm3.hip only (the CPU checker has its own copy, oracle/wsm3_column_oracle.h).
+ * Included by icar_amd/csrc/mp_wsm3.hip only (the CPU checker, oracle/wsm3_oracle.c, is a separate slab-by-slab restatement of the
+ * Fortran and shares no text with this file).
  */
 #ifndef ICAR_WSM3_COLUMN_H
 #define ICAR_WSM3_COLUMN_H

@@ -1,5 +1,5 @@
-"""WSM3 (src/physics/mp_wsm3.f90): the column restatement (icar_amd/csrc/wsm3_column.h compiled as C by
-oracle/wsm3_oracle.c) against the UNMODIFIED reference module compiled into oracle/_ref -- bit for bit:
+"""WSM3 (src/physics/mp_wsm3.f90): the checker's slab-by-slab restatement (oracle/wsm3_oracle.c, written
+from the Fortran, no text shared with the product) against the UNMODIFIED reference module compiled into oracle/_ref -- bit for bit:
   * the 42 constants wsm3init derives (rgmma's 10000-term products, the x**y of the slope limits ...);
   * whole tiles over several calls of wsm3 as mp_driver.f90:554-585 makes them: warm rain, cold rain / cloud ice with snow
     at the surface, a surface that crosses 0 C (rain and snow split), dt > 120 s (two minor loops), noisy vertical motion
