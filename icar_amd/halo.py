@@ -140,22 +140,28 @@ class HaloComm:
     def retrieve(self, tile, field_ids):
         """exchangeable%retrieve: `sync images(neighbors)` == wait for the posted transfers,
         then copy each inbox into the halo planes facing that neighbour."""
-        if self.loop and field_ids:
-            # my north edge is what arrives from the south, etc.
-            _unpack_all(tile, [_OPPOSITE[d] for d in self.loop], self.halo, field_ids, [self._loopbuf[d] for d in self.loop])
-        if not self.peers or not field_ids:
+        if not field_ids:
             return
-        for r in self._reqs:
-            r.wait()
-        self._reqs = []
-        if getattr(self, "_host_sync", False):
-            torch.cuda.current_stream().synchronize()   # r.wait() only blocks torch's stream; unpack runs on the context's
-        if self._stage:
-            for d in self.peers:
-                self._recv[d].copy_(self._hrecv[d])
-            torch.cuda.synchronize()                    # the copies ran on torch's stream, unpack runs on the context's
-        _unpack_all(tile, list(self.peers), self.halo, field_ids, [self._recv[d] for d in self.peers])
-
+        # ONE unpack for everything that arrived -- wrapped edges (my north edge is what arrives from the south, etc.) and the
+        # peers' messages -- so that the corner cells follow the reference's N, S, E, W retrieve order whatever mix of
+        # wrapping and neighbouring edges a tile has (exchangeable_obj.f90:138-151)
+        dirs, bufs = [], []
+        if self.loop:
+            dirs += [_OPPOSITE[d] for d in self.loop]; bufs += [self._loopbuf[d] for d in self.loop]
+        if self.peers:
+            for r in self._reqs:
+                r.wait()
+            self._reqs = []
+            if getattr(self, "_host_sync", False):
+                torch.cuda.current_stream().synchronize()   # r.wait() only blocks torch's stream; unpack runs on the context's
+            if self._stage:
+                for d in self.peers:
+                    self._recv[d].copy_(self._hrecv[d])
+                torch.cuda.synchronize()                    # the copies ran on torch's stream, unpack runs on the context's
+            dirs += list(self.peers); bufs += [self._recv[d] for d in self.peers]
+        if dirs:
+            order = sorted(range(len(dirs)), key=lambda n: dirs[n])       # N, S, E, W
+            _unpack_all(tile, [dirs[n] for n in order], self.halo, field_ids, [bufs[n] for n in order])
 
     # ---- exchange_u / exchange_v (exchangeable_obj.f90:158-229) -----------------------------------------------
     def exchange_uv(self, tile, u_field, v_field, which=0):
@@ -236,7 +242,7 @@ def co_min(value, group=None, device=None):
     """time_step.f90:413 `call co_min(seconds)`: all-reduce(min) of one REAL(8)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(value)
-    if device is None:                                  # RCCL reduces device memory only
+    if device is None:                                  # RCCL reduces device memory only; callers with a device tile pass its device
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)

@@ -11,5 +11,5 @@ obj = os.path.join(B.LIBDIR, src.replace(".hip", f"_{tag}.o"))
 subprocess.check_call([B.HIPCC] + B.FLAGS + B.PER_FILE_FLAGS.get(src, []) + extra + ["-c", os.path.join(B.CSRC, src), "-o", obj])
 objs = [obj if s == src else os.path.join(B.LIBDIR, s.replace(".hip", ".o")) for s in B.SOURCES]
 lib = os.path.join(B.LIBDIR, f"libicar_hip_{tag}.so")
-subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"])
+subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-ldl", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
 print(lib)
