@@ -116,6 +116,7 @@ int icar_mass_conservative_acceleration(icar_hip_ctx *c, int update);
 int icar_iterative_winds_sweep(icar_hip_ctx *c, float dx, int nsweeps, int update);
 int icar_make_winds_grid_relative(icar_hip_ctx *c, int update);
 int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, float *buf, bool unpack);
+enum { ICAR_DIAG_CELL = 4, ICAR_DIAG_FACE = 8 };     // finer parts of icar_diagnostic_update_run (step.hip), internal
 int icar_diagnostic_update_run(icar_hip_ctx *c, int parts);
 int icar_thompson_math_probe_run(icar_hip_ctx *c, int op, int n, const double *x, const double *y, double *out);
 int icar_thompson_dec_index_run(icar_hip_ctx *c, const float *rf, const double *rd, int n, int n2, int which, int *out);

@@ -14,48 +14,55 @@ __device__ __forceinline__ float exner_function(float pressure)
     return gf_powf(pressure / 100000.0f, Rd / cp);
 }
 
-#define DIAG_BY 8
-__global__ void __launch_bounds__(64 * DIAG_BY)
-k_diag_thermo(Dims d, const float *__restrict__ p, const float *__restrict__ th, float *__restrict__ exner,
-              float *__restrict__ p_i, float *__restrict__ psfc, float *__restrict__ T, float *__restrict__ T_i,
-              float *__restrict__ rho, const float *__restrict__ u, const float *__restrict__ v,
-              float *__restrict__ u_mass, float *__restrict__ v_mass)
+// diagnostic_update's thermodynamics in two launches:
+//   k_diag_cell  exner, temperature, density of every cell (:87-101): one pow per cell, 2 arrays in, 3 out -- what the
+//                microphysics that follows reads (exner) or is read from before the microphysics moves it (th);
+//   k_diag_face  interface pressure / temperature, surface pressure, mass-point winds (:88-108): neighbours of p and of the
+//                T just written, u, v -- nothing the microphysics touches, so the sub-step issues it on the second stream beside
+//                the interior launch (timestep.hip).
+// T(k+-1) read back from memory is the same th * exner the cell kernel stored, so the split changes no result.
+__global__ void __launch_bounds__(256)
+k_diag_cell(size_t n4, size_t n, const float *__restrict__ p, const float *__restrict__ th, float *__restrict__ exner,
+            float *__restrict__ T, float *__restrict__ rho)
 {
-    // the interface values need the temperature of the level below (above, at the surface): each thread evaluates the one
-    // pow of ITS cell and hands T to its k-neighbours through LDS; only the first level of a block's k-chunk (and the
-    // surface level, which looks up) evaluates a second one
-    __shared__ float s_t[DIAG_BY][64];
-    const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * DIAG_BY + threadIdx.y, j = blockIdx.z;
-    const bool in = (i < d.nx && k < d.nz);
-    const int c = in ? d.idx(i, k, j) : 0;
-    float pc = 0.0f, t = 0.0f;
-    if (in) {
-        pc = p[c];
-        const float ex = exner_function(pc);
-        exner[c] = ex;
-        t = th[c] * ex;                                           // :95
-        if (T) T[c] = t;
-        if (rho) rho[c] = pc / (Rd * t);                           // :101
-    }
-    s_t[threadIdx.y][threadIdx.x] = t;
-    __syncthreads();
-    if (!in) return;
-    // interface values (:88-98): level kms extrapolates from kms+1, others average with the level below
-    if (p_i || T_i) {
-        float pn, tn;
-        if (k == 0) {
-            const float p1 = p[c + d.sk];
-            const float t1 = (threadIdx.y + 1 < DIAG_BY && k + 1 < d.nz) ? s_t[threadIdx.y + 1][threadIdx.x] : th[c + d.sk] * exner_function(p1);
-            pn = pc + (pc - p1) / 2; tn = t + (t - t1) / 2;
-            if (psfc) psfc[i + d.nx * j] = pn;
-        } else {
-            const float pm = p[c - d.sk];
-            const float tm = threadIdx.y > 0 ? s_t[threadIdx.y - 1][threadIdx.x] : th[c - d.sk] * exner_function(pm);
-            pn = (pm + pc) / 2; tn = (tm + t) / 2;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n4) {
+        const float4 pc = ((const float4 *)p)[t], tc = ((const float4 *)th)[t];
+        float4 ex, tt, rr;
+        ex.x = exner_function(pc.x); ex.y = exner_function(pc.y); ex.z = exner_function(pc.z); ex.w = exner_function(pc.w);
+        tt.x = tc.x * ex.x; tt.y = tc.y * ex.y; tt.z = tc.z * ex.z; tt.w = tc.w * ex.w;                     // :95
+        rr.x = pc.x / (Rd * tt.x); rr.y = pc.y / (Rd * tt.y); rr.z = pc.z / (Rd * tt.z); rr.w = pc.w / (Rd * tt.w);   // :101
+        ((float4 *)exner)[t] = ex; ((float4 *)T)[t] = tt; ((float4 *)rho)[t] = rr;
+    } else {
+        const size_t c = 4 * n4 + (t - n4);                       // the cells left over when n is not a multiple of 4
+        if (c < n) {
+            const float pc = p[c], ex = exner_function(pc), tt = th[c] * ex;
+            exner[c] = ex; T[c] = tt; rho[c] = pc / (Rd * tt);
         }
-        if (p_i) p_i[c] = pn;
-        if (T_i) T_i[c] = tn;
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_diag_face(Dims d, const float *__restrict__ p, const float *__restrict__ T, float *__restrict__ p_i, float *__restrict__ psfc,
+            float *__restrict__ T_i, const float *__restrict__ u, const float *__restrict__ v,
+            float *__restrict__ u_mass, float *__restrict__ v_mass)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
+    if (i >= d.nx || k >= d.nz) return;
+    const int c = d.idx(i, k, j);
+    // interface values (:88-98): level kms extrapolates from kms+1, the others average with the level below
+    const float pc = p[c], t = T[c];
+    float pn, tn;
+    if (k == 0) {
+        const float p1 = p[c + d.sk], t1 = T[c + d.sk];
+        pn = pc + (pc - p1) / 2; tn = t + (t - t1) / 2;
+        psfc[i + d.nx * j] = pn;
+    } else {
+        const float pm = p[c - d.sk], tm = T[c - d.sk];
+        pn = (pm + pc) / 2; tn = (tm + t) / 2;
+    }
+    p_i[c] = pn;
+    T_i[c] = tn;
     if (u_mass) { const int cu = i + (d.nx + 1) * (k + d.nz * j); u_mass[c] = (u[cu + 1] + u[cu]) / 2; }   // :105
     if (v_mass) v_mass[c] = (v[c + d.sj] + v[c]) / 2;                                                       // :108
 }
@@ -180,26 +187,37 @@ k_enforce_limits(size_t n, LimitArgs a)
 }
 }  // namespace
 
-// parts: 1 = thermodynamics, mass-point winds, column integrals (:60-144) ; 2 = w_real (:165-194) ; 3 = all of diagnostic_update
+// parts: 1 = thermodynamics, mass-point winds, column integrals (:60-144) ; 2 = w_real (:165-194) ; 3 = all of diagnostic_update.
+// The sub-step splits 1 further: ICAR_DIAG_CELL (exner, T, density + the column integrals when they are on the device) before
+// the microphysics, ICAR_DIAG_FACE (interface values, mass-point winds) beside it; 1 = both.  With column integrals on the
+// device (they read the face kernel's outputs AND the water species) everything runs at ICAR_DIAG_CELL and _FACE is empty.
 int icar_diagnostic_update_run(icar_hip_ctx *c, int parts)
 {
     const float *u = (const float *)c->field[ICAR_F_U], *v = (const float *)c->field[ICAR_F_V];
-    if (parts & 1) {
+    if (parts & 1) parts |= ICAR_DIAG_CELL | ICAR_DIAG_FACE;
+    if (parts & (ICAR_DIAG_CELL | ICAR_DIAG_FACE)) {
     const float *p = icar_field_f(c, ICAR_F_PRESSURE), *th = icar_field_f(c, ICAR_F_POTENTIAL_TEMPERATURE);
     if (!p || !th) return 1;
-    icar_winds_changed(c);                                       // density is rewritten: Courant winds (advect_density) are stale
     float *ex = icar_field_f(c, ICAR_F_EXNER, false), *pi = icar_field_f(c, ICAR_F_PRESSURE_INTERFACE, false);
     float *ps = icar_field_f(c, ICAR_F_SURFACE_PRESSURE, false), *T = icar_field_f(c, ICAR_F_TEMPERATURE, false);
     float *Ti = icar_field_f(c, ICAR_F_TEMPERATURE_INTERFACE, false), *rho = icar_field_f(c, ICAR_F_DENSITY, false);
     if (!ex || !pi || !ps || !T || !Ti || !rho) return 1;
     float *um = u ? icar_field_f(c, ICAR_F_U_MASS, false) : nullptr, *vm = v ? icar_field_f(c, ICAR_F_V_MASS, false) : nullptr;
-    ScopedTimer t(c, "diag");
-    dim3 g((c->d.nx + 63) / 64, (c->d.nz + DIAG_BY - 1) / DIAG_BY, c->d.ny), b(64, DIAG_BY);
-    hipLaunchKernelGGL(k_diag_thermo, g, b, 0, c->stream, c->d, p, th, ex, pi, ps, T, Ti, rho, u, v, um, vm);
     ColumnArgs ca;
     ca.ivt = (float *)c->field[ICAR_F_IVT]; ca.iwv = (float *)c->field[ICAR_F_IWV];
     ca.iwl = (float *)c->field[ICAR_F_IWL]; ca.iwi = (float *)c->field[ICAR_F_IWI];
-    if (ca.ivt || ca.iwv || ca.iwl || ca.iwi) {
+    const bool columns = ca.ivt || ca.iwv || ca.iwl || ca.iwi;
+    ScopedTimer t(c, "diag");
+    if (parts & ICAR_DIAG_CELL) {
+        icar_winds_changed(c);                                   // density is rewritten: Courant winds (advect_density) are stale
+        const size_t n4 = c->n3 / 4, rest = c->n3 - 4 * n4, nthr = n4 + rest;
+        hipLaunchKernelGGL(k_diag_cell, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, n4, c->n3, p, th, ex, T, rho);
+    }
+    if (columns ? (parts & ICAR_DIAG_CELL) : (parts & ICAR_DIAG_FACE)) {          // (with column integrals: at the CELL call)
+        dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
+        hipLaunchKernelGGL(k_diag_face, g, b, 0, c->stream, c->d, p, T, pi, ps, Ti, u, v, um, vm);
+    }
+    if (columns && (parts & ICAR_DIAG_CELL)) {
         ca.qv = (const float *)c->field[ICAR_F_WATER_VAPOR]; ca.um = um; ca.vm = vm; ca.p_i = pi;
         ca.liq[0] = (const float *)c->field[ICAR_F_CLOUD_WATER]; ca.liq[1] = (const float *)c->field[ICAR_F_RAIN];
         ca.ice[0] = (const float *)c->field[ICAR_F_CLOUD_ICE]; ca.ice[1] = (const float *)c->field[ICAR_F_SNOW];

@@ -176,10 +176,13 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
     const float dtf = (float)dt;
     const bool adv = (g.advection == ICAR_ADV_UPWIND || g.advection == ICAR_ADV_MPDATA);
     const bool stepping = dt > 1e-3;                                              // :483
-    bool wreal_later = false;
+    bool wreal_later = false, face_later = false;
     if (g.diagnostics) {                                                          // :474
         if (g.microphysics != kMP_WSM3) {                                         // WSM3 reads w_real
-            if (icar_diagnostic_update_run(c, 1)) return 1;
+            // exner / T / density now; the interface values and mass-point winds (nothing the microphysics reads or writes)
+            // beside the interior launch below
+            face_later = stepping && g.microphysics != 0;
+            if (icar_diagnostic_update_run(c, face_later ? ICAR_DIAG_CELL : 1)) return 1;
             if (stepping) wreal_later = true;                                     // beside the advection, below
             else if (icar_diagnostic_update_run(c, 2)) return 1;
         } else if (icar_diagnostic_update_run(c, 3)) return 1;
@@ -198,6 +201,7 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
             if (aux.begin()) return 1;
             if (icar_mp_run(c, dt, 1, -1)) return 1;                              // :512 strips (the halo pass leaves last_model_time alone, :711)
             if (halo_send(c)) return 1;                                           // :515 pack + RCCL send / recv
+            if (face_later && icar_diagnostic_update_run(c, ICAR_DIAG_FACE)) return 1;
             // the Courant winds (and MPDATA coefficients) read u, v, w, density and the jacobians, none of which the microphysics
             // touches: streaming kernels beside the VALU-bound interior launch
             if (adv && setup_winds(c, dtf)) return 1;
