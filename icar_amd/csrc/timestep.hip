@@ -196,6 +196,13 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
         // that follows -- goes to the second stream and has finished long before the join.  (Rounds 1-2 had it the other way
         // round: every edge of the critical path was then a cross-stream event, ~20 us each on this runtime.)
         if (icar_hip_aux_fork(c)) return 1;
+        // The interior launch is ISSUED first: on a small tile the host's launch rate is the limit, and the ~8 launches of the side
+        // work in front of it delayed the critical kernel by ~0.1 ms.  mp(halo=1) must still see the clock state it sees in the
+        // reference's order (it runs before the interior pass moves last_model_time, :711-713), so that state is put back for it.
+        const double mp_last_before = c->step.mp_last_model_time;
+        if (icar_mp_run(c, dt, -1, 1)) return 1;                                  // :523 interior
+        const double mp_last_after = c->step.mp_last_model_time;
+        c->step.mp_last_model_time = mp_last_before;
         {
             AuxScope aux(c);
             if (aux.begin()) return 1;
@@ -206,7 +213,7 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
             // touches: streaming kernels beside the VALU-bound interior launch
             if (adv && setup_winds(c, dtf)) return 1;
         }
-        if (icar_mp_run(c, dt, -1, 1)) return 1;                                  // :523 interior
+        c->step.mp_last_model_time = mp_last_after;
         if (icar_hip_aux_join(c)) return 1;
         if (halo_retrieve(c)) return 1;                                           // :526
     } else {
@@ -214,7 +221,10 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
         if (halo_retrieve(c)) return 1;
     }
 
-    // :529-534  advect, with the whole-field forcing that does not depend on it (and the next CFL reduction) beside it
+    // :529-534  advect, with the whole-field forcing that does not depend on it (and the next CFL reduction) beside it.
+    // (Measured alternative: w_real, the forcing of u, v, w and the CFL reduction beside the interior microphysics instead.  The
+    // advection alone takes 1.02 ms instead of 1.12 with them in its shadow, but its persistent blocks leave them unused register
+    // slots, while beside Thompson every streaming wave displaces a compute wave: 3.20 instead of 3.08 ms per step.)
     int aside_f[16], aside_b[16], na = 0, rest_f[16], rest_b[16], nr = 0;
     for (int m = 0; m < g.n_forced; ++m) {
         const int f = g.forced_fields[m];
