@@ -325,6 +325,7 @@ def main():
     from icar_amd import capi
     d, opt, case, g = build_tile(args, rank, world, dev_index)
     lib = capi.lib()
+    kind = int(lib.icar_hip_comm_kind(d.ctx))
     nscal = sum(1 for v in opt.vars_to_advect.values() if v > 0)
 
     def barrier():
@@ -413,9 +414,12 @@ def main():
                                    f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
                        "global_grid": [g.nx_global, g.ny_global, args.nz],
                        "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",
-                       "backend": ("rccl" if backend == "nccl" else backend) if in_group else "none",
-                       "halo": "one ncclSend/ncclRecv group per step issued by the library (icar_hip_halo_send), strips+pack on the main stream, interior mp on the second stream" if world > 1
-                               else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips on the main stream, interior mp on the second stream",
+                       # the transport the library actually opened (icar_hip_comm_kind), not the one asked for
+                       "backend": {capi.COMM_RCCL: "rccl", capi.COMM_HOST: "host-staged (functional path, not a performance number)"}.get(kind, "none") if in_group else "none",
+                       **({"transport_note": d.comm.transport_note} if getattr(d.comm, "transport_note", None) else {}),
+                       "halo": ("one ncclSend/ncclRecv group per step issued by the library (icar_hip_halo_send)" if kind == capi.COMM_RCCL else
+                                "one message per neighbour through pinned host memory (icar_hip_comm_init_host)") + ", strips+pack on the second stream beside the interior mp" if world > 1
+                               else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips+pack on the second stream beside the interior mp",
                        "dt_s": dt, "mp_active_column_fraction": active},
             "roofline": {"bound": "hbm", "kernel": f"advect ({ADVECT_KERNELS[args.adv]})",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

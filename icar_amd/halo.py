@@ -63,6 +63,7 @@ class HaloComm:
         self._reqs = []
         self._nf = None
         self._stage = False
+        self.transport_note = None
 
     def attach(self, domain):
         """Initialise the library's communicator of a device tile (icar_hip_comm_init / _init_host): collective over the
@@ -80,20 +81,40 @@ class HaloComm:
             check(lib().icar_hip_comm_init(domain.ctx, 1, 0, None, arr), "icar_hip_comm_init")
             return
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        self.transport_note = None
         if dist.get_backend(self.group) == "nccl":
+            # RCCL.  Every image must end up with the SAME transport, so the outcome of the initialisation is agreed on over the
+            # launcher's own process group; if any image could not open its communicator (no librccl, a refused device ...) all of
+            # them fall back to the host-staged transport and say so (bench.py prints it: a degraded run, not a silent one).
             uid = ctypes.create_string_buffer(128)
-            if rank == 0:
-                check(lib().icar_hip_comm_unique_id(uid), "icar_hip_comm_unique_id")
+            err = None
+            try:
+                if rank == 0:
+                    check(lib().icar_hip_comm_unique_id(uid), "icar_hip_comm_unique_id")
+            except RuntimeError as e:
+                err = str(e)
             t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).to(f"cuda:{domain.device}")
             dist.broadcast(t, 0, group=self.group)                      # co_broadcast(uid, 1) in a coarray host
-            check(lib().icar_hip_comm_init(domain.ctx, world, rank, bytes(t.cpu().numpy().tobytes()), arr), "icar_hip_comm_init")
-        else:
-            import os
-            name = [f"icar_hip_{os.getpid()}_{id(self) & 0xffffff:x}" if rank == 0 else None]
-            dist.broadcast_object_list(name, 0, group=self.group)
-            need = torch.tensor([max(domain.halo_count(d, self.halo) for d in (0, 1, 2, 3)) * 4 * 11], dtype=torch.int64)
-            dist.all_reduce(need, op=dist.ReduceOp.MAX, group=self.group)
-            check(lib().icar_hip_comm_init_host(domain.ctx, world, rank, name[0].encode(), int(need.item()), arr), "icar_hip_comm_init_host")
+            if err is None and bool(t.any().item()):
+                try:
+                    check(lib().icar_hip_comm_init(domain.ctx, world, rank, bytes(t.cpu().numpy().tobytes()), arr), "icar_hip_comm_init")
+                except RuntimeError as e:
+                    err = str(e)
+            elif err is None:
+                err = "image 1 could not make an RCCL unique id"
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=f"cuda:{domain.device}")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 1:
+                return
+            lib().icar_hip_comm_destroy(domain.ctx)
+            self.transport_note = "RCCL communicator not available on every image (%s): host-staged transport" % (err or "another image failed")
+        import os
+        name = [f"icar_hip_{os.getpid()}_{id(self) & 0xffffff:x}" if rank == 0 else None]
+        dist.broadcast_object_list(name, 0, group=self.group)
+        dev = f"cuda:{domain.device}" if dist.get_backend(self.group) == "nccl" else "cpu"
+        need = torch.tensor([max(domain.halo_count(d, self.halo) for d in (0, 1, 2, 3)) * 4 * 11], dtype=torch.int64, device=dev)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX, group=self.group)
+        check(lib().icar_hip_comm_init_host(domain.ctx, world, rank, name[0].encode(), int(need.item()), arr), "icar_hip_comm_init_host")
 
     def _buffers(self, tile, nfields):
         if self._nf != nfields:

@@ -32,7 +32,7 @@ def test_bench_gpus_n_spawns_n_ranks_on_the_fixed_global_grid(n, decomp):
     r = _run(["--gpus", str(n)] + SMALL, {"ICAR_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
     out = _line(r)
-    assert out["n_gpus"] == n and out["config"]["decomposition"] == decomp and out["config"]["backend"] == "gloo"
+    assert out["n_gpus"] == n and out["config"]["decomposition"] == decomp and out["config"]["backend"].startswith("host-staged")
     assert out["scaling"] == "strong" and out["config"]["global_grid"] == [64, 48, 12]
     # value = cells all ranks own (the interior of the GLOBAL grid, whatever N) x steps / time
     cells = out["value"] * out["ms_per_step"] * 1e-3
@@ -82,3 +82,20 @@ def test_bench_under_the_launcher_with_one_rank_initialises_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     out = _line(r)
     assert out["n_gpus"] == 1 and out["config"]["backend"] == "rccl" and out["value"] > 0
+
+
+def test_bench_falls_back_to_the_host_transport_when_rccl_init_fails():
+    """An image whose ncclCommInitRank fails must not leave the others in a different transport: the outcome is agreed on over the
+    launcher's process group, every image drops its communicator, all open the host-staged one, and the line says so."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_rccl_fallback_child.py"), "--gpus", "1"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _line(r)
+    assert out["config"]["backend"].startswith("host-staged") and "simulated" in out["config"]["transport_note"] and out["value"] > 0
