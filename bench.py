@@ -261,6 +261,42 @@ def cpu_baseline(args, nscalars):
                       f"oracle/*.c CPU restatement (bit-identical to the reference kernels) with OpenMP on {orc.num_threads()} threads, {el:.1f} s"}
 
 
+
+def probe_traffic(args):
+    """HBM bytes one advect() call moves, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one
+    pass, MI355X_MICROARCH.md) over a 3-step child run of this same configuration, counters only (--kernel-trace + --pmc, no
+    other trace domain).  FETCH_SIZE is doubled (gfx950's rocprofv3 counts 128-B requests as 64 B).  Returns
+    (bytes, read, write) or None when rocprofv3 is missing, times out or finds no dispatch of the kernel."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-traffic-probe",
+             "--nx", str(args.nx), "--ny", str(args.ny), "--nz", str(args.nz), "--adv", args.adv, "--mp", args.mp, "--hill", str(args.hill)]
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="icar_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
+                           cwd="/tmp", env=env, timeout=180, capture_output=True)
+            vals = []
+            for fn in glob.glob(os.path.join(out, "**", "p_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(fn)):
+                    if ADVECT_KERNELS[args.adv] in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            got[ctr] = sum(vals) / len(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    rd, wr = 2.0 * 1024.0 * got["FETCH_SIZE"], 1024.0 * got["WRITE_SIZE"]          # KiB units; x2: see above
+    return rd + wr, rd, wr
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU, RCCL) under
     torch.distributed.run on 127.0.0.1 and pass rank 0's JSON line through."""
@@ -287,6 +323,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong (default): the nx x ny x nz grid is global and split over the GPUs; weak: it is the tile of every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic-probe", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--ref-child", default=None, help=argparse.SUPPRESS)      # internal: cpu_reference()'s child process
     ap.add_argument("--ref-nscal", type=int, default=9, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -367,7 +404,7 @@ def main():
     # HBM bytes per advect() call from the PMC passes (profiles/run_profiles.sh: FETCH_SIZE x2 + WRITE_SIZE, separate
     # runs of this same command): counters cannot be read inside this process, so the figure is attached only when it was
     # taken on THIS configuration and THIS kernel generation; otherwise null.
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "advect_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -376,6 +413,7 @@ def main():
                     "generation": KERNEL_GENERATION}
             if tj.get("config") == want:
                 traffic = tj.get("hbm_bytes_per_advect_call")
+                traffic_source = "profiles/advect_traffic.json (PMC passes of an earlier run of this configuration and kernel generation)"
         except Exception:
             traffic = None
 
@@ -423,7 +461,7 @@ def main():
                        "dt_s": dt, "mp_active_column_fraction": active},
             "roofline": {"bound": "hbm", "kernel": f"advect ({ADVECT_KERNELS[args.adv]})",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
                          "mp_ms_per_step": mp_ms_step,
                          # the once-per-step setup of the advection (Courant winds + the scalar-independent MPDATA coefficients),
                          # issued beside the interior microphysics; not part of avg_ms
@@ -438,6 +476,13 @@ def main():
                              "ms_per_step": mp_ms_step,
                              "algorithmic_GBps": (mem_cells * (84 if args.mp == "thompson" else 56) / (mp_ms_step * 1e-3) / 1e9) if mp_ms_step > 0 else 0.0},
         }
+        if world == 1 and not args.no_traffic_probe and not args.no_cpu_baseline:        # (the full line only: profiling scripts pass --no-cpu-baseline)
+            # roofline.traffic measured NOW on this box (counters cannot be read inside this process: two child runs under rocprofv3)
+            t = probe_traffic(args)
+            if t is not None:
+                out["roofline"].update({"traffic": t[0], "traffic_read_bytes": t[1], "traffic_write_bytes": t[2],
+                                        "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x 2 for gfx950) over "
+                                                          "3-step child runs of this configuration, mean per dispatch of " + ADVECT_KERNELS[args.adv]})
         if not args.no_cpu_baseline and world == 1:          # the CPU legs are timed at N=1 only (the other ranks would idle at the barrier)
             out["cpu_baseline"] = cpu_baseline(args, nscal)
             r = cpu_reference(args, d, nscal)
