@@ -247,10 +247,16 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
             // (with RCCL the tile maximum is also all-reduced over the images here, in the advection's shadow)
             if (cfl_ahead && icar_max_courant_prefetch_run(c, g.dx, c->step.dz_levels.data(), c->comm && icar_hip_comm_kind(c) == ICAR_COMM_RCCL)) return 1;
         }
-        if (icar_hip_aux_join(c)) return 1;
     }
+    // the side work touches u, v, w, p, w_real and the CFL scalar; what is left on the main stream touches advected scalars only, so
+    // the join can wait until after it (on a small tile the side chain is as long as the advection: its tail then overlaps the
+    // boundary-ring forcing instead of delaying it).  Any other forced field keeps the join in front.
+    bool scalars_only = true;
+    for (int m = 0; m < nr; ++m) scalars_only = scalars_only && rest_f[m] >= 0 && rest_f[m] < ICAR_N_ADVECTABLE;
+    if (beside && !scalars_only && icar_hip_aux_join(c)) return 1;
     if (nr && icar_apply_forcing_run(c, dt, rest_f, rest_b, nr, g.west_boundary, g.east_boundary, g.south_boundary, g.north_boundary)) return 1;   // :534
     if (enforce && icar_enforce_limits_run(c, g.advect_fields, g.n_advect)) return 1;                                                                // :537-539
+    if (beside && scalars_only && icar_hip_aux_join(c)) return 1;
     return 0;
 }
 
