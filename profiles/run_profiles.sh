@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 RND=${1:-r03}
 O=gpurun_out/$RND; rm -rf $O; mkdir -p $O
-timeout 400 python bench.py > $O/bench_line.json 2> $O/bench.err
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err      # the driver's command
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- $B > $O/trace.log 2>&1
 P="python bench.py --steps 4 --warmup 2 --no-cpu-baseline"
