@@ -56,3 +56,31 @@ def test_device_float_transcendentals_equal_the_hosts_libm(oracle):
         parity_record("glibc_math", "device REAL(4) transcendentals vs the host libm (bit patterns)", stats)
     finally:
         d.close()
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("ICAR_EXHAUSTIVE"), reason="several minutes: set ICAR_EXHAUSTIVE=1 (run once per round, result in profiles/r03_parity.json)")
+def test_device_one_argument_functions_on_every_real4(oracle):
+    """expf, logf, log10f, atanf on the device for ALL 2^32 REAL(4) bit patterns against the host's libm."""
+    d = single_image_domain(ideal.make_case(12, 6, 12))
+    chunk = 1 << 25
+    stats = {}
+    try:
+        out = np.zeros(chunk, np.float64)
+        for op, name in ((4, "expf"), (5, "logf"), (6, "log10f"), (7, "atanf")):
+            differ = 0; first = None
+            for lo in range(0, 1 << 32, chunk):
+                x = np.arange(lo, lo + chunk, dtype=np.uint64).astype(np.uint32).view(np.float32)
+                xd = x.astype(np.float64)
+                check(lib().icar_hip_thompson_math_probe(d.ctx, op, chunk, xd.ctypes.data_as(ctypes.c_void_p), None,
+                                                         out.ctypes.data_as(ctypes.c_void_p)), "math_probe")
+                got, want = out.astype(np.float32), oracle.libm_f(op, x)
+                bad = ~((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))
+                nb = int(bad.sum())
+                if nb and first is None:
+                    first = (hex(int(x[bad][0].view(np.uint32))), float(got[bad][0]), float(want[bad][0]))
+                differ += nb
+            stats[name] = {"n": 1 << 32, "differ": differ, "first": first}
+            assert differ == 0, f"{name}: {differ} of 2^32 differ from libm, first {first}"
+        parity_record("glibc_math_exhaustive", "device expf / logf / log10f / atanf vs the host libm on all 2^32 REAL(4) arguments", stats)
+    finally:
+        d.close()
