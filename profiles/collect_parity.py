@@ -17,7 +17,7 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "parity", "*.jsonl"))
         w = {}
         for st in fields.values():
             for k, v in st.items():
-                if k != "cells":
+                if k != "cells" and isinstance(v, (int, float)):
                     w[k] = max(w.get(k, 0), v)
         summary[lab] = w
     out[name] = {"worst_per_label": summary, "per_field": recs}
