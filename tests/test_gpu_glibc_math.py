@@ -84,3 +84,38 @@ def test_device_one_argument_functions_on_every_real4(oracle):
         parity_record("glibc_math_exhaustive", "device expf / logf / log10f / atanf vs the host libm on all 2^32 REAL(4) arguments", stats)
     finally:
         d.close()
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("ICAR_EXHAUSTIVE"), reason="several minutes: set ICAR_EXHAUSTIVE=1 (run once per round, result in profiles/r03_parity.json)")
+def test_device_powf_on_a_billion_pairs(oracle):
+    """powf (and the level code's shared-base form) on the device for 2^30 pairs against the host's libm: half of them arbitrary bit
+    patterns, half positive bases of every binade with exponents in +-16 (the scheme's use)."""
+    d = single_image_domain(ideal.make_case(12, 6, 12))
+    chunk = 1 << 24
+    rng = np.random.default_rng(77)
+    stats = {"powf": {"n": 0, "differ": 0}, "powf_shared_base": {"n": 0, "differ": 0}}
+    first = None
+    try:
+        out = np.zeros(chunk, np.float64)
+        for it in range(64):
+            if it % 2 == 0:
+                x = rng.integers(0, 2 ** 32, chunk, dtype=np.uint64).astype(np.uint32).view(np.float32)
+                y = rng.integers(0, 2 ** 32, chunk, dtype=np.uint64).astype(np.uint32).view(np.float32)
+            else:
+                x = np.abs(rng.integers(0, 2 ** 32, chunk, dtype=np.uint64).astype(np.uint32).view(np.float32))
+                y = rng.uniform(-16.0, 16.0, chunk).astype(np.float32)
+            want = oracle.libm_f(3, x, y)
+            xd, yd = x.astype(np.float64), y.astype(np.float64)
+            for op, name in ((3, "powf"), (8, "powf_shared_base")):
+                check(lib().icar_hip_thompson_math_probe(d.ctx, op, chunk, xd.ctypes.data_as(ctypes.c_void_p), yd.ctypes.data_as(ctypes.c_void_p),
+                                                         out.ctypes.data_as(ctypes.c_void_p)), "math_probe")
+                got = out.astype(np.float32)
+                bad = ~((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))
+                nb = int(bad.sum())
+                if nb and first is None:
+                    first = (name, float(x[bad][0]), float(y[bad][0]), float(got[bad][0]), float(want[bad][0]))
+                stats[name]["n"] += chunk; stats[name]["differ"] += nb
+        assert stats["powf"]["differ"] == 0 and stats["powf_shared_base"]["differ"] == 0, (stats, first)
+        parity_record("glibc_math_exhaustive", "device powf vs the host libm on 2^30 pairs", stats)
+    finally:
+        d.close()
