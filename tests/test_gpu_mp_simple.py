@@ -236,3 +236,11 @@ def test_mp_update_interval_and_top_mp_level(oracle):
     assert np.array_equal(d.get("water_vapor")[:, top:, :], c["water_vapor"][:, top:, :])       # above top_mp_level nothing happened
     assert not np.array_equal(d.get("water_vapor")[:, :top, :], c["water_vapor"][:, :top, :])
     d.close()
+
+
+def test_mp_simple_full_size_every_column_bit_exact(oracle):
+    """512 x 512 x 40: every cell of two calls, device vs the CPU oracle in the reference's own math, bit for bit"""
+    out, ref = run(oracle, mode=0, nx=512, ny=512, nz=40, steps=2, dt=45.0, moist=1.8, cool=1.0)
+    assert ref["rain_mass"].max() > 1e-5 and ref["cloud_water_mass"].max() > 1e-5
+    for k in ref:
+        assert np.array_equal(out[k], ref[k]), f"{k}: {(out[k] != ref[k]).sum()} cells differ"

@@ -72,3 +72,12 @@ def test_wsm3_bit_exact_vs_reference_math(oracle, case):
         assert acc_s.max() > (0.1 if case == "snow_at_surface" else 0.0)
 
 
+
+
+def test_wsm3_full_size_every_column_bit_exact(oracle):
+    """512 x 512 x 40: every cell of two calls, device vs the checker's slab restatement (oracle/wsm3_oracle.c), bit for bit"""
+    k = dict(nx=512, ny=512, nz=40, steps=2, dt=60.0, moist=1.5, cool0=15.0, cool=1.0, seed=21)
+    got, want, pa, sa, acc_r, acc_s = run(oracle, k, mode=0)
+    for n in want:
+        assert np.array_equal(got[n].view(np.int32), want[n].view(np.int32)), f"{n}: {(got[n] != want[n]).sum()} cells differ"
+    assert np.array_equal(pa, acc_r) and np.array_equal(sa, acc_s) and acc_r.max() > 0

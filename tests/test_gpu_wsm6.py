@@ -142,3 +142,14 @@ def test_wsm6_full_size_budget_and_column_subset_vs_oracle(oracle):
         parity_record("wsm6", "full_size_subset/mode0", {k: field_stats(got, want, 1e-5)})
         assert np.array_equal(got.view(np.int32), want.view(np.int32)), f"{k}: {(got != want).sum()} of {got.size} cells differ"
     assert np.array_equal(precip[jj, ii], rain_acc[1, 1:-1])
+
+
+def test_wsm6_full_size_every_column_bit_exact(oracle):
+    """512 x 512 x 40: every cell of two calls, device vs the CPU oracle in the reference's own math, bit for bit"""
+    k = dict(nx=512, ny=512, nz=40, steps=2, dt=60.0, moist=1.5, cool0=15.0, cool=1.0, seed=22)
+    got, want, dacc, acc = run(oracle, k, mode=0)
+    for n in KEYS:
+        assert np.array_equal(got[n].view(np.int32), want[n].view(np.int32)), f"{n}: {(got[n] != want[n]).sum()} cells differ"
+    for n in acc:
+        assert np.array_equal(dacc[n], acc[n]), n
+    assert acc["rain"].max() > 0 and want["cloud_water"].max() > 1e-5
