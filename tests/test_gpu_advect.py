@@ -253,3 +253,13 @@ def test_mpdata_fct_is_sign_preserving_and_bounded_on_a_sharp_blob(oracle):
             s[m][...] = got                                                # the next step from equal inputs
     assert 0.2 < float(d.get("water_vapor").max()) < 1.1                 # the blob has moved and spread, not vanished
     d.close()
+
+
+def test_config3_whole_domain_1024_every_cell_vs_oracle(oracle):
+    """configs[3]'s whole 1024 x 1024 x 40 domain on one GPU (the largest tile the 32-bit buffer offsets of the fused kernel
+    were sized for: 42 M cells x 11 coefficient arrays = 1.8 GB < 2 GiB): three scalars, one MPDATA step with advect_density,
+    every cell within 1e-5 of the local scale of the CPU oracle, and the upwind scheme bit for bit."""
+    nx = ny = 1024; nz = 40
+    names = ["water_vapor", "potential_temperature", "cloud_water"]
+    assert run_case(oracle, kADV_MPDATA, nx, ny, nz, names, dens=True, nsteps=1) <= 1e-5
+    run_case(oracle, kADV_UPWIND, nx, ny, nz, names[:2], nsteps=1)
