@@ -13,6 +13,6 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1] + "/s/p_counter_collection.csv")):
     k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in ("k_thompson_pack", "k_mpdata_fused", "k_wsm3_fall_tile", "k_wsm3_rates", "k_wsm3_prep"):
+for k in ("k_thompson_pack", "k_mpdata_fused", "k_mp_simple_pack", "k_w6_fall_tile", "k_w6_rates", "k_w6_prep", "k_wsm3_fall_tile", "k_wsm3_rates", "k_wsm3_prep"):
     if k in acc: print(k, {c: f"{sum(v)/len(v):.4g}" for c, v in sorted(acc[k].items())})
 PY

@@ -1,0 +1,58 @@
+"""The CPU restatements of WSM3 / WSM6 (oracle/wsm3_oracle.c, oracle/wsm6_oracle.c) against golden vectors produced by the
+REFERENCE's own compiled modules (tests/golden/make_golden_wsm.py, oracle/_ref): the wsm3init / wsm6init constants, the scalar
+arguments of mp_driver.f90 and the state + surface accumulators after several calls -- bit for bit.  These fixtures pin the
+checkers where /root/reference (and with it oracle/_ref) is absent; tests/test_oracle_wsm3.py / _wsm6.py call the compiled
+reference directly where it is present."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLD)
+import make_golden_wsm as G  # noqa: E402  (the case table and the input recipe; it imports oracle.ref only when it generates)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.int32)
+
+
+@pytest.mark.parametrize("name", list(G.CASES))
+def test_wsm_golden(oracle, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    p = json.loads(str(g["params"]))
+    assert p == G.CASES[name], "fixture made with other parameters: rerun tests/golden/make_golden_wsm.py"
+    nx, ny, nz, dt = p["nx"], p["ny"], p["nz"], p["dt"]
+    c, w, A = G.make_inputs(p)
+    assert G.fingerprint(c, w, A) == float(g["input_fingerprint"]), "icar_amd.ideal drifted: the stored outputs belong to other inputs"
+    a18 = g["args18"].astype(np.float32).copy(); a18[0] = dt
+    z2 = lambda: np.zeros((ny, nx), np.float32)
+    oracle.set_math_mode(0)
+    if p["scheme"] == 3:
+        got = oracle.wsm3_init()
+        for n, want in zip(oracle.WSM3_CONSTS, g["consts"]):
+            assert bits(got[n]) == bits(want), (n, float(got[n]), float(want))
+        acc = [z2() for _ in range(5)]
+        for _ in range(p["steps"]):
+            assert oracle.wsm3(A["potential_temperature"], A["water_vapor"], A["cloud_water"], A["rain"], w, c["density"], c["exner"], c["pressure"],
+                               c["dz_mass"], a18, *acc, 2, nx - 1, 2, ny - 1, 1, nz) == 0
+            A["potential_temperature"] -= np.float32(p["cool"])
+        accs = dict(zip(("rain", "rainncv", "snow", "snowncv", "sr"), acc)); keys = G.K3
+    else:
+        got = oracle.wsm6_init()
+        for n, want in zip(oracle.WSM6_CONSTS, g["consts"]):
+            assert bits(got[n]) == bits(want), (n, float(got[n]), float(want))
+        accs = dict(rain=z2(), sr=z2(), snow=z2(), graupel=z2())
+        for _ in range(p["steps"]):
+            assert oracle.wsm6(A["potential_temperature"], A["water_vapor"], A["cloud_water"], A["rain"], A["cloud_ice"], A["snow"], A["graupel"],
+                               c["density"], c["exner"], c["pressure"], c["dz_mass"], a18, accs["rain"], accs["sr"], accs["snow"], accs["graupel"],
+                               2, nx - 1, 2, ny - 1, 1, nz) == 0
+            A["potential_temperature"] -= np.float32(p["cool"])
+        keys = G.K6
+    for n in keys:
+        assert np.array_equal(bits(A[n]), bits(g[n])), f"{n}: {np.count_nonzero(bits(A[n]) != bits(g[n]))} cells differ"
+    for n, a in accs.items():
+        assert np.array_equal(bits(a), bits(g["acc_" + n])), "acc_" + n
+    assert g["acc_rain"].max() > 1.0 and g["cloud_water"].max() > 1e-5
