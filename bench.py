@@ -280,7 +280,7 @@ def probe_traffic(args):
         out = tempfile.mkdtemp(prefix="icar_pmc_", dir="/tmp")
         try:
             subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
-                           cwd="/tmp", env=env, timeout=180, capture_output=True)
+                           cwd="/tmp", env=env, timeout=90, capture_output=True)      # (a child takes ~12 s; a stuck profiler costs the line 90 s, not the run)
             vals = []
             for fn in glob.glob(os.path.join(out, "**", "p_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(fn)):
