@@ -47,6 +47,9 @@ struct WaveComm {
     __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4])
     { for (int s = 0; s < 4; ++s) sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); }
     __device__ __forceinline__ void up6(const float v[6], float u[6]) { for (int s = 0; s < 6; ++s) u[s] = __shfl_down(v[s], 1); }
+    __device__ __forceinline__ void loop_max4(const int n[4], int out[4]) { for (int s = 0; s < 4; ++s) out[s] = n[s]; }
+    __device__ __forceinline__ void up6_of(const float v[6], float u[6], unsigned slots)
+    { for (int s = 0; s < 6; ++s) if (slots & (1u << s)) u[s] = __shfl_down(v[s], 1); }
 };
 
 // cpb whole columns per block of nt >= cpb*nz threads; thread = level*cpb + column.  LDS (dynamic):
@@ -144,12 +147,20 @@ struct BlockComm {
         __syncthreads();
         return __int_as_float(scolmax[col]);
     }
+    // maximum over a wave first (butterfly): 64 lanes hitting ONE LDS address with an atomic serialise, ~15 cycles each -- a
+    // block-wide atomicMax per thread cost a 240-thread block ~3.6 k cycles per call
+    static __device__ __forceinline__ int wave_max(int v)
+    {
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        return v;
+    }
     __device__ __forceinline__ int loop_max(int n)
     {
         __syncthreads();
         if (tid == 0) *sblkmax = 0;
         __syncthreads();
-        if (active) atomicMax(sblkmax, n);
+        const int w = wave_max(active ? n : 0);
+        if ((tid & 63) == 0) atomicMax(sblkmax, w);
         __syncthreads();
         return *sblkmax;
     }
@@ -200,6 +211,9 @@ struct BlockComm {
     {
         int *cm = shas;                                                           // 8 x (cpb+1) ints, nt >= 8(cpb+1) for nz >= 9
         if (8 * (cpb + 1) > nt) { for (int s = 0; s < 4; ++s) sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); return; }
+        // (measured: these per-thread LDS atomics -- ~10 lanes of a wave per word -- beat both a gather by 8 cpb leader threads
+        // looping over the levels, 1.88 -> 2.03 ms, and a pre-reduction with wave shifts by cpb, 2 cpb, ..., 2.05 ms; only atomics of a
+        // WHOLE wave on one word are worth avoiding, see loop_max)
         __syncthreads();
         if (tid < 8 * (cpb + 1)) cm[tid] = 0;
         __syncthreads();
@@ -221,6 +235,25 @@ struct BlockComm {
         __syncthreads();
         const bool up = active && k + 1 < nz;
         for (int s = 0; s < 6; ++s) u[s] = up ? F(b, s, tid + cpb) : 0.f;
+    }
+    // the block's maxima of four loop counts in one barrier round (the integer area of carry_down2 / sed_plan is free by then)
+    __device__ __forceinline__ void loop_max4(const int n[4], int out[4])
+    {
+        __syncthreads();
+        if (tid < 4) scolmax[tid] = 0;
+        __syncthreads();
+        for (int s = 0; s < 4; ++s) { const int w = wave_max(active ? n[s] : 0); if ((tid & 63) == 0) atomicMax(&scolmax[s], w); }
+        __syncthreads();
+        for (int s = 0; s < 4; ++s) out[s] = scolmax[s];
+    }
+    // up6 restricted to the slots named in `slots` (block-uniform): the others are neither written nor read
+    __device__ __forceinline__ void up6_of(const float v[6], float u[6], unsigned slots)
+    {
+        const int b = (int)((++step) & 1u);
+        for (int s = 0; s < 6; ++s) if (slots & (1u << s)) F(b, s, tid) = v[s];
+        __syncthreads();
+        const bool up = active && k + 1 < nz;
+        for (int s = 0; s < 6; ++s) if (slots & (1u << s)) u[s] = up ? F(b, s, tid + cpb) : 0.f;
     }
 };
 
