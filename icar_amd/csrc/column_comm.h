@@ -44,10 +44,10 @@ struct WaveComm {
     // the same three services for several species at once (BlockComm pays one barrier round for all of them)
     __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1)
     { carry_down2(a0, b0, has0); carry_down2(a1, b1, has1); }
-    __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4])
-    { for (int s = 0; s < 4; ++s) sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); }
+    // nblk[s]: the longest sub-step loop of species s among the columns this communicator spans (here: the one column)
+    __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4], int nblk[4])
+    { for (int s = 0; s < 4; ++s) { sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); nblk[s] = (int)lroundf(1.f / onstep[s]); } }
     __device__ __forceinline__ void up6(const float v[6], float u[6]) { for (int s = 0; s < 6; ++s) u[s] = __shfl_down(v[s], 1); }
-    __device__ __forceinline__ void loop_max4(const int n[4], int out[4]) { for (int s = 0; s < 4; ++s) out[s] = n[s]; }
     __device__ __forceinline__ void up6_of(const float v[6], float u[6], unsigned slots)
     { for (int s = 0; s < 6; ++s) if (slots & (1u << s)) u[s] = __shfl_down(v[s], 1); }
 };
@@ -207,10 +207,15 @@ struct BlockComm {
         step = 0;
     }
     // four sedimentation plans in one exchange: per-column max level with a sedimenting particle and max sub-step count
-    __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4])
+    // nblk[s]: the block's longest sub-step loop of species s = the maximum over its columns of what nstep will be (max(ns, 1)),
+    // read from the per-column maxima that are in LDS anyway -- no reduction round of its own
+    __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4], int nblk[4])
     {
         int *cm = shas;                                                           // 8 x (cpb+1) ints, nt >= 8(cpb+1) for nz >= 9
-        if (8 * (cpb + 1) > nt) { for (int s = 0; s < 4; ++s) sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); return; }
+        if (8 * (cpb + 1) > nt) {
+            for (int s = 0; s < 4; ++s) { sed_plan(cond[s], ns[s], kte, ksed1[s], onstep[s]); nblk[s] = loop_max((int)lroundf(1.f / onstep[s])); }
+            return;
+        }
         // (measured: these per-thread LDS atomics -- ~10 lanes of a wave per word -- beat both a gather by 8 cpb leader threads
         // looping over the levels, 1.88 -> 2.03 ms, and a pre-reduction with wave shifts by cpb, 2 cpb, ..., 2.05 ms; only atomics of a
         // WHOLE wave on one word are worth avoiding, see loop_max)
@@ -226,6 +231,9 @@ struct BlockComm {
             int ks = cm[(2 * s) * (cpb + 1) + col]; const int n = cm[(2 * s + 1) * (cpb + 1) + col];
             if (ks == kte) ks = kte - 1;
             ksed1[s] = ks; onstep[s] = (n > 0) ? 1.f / (float)n : 1.0f;
+            int nb = 1;
+            for (int c = 0; c < cpb; ++c) nb = max(nb, cm[(2 * s + 1) * (cpb + 1) + c]);      // (columns outside the tile hold 0)
+            nblk[s] = nb;
         }
     }
     __device__ __forceinline__ void up6(const float v[6], float u[6])
@@ -235,16 +243,6 @@ struct BlockComm {
         __syncthreads();
         const bool up = active && k + 1 < nz;
         for (int s = 0; s < 6; ++s) u[s] = up ? F(b, s, tid + cpb) : 0.f;
-    }
-    // the block's maxima of four loop counts in one barrier round (the integer area of carry_down2 / sed_plan is free by then)
-    __device__ __forceinline__ void loop_max4(const int n[4], int out[4])
-    {
-        __syncthreads();
-        if (tid < 4) scolmax[tid] = 0;
-        __syncthreads();
-        for (int s = 0; s < 4; ++s) { const int w = wave_max(active ? n[s] : 0); if ((tid & 63) == 0) atomicMax(&scolmax[s], w); }
-        __syncthreads();
-        for (int s = 0; s < 4; ++s) out[s] = scolmax[s];
     }
     // up6 restricted to the slots named in `slots` (block-uniform): the others are neither written nor read
     __device__ __forceinline__ void up6_of(const float v[6], float u[6], unsigned slots)
