@@ -208,35 +208,38 @@ int icar_halo_pack_dirs(icar_hip_ctx *c, int ndir, const int *dirs, int h, const
 // ------------------------------------------------------------------------------------------------
 // T2: compute_dt strictness-3 reduction (time_step.f90:264-289)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+// One thread per (i, j) column, levels marched in registers (|w| of the level below is carried), raw buffer loads with scalar
+// row / level offsets: at most 16 VGPRs (the attribute counts half of the unified file), so that the prefetched reduction
+// finds a wave slot on EVERY SIMD beside the MPDATA launch it is issued next to (whose persistent blocks leave 16 registers per
+// SIMD; the former grid-stride kernel needed 61 and ran on the 13 idle CUs only: 0.38 ms in the advection's shadow).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(8)))
 k_max_courant(Dims d, const float *__restrict__ u, const float *__restrict__ v,
               const float *__restrict__ w, const float *__restrict__ dzl, float dx,
               unsigned *__restrict__ out)
 {
-    // grid-stride over (k,j) lines, lanes along i; one atomic per block at the end
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    auto mk = [](const float *p) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, -1, 0x00020000); };
+    const rsrc_t ru = mk(u), rv = mk(v), rw = mk(w);
+    auto ld = [](rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); };
     float cur = 0.0f;
-    const int nlines = d.nz * d.ny;
-    for (int line = blockIdx.x * 4 + threadIdx.y; line < nlines; line += gridDim.x * 4) {
-        const int k = line % d.nz, j = line / d.nz;
-        const int zo = (k == 0) ? 0 : -d.sk;
-        const float rdz = dzl[k];
-        for (int i = threadIdx.x; i < d.nx; i += 64) {
-            const int c = d.idx(i, k, j);
-            const int cu = i + (d.nx + 1) * (k + d.nz * j);
-            const float cw = fmaxf(fabsf(u[cu]), fabsf(u[cu + 1])) / dx
-                           + fmaxf(fabsf(v[c]), fabsf(v[c + d.sj])) / dx
-                           + fmaxf(fabsf(w[c]), fabsf(w[c + zo])) / rdz;
+    if (i < d.nx) {
+        const int vi = 4 * i, nxu = d.nx + 1;
+        float wbelow = 0.0f;
+#pragma unroll 1
+        for (int k = 0; k < d.nz; ++k) {
+            const int sc = 4 * d.idx(0, k, j), scu = 4 * (nxu * (k + d.nz * j));     // wave-uniform
+            const float au = fmaxf(fabsf(ld(ru, vi, scu)), fabsf(ld(ru, vi, scu + 4)));
+            const float av = fmaxf(fabsf(ld(rv, vi, sc)), fabsf(ld(rv, vi, sc + 4 * d.sj)));
+            const float aw0 = fabsf(ld(rw, vi, sc));
+            const float aw = (k == 0) ? aw0 : fmaxf(aw0, wbelow);                     // (level 0 looks at itself, :281)
+            const float cw = au / dx + av / dx + aw / dzl[k];
             cur = fmaxf(cur, cw);
+            wbelow = aw0;
         }
     }
     for (int o = 32; o > 0; o >>= 1) cur = fmaxf(cur, __shfl_down(cur, o));
-    __shared__ float s[4];
-    if (threadIdx.x == 0) s[threadIdx.y] = cur;
-    __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        cur = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-        atomicMax(out, __float_as_uint(cur));   // non-negative floats order like unsigned ints
-    }
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(cur));   // non-negative floats order like unsigned ints
 }
 
 // out != nullptr: the maximum is copied to the host (one stream synchronisation).  d_out != nullptr: it is left in device
@@ -271,8 +274,8 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
     }
     float *red = d_out ? d_out : c->d_red;
     HIPCHK(hipMemsetAsync(red, 0, sizeof(float), c->stream));
-    const int nlines = c->d.nz * c->d.ny;
-    dim3 g(std::min((nlines + 3) / 4, 2048)), b(64, 4);
+    if ((size_t)(c->d.nx + 1) * c->d.nz * (c->d.ny + 1) * sizeof(float) >= ((size_t)1 << 31)) { icar_set_error("max_courant: a field of 2 GiB or more is not supported (32-bit buffer offsets)"); return 1; }
+    dim3 g((c->d.nx + 63) / 64, c->d.ny), b(64);
     ScopedTimer t(c, "cfl");
     hipLaunchKernelGGL(k_max_courant, g, b, 0, c->stream, c->d, u, v, w, dzl, dx, (unsigned *)red);
     HIPCHK(hipGetLastError());
