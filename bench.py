@@ -372,6 +372,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Before anything is timed, the transport proves itself (exchangeable_obj.f90:138-356): the communicator must connect as many
+    # images as the launcher started, one exchange of a rank-stamped field must put every neighbour's stamp into the halo cells
+    # facing it (checked on the device), and a run with a GPU per rank must not have degraded to the host-staged transport.
+    ranks_seen, halo_check = 1, "not applicable (one image, no process group)"
+    if in_group:
+        nr = ctypes.c_int(0); nbad = ctypes.c_int(-1)
+        capi.check(lib.icar_hip_comm_ranks(d.ctx, ctypes.byref(nr)), "icar_hip_comm_ranks")
+        capi.check(lib.icar_hip_halo_selfcheck(d.ctx, 1, ctypes.byref(nbad)), "icar_hip_halo_selfcheck")
+        ranks_seen = int(nr.value)
+        bad_t = torch.tensor([float(nbad.value), float(ranks_seen != world)], dtype=torch.float64, device=red_device)
+        if world > 1:
+            dist.all_reduce(bad_t)
+        halo_check = "ok" if bad_t[0].item() == 0 else f"FAILED: {int(bad_t[0].item())} halo cells do not carry their neighbour's stamp"
+        degraded = backend == "nccl" and kind != capi.COMM_RCCL
+        if bad_t[0].item() != 0 or bad_t[1].item() != 0 or degraded:
+            if rank == 0:
+                print(json.dumps({"error": "transport self-check failed", "ranks_seen": ranks_seen, "world": world, "halo_check": halo_check,
+                                  "backend_kind": kind, "degraded_to_host_staged": bool(degraded)}), flush=True)
+            d.close()
+            raise SystemExit(3)
+
     if args.warmup > 0:
         run_steps(d, opt, args.warmup)
     barrier()
@@ -478,6 +499,7 @@ def main():
                        "halo": ("one ncclSend/ncclRecv group per step issued by the library (icar_hip_halo_send)" if kind == capi.COMM_RCCL else
                                 "one message per neighbour through pinned host memory (icar_hip_comm_init_host)") + ", strips+pack on the second stream beside the interior mp" if world > 1
                                else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips+pack on the second stream beside the interior mp",
+                       "ranks_seen": ranks_seen, "halo_check": halo_check,
                        "dt_s": dt, "mp_active_column_fraction": active},
             "later_window": later,
             "roofline": {"bound": "hbm", "kernel": f"advect ({ADVECT_KERNELS[args.adv]})",

@@ -14,6 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicar_hip.so")
 SOURCES = ["capi.hip", "advect.hip", "mpdata.hip", "mp_simple.hip", "mp_thompson.hip", "thompson_tables.hip", "step.hip", "linear_winds.hip", "iterative_winds.hip", "mp_wsm3.hip", "mp_wsm6.hip", "comm.hip", "timestep.hip"]
+NO_SCRATCH = {"mp_thompson.hip": ["k_thompson_march"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # finite data only: drop the NaN-canonicalisation v_max x,x,x in front of every fmin/fmax (no effect on finite results)
 PER_FILE_FLAGS = {"advect.hip": ["-fno-honor-nans"],
@@ -42,7 +43,15 @@ def build(force=False, verbose=False):
             cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            if s in NO_SCRATCH:
+                # kernels that must not spill (see the comment at k_thompson_march): read the compiler's own resource report
+                rep = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], check=True, capture_output=True, text=True).stderr
+                for kern in NO_SCRATCH[s]:
+                    blocks = [b for b in rep.split("Function Name: ")[1:] if kern in b.split("\n")[0] and "remark" in b]
+                    if not blocks or any("ScratchSize [bytes/lane]: 0" not in b for b in blocks):
+                        raise RuntimeError(f"{s}: {kern} must compile without scratch")
+            else:
+                subprocess.check_call(cmd)
         objs.append(obj)
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-ldl", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]

@@ -444,6 +444,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     if (c->h_cfl_pre) hipHostFree(c->h_cfl_pre);
     if (c->cfl_ev) hipEventDestroy(c->cfl_ev);
     if (c->iw_adj) hipFree(c->iw_adj);
+    if (c->th_ws) hipFree(c->th_ws);
     if (c->wgr_tmp) hipFree(c->wgr_tmp);
     icar_wsm3_free(c);
     icar_wsm6_free(c);
@@ -584,6 +585,13 @@ int icar_hip_thompson_tiles(icar_hip_ctx *c, float dt, int ntiles, const int til
     if (!c || !tiles) { icar_set_error("thompson_tiles: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_thompson_run_tiles(c, dt, ntiles, tiles, kts, kte, ids, ide, jds, jde, kds, kde);
+}
+
+int icar_hip_thompson_layout(icar_hip_ctx *c, int layout)
+{
+    if (!c || layout < 0 || layout > 2) { icar_set_error("thompson_layout: ctx and layout in 0..2"); return 1; }
+    c->th_layout = layout;
+    return 0;
 }
 
 int icar_hip_thompson_dec_index(icar_hip_ctx *c, const float *r4, const double *r8, int n, int n2, int which, int *out)

@@ -11,7 +11,7 @@ struct WaveComm {
     __device__ __forceinline__ WaveComm(int lane, int nz) : k(lane), active(lane < nz) {}
     __device__ __forceinline__ bool any(bool p) { return __any(p); }
     // min over levels >= own (inactive top lanes pass the neutral element)
-    __device__ __forceinline__ double suffix_min(double v)
+    __device__ __forceinline__ double suffix_min(double v, int = 0)
     {
         for (int dd = 1; dd < 64; dd <<= 1) {
             const double o_ = __shfl_down(v, dd);
@@ -42,7 +42,7 @@ struct WaveComm {
     __device__ __forceinline__ void up2(float x, float y, float &ux, float &uy) { ux = __shfl_down(x, 1); uy = __shfl_down(y, 1); }
     __device__ __forceinline__ float up1(float x) { return __shfl_down(x, 1); }
     // the same three services for several species at once (BlockComm pays one barrier round for all of them)
-    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1)
+    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1, int = 0)
     { carry_down2(a0, b0, has0); carry_down2(a1, b1, has1); }
     // nblk[s]: the longest sub-step loop of species s among the columns this communicator spans (here: the one column)
     __device__ __forceinline__ void sed_plan4(const int cond[4], const int ns[4], int kte, int ksed1[4], float onstep[4], int nblk[4])
@@ -71,7 +71,7 @@ struct BlockComm {
     }
     __device__ __forceinline__ float &F(int b, int w, int t) { return sf[(b * 6 + w) * nt + t]; }
     __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p); }
-    __device__ __forceinline__ double suffix_min(double v)
+    __device__ __forceinline__ double suffix_min(double v, int = 0)
     {
         // two-level: minimum over the rest of my chunk of 8 levels, then over the chunk minima above (<= 7 + nz/8 reads
         // instead of up to nz-1; a wave pays for its lowest lane).  min is exact, so the grouping does not matter.
@@ -181,7 +181,7 @@ struct BlockComm {
         return (active && k + 1 < nz) ? F(b, 0, tid + cpb) : 0.f;
     }
     // two species in one exchange (nz <= 64: per-column bit masks in the sd area; else two plain calls)
-    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1)
+    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1, int = 0)
     {
         if (nz > 64) { carry_down2(a0, b0, has0); carry_down2(a1, b1, has1); return; }
         __syncthreads();

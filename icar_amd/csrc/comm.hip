@@ -39,6 +39,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -59,7 +60,7 @@ int rccl_load()
 #define SYM(field, name) do { *(void **)(&r.field) = dlsym(so, name); if (!r.field) { icar_set_error("comm_init: librccl lacks " name); dlclose(so); return 1; } } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
     SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
-    SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+    SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString"); SYM(CommCount, "ncclCommCount");
 #undef SYM
     g_rccl = r;
     return 0;
@@ -81,6 +82,24 @@ constexpr uint64_t kMagic = 0x4943415248495031ull;          // "ICARHIP1"
 constexpr double kWaitSeconds = 60.0;                        // a lost neighbour is an error, not a hang
 
 inline int opposite(int d) { return d ^ 1; }                 // north 0 <-> south 1, east 2 <-> west 3
+
+__global__ void k_stamp_fill(float *__restrict__ f, size_t n, float v)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) f[t] = v;
+}
+// direction order of the transport: north 0 (rows ny-h..), south 1 (rows ..h-1), east 2 (columns nx-h..), west 3 (columns ..h-1);
+// want < 0: no neighbour on that side, its halo cells keep this image's own stamp and are not checked
+__global__ void k_stamp_check(Dims d, const float *__restrict__ f, int h, float wn, float ws, float we, float ww, int *__restrict__ bad)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)d.nx * d.nz * d.ny) return;
+    const int i = (int)(t % d.nx), j = (int)(t / ((size_t)d.nx * d.nz));
+    const bool n_ = j >= d.ny - h, s_ = j < h, e_ = i >= d.nx - h, w_ = i < h;
+    if ((n_ || s_) && (e_ || w_)) return;                      // corner
+    const float want = n_ ? wn : s_ ? ws : e_ ? we : w_ ? ww : -1.0f;
+    if (want >= 0.0f && f[t] != want) atomicAdd(bad, 1);
+}
 
 }  // namespace
 
@@ -400,5 +419,53 @@ int icar_hip_co_max(icar_hip_ctx *c, double *value)
 }
 
 int icar_hip_comm_kind(icar_hip_ctx *c) { return (c && c->comm) ? c->comm->kind : ICAR_COMM_NONE; }
+
+// How many images the transport itself says it connects: ncclCommCount of the RCCL communicator, the header of the shared
+// segment of the host-staged transport, 1 without a transport.
+int icar_hip_comm_ranks(icar_hip_ctx *c, int *nranks)
+{
+    if (!c || !nranks) { icar_set_error("comm_ranks: null argument"); return 1; }
+    *nranks = 1;
+    IcarComm *m = c->comm;
+    if (!m) return 0;
+    if (m->kind == ICAR_COMM_RCCL) { int n = 0; NCHK(g_rccl.CommCount(m->nccl, &n)); *nranks = n; }
+    else if (m->kind == ICAR_COMM_HOST) *nranks = (int)((ShmHeader *)m->shm)->nranks;
+    return 0;
+}
+
+// One halo_send / halo_retrieve (exchangeable_obj.f90:138-356) of a field stamped with this image's rank + 1, checked on the
+// device: every halo cell (corners aside: they ride on the N / S rows and carry the neighbour's own halo) must hold the stamp
+// of the neighbour on that side.  The field's contents are put back.  n_bad = cells that do not.
+int icar_hip_halo_selfcheck(icar_hip_ctx *c, int halo, int *n_bad)
+{
+    if (!c || !n_bad) { icar_set_error("halo_selfcheck: null argument"); return 1; }
+    IcarComm *m = c->comm;
+    if (!m) { icar_set_error("halo_selfcheck: no transport (icar_hip_comm_init)"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    const int fid = ICAR_F_WATER_VAPOR;
+    float *f = icar_field_f(c, fid);
+    if (!f) return 1;
+    float *keep = nullptr; int *d_bad = nullptr;
+    HIPCHK(hipMalloc(&keep, c->n3 * sizeof(float)));
+    if (icar_hip_check(hipMalloc(&d_bad, sizeof(int)), "hipMalloc")) { (void)hipFree(keep); return 1; }
+    int rc = 1;
+    do {
+        if (icar_hip_check(hipMemcpyAsync(keep, f, c->n3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "save")) break;
+        if (icar_hip_check(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream), "memset")) break;
+        hipLaunchKernelGGL(k_stamp_fill, dim3((unsigned)((c->n3 + 255) / 256)), dim3(256), 0, c->stream, f, c->n3, (float)(m->rank + 1));
+        if (icar_comm_halo_send(c, halo, &fid, 1)) break;
+        if (icar_comm_halo_retrieve(c, halo, &fid, 1)) break;
+        float want[4];
+        for (int d = 0; d < 4; ++d) want[d] = m->nb[d] >= 0 ? (float)(m->nb[d] + 1) : m->nb[d] == ICAR_NEIGHBOR_SELF ? (float)(m->rank + 1) : -1.0f;
+        hipLaunchKernelGGL(k_stamp_check, dim3((unsigned)((c->n3 + 255) / 256)), dim3(256), 0, c->stream, c->d, f, halo, want[0], want[1], want[2], want[3], d_bad);
+        if (icar_hip_check(hipGetLastError(), "stamp check")) break;
+        if (icar_hip_check(hipMemcpyAsync(f, keep, c->n3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "restore")) break;
+        if (icar_hip_check(hipMemcpyAsync(n_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream), "read")) break;
+        if (icar_hip_check(hipStreamSynchronize(c->stream), "sync")) break;
+        rc = 0;
+    } while (0);
+    (void)hipFree(keep); (void)hipFree(d_bad);
+    return rc;
+}
 
 }  // extern "C"

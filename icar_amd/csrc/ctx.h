@@ -72,6 +72,8 @@ struct icar_hip_ctx {
     std::vector<float> dzl_host;         // dz_levels last uploaded behind d_red (compute_dt re-sends them only when they change)
     int *d_flag = nullptr;
     ThompsonTables *thompson = nullptr;
+    float *th_ws = nullptr; size_t th_ws_floats = 0;   // k_thompson_march: ThHand of every cell between its two sweeps (mp_thompson.hip)
+    int th_layout = 0;                   // 0 / 1 = one level per thread, 2 = one column per lane (icar_hip_thompson_layout)
     LinWinds *linwinds = nullptr;
     Wsm3State *wsm3 = nullptr;
     Wsm6State *wsm6 = nullptr;

@@ -101,7 +101,9 @@ __device__ __forceinline__ double d_log_k(const DK &K, double x)
     // statement each chain pair (the compiler pads every asm statement that consumes the result of the previous one with
     // an s_nop it cannot prove unnecessary; dependent v_fma_f64 need none)
     double ta = fma(w, K.lg[5], K.lg[3]), tb = fma(w, K.lg7, K.lg[4]);
-    asm("v_fma_f64 %0, %2, %0, %3\n\tv_fma_f64 %1, %2, %1, %4\n\tv_fma_f64 %1, %2, %1, %5"
+    // (s_nop 1: gfx94x / gfx950 need two wait states between a VALU write of an SGPR -- the v_readlane_b32 that restores a
+    // spilled coefficient -- and a VALU read of it; the compiler's hazard recogniser does not look inside an asm statement)
+    asm("s_nop 1\n\tv_fma_f64 %0, %2, %0, %3\n\tv_fma_f64 %1, %2, %1, %4\n\tv_fma_f64 %1, %2, %1, %5"
         : "+v"(ta), "+v"(tb) : "v"(w), "s"(K.lg[1]), "s"(K.lg[2]), "s"(K.lg[0]));
     const double t1 = w * ta, t2 = z * tb;
     const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
@@ -113,7 +115,7 @@ __device__ __forceinline__ double d_exp_k(const DK &K, double x)
     double r = fma(-k, K.ln2_hi, x);
     r = fma(-k, K.ln2_lo, r);
     double p = fma(r, K.e13, K.e[0]);
-    asm("v_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %5\n\t"
+    asm("s_nop 1\n\tv_fma_f64 %0, %0, %1, %2\n\tv_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %5\n\t"
         "v_fma_f64 %0, %0, %1, %6\n\tv_fma_f64 %0, %0, %1, %7\n\tv_fma_f64 %0, %0, %1, %8\n\tv_fma_f64 %0, %0, %1, %9\n\t"
         "v_fma_f64 %0, %0, %1, %10\n\tv_fma_f64 %0, %0, %1, 0.5\n\tv_fma_f64 %0, %0, %1, 1.0\n\tv_fma_f64 %0, %0, %1, 1.0"
         : "+v"(p) : "v"(r), "s"(K.e[1]), "s"(K.e[2]), "s"(K.e[3]), "s"(K.e[4]), "s"(K.e[5]), "s"(K.e[6]), "s"(K.e[7]),

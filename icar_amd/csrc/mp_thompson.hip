@@ -268,6 +268,212 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
     th[c] = t1d / pi_;
 }
+
+// ---- one column per LANE, levels marched top-down (north_star's layout; round 4) ---------------------------------------------
+// A wave owns 64 neighbouring columns (lanes along i) and every VALU instruction works on ONE level of them, so the lanes of a
+// wave take the same branches (rain below / ice above no longer share a wave).  Every vertical coupling of the scheme is
+// sequential in a thread that walks down its column: the graupel intercept's running minimum (:1456-1468, :2379-2391), the
+// fall speeds copied from the nearest level above that holds the species (:2544-2639); only nstep = max over the column of the
+// sub-step counts (:2548-2649) needs the whole column before the sedimentation starts.  So two sweeps:
+//   sweep 1 (top-down): point physics of each level, ThHand -> coalesced HBM workspace ws[level][value][column]
+//   sweep 2 (top-down): sedimentation + melt / freeze + update.  The sub-steps of a level need, for n = 1..nstep, the flux that
+//           left the level above in sub-step n (:2660-2770 computes every level's flux before it updates any level): the wave
+//           keeps that history in LDS (one 256-B row per sub-step and moment), reads row n, overwrites it with its own flux.
+// No barriers, no cross-lane traffic.  If a wave's sub-step counts do not fit its LDS rows the sub-steps are done in chunks,
+// one extra sweep over the workspace per chunk.
+struct MarchComm {
+    int k; bool active;
+    double run_min[2]; float ca[2][4];
+    __device__ __forceinline__ MarchComm() : k(0), active(true)
+    {
+        run_min[0] = run_min[1] = __builtin_inf();
+        for (int w = 0; w < 2; ++w) for (int s = 0; s < 4; ++s) ca[w][s] = 0.f;       /* vtXk(kte+1) = 0 */
+    }
+    __device__ __forceinline__ bool any(bool) { return true; }          /* quiet columns are found by the kernel's first sweep */
+    __device__ __forceinline__ double suffix_min(double v, int which) { run_min[which] = fmin(run_min[which], v); return run_min[which]; }
+    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1, int which)
+    {
+        if (has0) { ca[which][0] = a0; ca[which][1] = b0; } else { a0 = ca[which][0]; b0 = ca[which][1]; }
+        if (has1) { ca[which][2] = a1; ca[which][3] = b1; } else { a1 = ca[which][2]; b1 = ca[which][3]; }
+    }
+};
+
+#define TH_MARCH_ROWS 64          /* LDS flux-history rows (256 B each) per wave: 16 KB, 8 waves per CU */
+
+struct MarchArgs { int i0, ni, j0, ncol, ncolp, k0, nk; };
+
+__device__ __forceinline__ int th_wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+
+// Register budget: 2 waves per SIMD (<= 256 VGPRs; the kernel takes 224, no scratch).  At 3 waves per SIMD (168 VGPRs) the
+// level loop spills ~60 VGPRs on top of ~200 SGPRs parked in VGPR lanes, and that build returned wrong rain numbers at
+// the top rain level of some columns (same source; with -DTH_MARCH_WAVES=2 every test is bit-exact) -- icar_amd/build.py
+// refuses a build of this kernel that needs scratch.
+#define TH_MARCH_WAVES 2
+__global__ void __launch_bounds__(64, TH_MARCH_WAVES)
+k_thompson_march(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
+                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
+                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
+                 double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
+                 float dt, MarchArgs a, float *__restrict__ ws)
+{
+    __shared__ float hist[TH_MARCH_ROWS * 64];
+    gf_lds_init(threadIdx.x, 64);
+    const float R1 = TH_R1, R2 = TH_R2, eps = TH_eps;
+    const int lane = threadIdx.x, col = blockIdx.x * 64 + lane, nk = a.nk, kte = nk - 1;
+    const bool on = col < a.ncol;
+    const int colc = on ? col : a.ncol - 1;
+    const int jj = a.j0 + colc / a.ni, ii = a.i0 + colc % a.ni;
+    const int base = d.idx(ii, a.k0, jj), sk = d.nx;
+
+    /* ---- which columns have nothing to do (:1240-1363): no hydrometeor above R1 and no ice supersaturation at any level ---- */
+    bool quiet = true;
+    for (int k = 0; k < nk; ++k) {
+        const int c = base + k * sk;
+        const bool wet = (qc[c] > R1) || (qi[c] > R1) || (qr[c] > R1) || (qs[c] > R1) || (qg[c] > R1);
+        const float temp = th[c] * pii[c], pres = p[c], qv_ = fmaxf(1.E-10f, qv[c]);
+        const float qvs_ = rslf(pres, temp);
+        const float qvsi_ = (temp - 273.15f <= 0.0f) ? rsif(pres, temp) : qvs_;
+        float ssati_ = qv_ / qvsi_ - 1.f;
+        if (fabsf(ssati_) < eps) ssati_ = 0.0f;
+        if (wet || ssati_ > 0.0f) quiet = false;
+        if (!__any(quiet && on)) break;
+    }
+    const bool live = on && !quiet;
+    int nstep[4] = {0, 0, 0, 0}, ksed1[4] = {0, 0, 0, 0};
+    float onstep[4] = {1.f, 1.f, 1.f, 1.f};
+
+    if (__any(live)) {
+        /* ---- sweep 1: point physics, top-down ---- */
+        MarchComm x;
+        int nsmax[4] = {0, 0, 0, 0}, ks[4] = {-1, -1, -1, -1};
+        for (int k = kte; k >= 0; --k) {
+            const int c = base + k * sk;
+            x.k = k;
+            const float pi_ = pii[c];
+            float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
+                  qg1d = qg[c], ni1d = ni[c], nr1d = nr[c];
+            ThHand h;
+            th_level_physics(T, x, nk, dt, dz1d, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d, p1d, h);
+            for (int s = 0; s < 4; ++s) {
+                if (h.c4[s] && ks[s] < 0) ks[s] = k;                      /* top-down: the first one is the highest (:2548) */
+                nsmax[s] = max(nsmax[s], h.ns4[s]);
+            }
+            float *w = ws + (size_t)k * TH_NHAND * a.ncolp + col;
+            const float hv[TH_NHAND] = {h.vtrk, h.vtnrk, h.vtik, h.vtnik, h.vtsk, h.vtgk, h.rr, h.nr, h.ri, h.ni, h.rs, h.rg,
+                                        h.qrten, h.nrten, h.qiten, h.niten, h.qsten, h.qgten, h.qcten, h.qvten, h.tten,
+                                        h.rho, h.temp, h.ocp, h.lvap};
+            for (int v = 0; v < TH_NHAND; ++v) w[(size_t)v * a.ncolp] = hv[v];
+        }
+        for (int s = 0; s < 4; ++s) {                                     /* the plan: BlockComm::sed_plan4 for one column */
+            const int n = live ? nsmax[s] : 0;
+            int kk = ks[s] < 0 ? 0 : ks[s];
+            if (kk == kte) kk = kte - 1;
+            ksed1[s] = kk; onstep[s] = (n > 0) ? 1.f / (float)n : 1.0f;
+            nstep[s] = live ? (int)lroundf(1.f / onstep[s]) : 0;
+        }
+    }
+    /* ---- sweep 2: sedimentation in chunks of sub-steps that fit the LDS rows (one chunk unless nstep is unusually large) ---- */
+    int nw[4], C[4];
+    for (int s = 0; s < 4; ++s) nw[s] = th_wave_max(nstep[s]);
+    if (2 * nw[0] + 2 * nw[1] + nw[2] + nw[3] <= TH_MARCH_ROWS) { for (int s = 0; s < 4; ++s) C[s] = nw[s]; }
+    else { for (int s = 0; s < 4; ++s) C[s] = min(nw[s], TH_MARCH_ROWS / 6); }
+    int nsweep = 1;
+    for (int s = 0; s < 4; ++s) if (C[s] > 0) nsweep = max(nsweep, (nw[s] + C[s] - 1) / C[s]);
+    float *H0 = hist + lane, *H1 = H0 + 64 * C[0], *H2 = H1 + 64 * C[0], *H3 = H2 + 64 * C[1], *H4 = H3 + 64 * C[1], *H5 = H4 + 64 * C[2];
+    float pptrain = 0.f, pptsnow = 0.f, pptgraul = 0.f, pptice = 0.f;
+    for (int sw = 0; sw < nsweep; ++sw) {
+        const bool last = (sw == nsweep - 1);
+        for (int k = kte; k >= 0; --k) {
+            const int c = base + k * sk;
+            ThHand h;
+            if (live) {
+                const float *w = ws + (size_t)k * TH_NHAND * a.ncolp + col;
+                float hv[TH_NHAND];
+                for (int v = 0; v < TH_NHAND; ++v) hv[v] = w[(size_t)v * a.ncolp];
+                h.vtrk = hv[0]; h.vtnrk = hv[1]; h.vtik = hv[2]; h.vtnik = hv[3]; h.vtsk = hv[4]; h.vtgk = hv[5];
+                h.rr = hv[6]; h.nr = hv[7]; h.ri = hv[8]; h.ni = hv[9]; h.rs = hv[10]; h.rg = hv[11];
+                h.qrten = hv[12]; h.nrten = hv[13]; h.qiten = hv[14]; h.niten = hv[15]; h.qsten = hv[16]; h.qgten = hv[17];
+                h.qcten = hv[18]; h.qvten = hv[19]; h.tten = hv[20]; h.rho = hv[21]; h.temp = hv[22]; h.ocp = hv[23]; h.lvap = hv[24];
+                const float odzq = 1.f / dz[c], orho = 1.f / h.rho;
+                /* :2660-2770, sub-steps n of this chunk; `up` = what left the level above in the same sub-step */
+#define TH_SED2(S, HM, HN, VM, VN, QM, QN, TM, TN, FLOORN, PPT)                                                          \
+                for (int n = sw * C[S] + 1, r = 0; r < C[S] && n <= nw[S]; ++n, ++r) {                                \
+                    if (n <= nstep[S]) {                                                                               \
+                        const float sed_m = VM * QM, sed_n = VN * QN;                                                  \
+                        const float up_m = (k < kte) ? HM[64 * r] : 0.f, up_n = (k < kte) ? HN[64 * r] : 0.f;          \
+                        if (k == kte) {                                                                                \
+                            TM = TM - sed_m * odzq * onstep[S] * orho;                                                 \
+                            TN = TN - sed_n * odzq * onstep[S] * orho;                                                 \
+                            QM = fmaxf(R1, QM - sed_m * odzq * dt * onstep[S]);                                        \
+                            QN = fmaxf(FLOORN, QN - sed_n * odzq * dt * onstep[S]);                                    \
+                        } else if (k <= ksed1[S]) {                                                                    \
+                            TM = TM + (up_m - sed_m) * odzq * onstep[S] * orho;                                        \
+                            TN = TN + (up_n - sed_n) * odzq * onstep[S] * orho;                                        \
+                            QM = fmaxf(R1, QM + (up_m - sed_m) * odzq * dt * onstep[S]);                               \
+                            QN = fmaxf(FLOORN, QN + (up_n - sed_n) * odzq * dt * onstep[S]);                           \
+                        }                                                                                              \
+                        if (k == 0 && QM > R1 * 10.f) PPT = PPT + sed_m * dt * onstep[S];                              \
+                        HM[64 * r] = sed_m; HN[64 * r] = sed_n;                                                        \
+                    }                                                                                                  \
+                }
+#define TH_SED1(S, HM, VM, QM, TM, PPT)                                                                                 \
+                for (int n = sw * C[S] + 1, r = 0; r < C[S] && n <= nw[S]; ++n, ++r) {                                \
+                    if (n <= nstep[S]) {                                                                               \
+                        const float sed_m = VM * QM;                                                                   \
+                        const float up_m = (k < kte) ? HM[64 * r] : 0.f;                                               \
+                        if (k == kte) {                                                                                \
+                            TM = TM - sed_m * odzq * onstep[S] * orho;                                                 \
+                            QM = fmaxf(R1, QM - sed_m * odzq * dt * onstep[S]);                                        \
+                        } else if (k <= ksed1[S]) {                                                                    \
+                            TM = TM + (up_m - sed_m) * odzq * onstep[S] * orho;                                        \
+                            QM = fmaxf(R1, QM + (up_m - sed_m) * odzq * dt * onstep[S]);                               \
+                        }                                                                                              \
+                        if (k == 0 && QM > R1 * 10.f) PPT = PPT + sed_m * dt * onstep[S];                              \
+                        HM[64 * r] = sed_m;                                                                            \
+                    }                                                                                                  \
+                }
+                TH_SED2(0, H0, H1, h.vtrk, h.vtnrk, h.rr, h.nr, h.qrten, h.nrten, R2, pptrain)
+                TH_SED2(1, H2, H3, h.vtik, h.vtnik, h.ri, h.ni, h.qiten, h.niten, R2, pptice)
+                TH_SED1(2, H4, h.vtsk, h.rs, h.qsten, pptsnow)
+                TH_SED1(3, H5, h.vtgk, h.rg, h.qgten, pptgraul)
+#undef TH_SED2
+#undef TH_SED1
+                if (!last) {                                             /* park what the sub-steps moved for the next chunk */
+                    float *wr = ws + (size_t)k * TH_NHAND * a.ncolp + col;
+                    const float back[12] = {h.rr, h.nr, h.ri, h.ni, h.rs, h.rg, h.qrten, h.nrten, h.qiten, h.niten, h.qsten, h.qgten};
+                    for (int v = 0; v < 12; ++v) wr[(size_t)(6 + v) * a.ncolp] = back[v];
+                }
+            }
+            if (last) {
+                const float pi_ = pii[c];
+                float t1d = th[c] * pi_, qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c], qg1d = qg[c],
+                      ni1d = ni[c], nr1d = nr[c];
+                /* :1240-1319 what the column routine does to its arguments before anything else */
+                if (!(qc1d > R1)) qc1d = 0.0f;
+                if (!(qi1d > R1)) { qi1d = 0.0f; ni1d = 0.0f; }
+                if (!(qr1d > R1)) { qr1d = 0.0f; nr1d = 0.0f; }
+                if (!(qs1d > R1)) qs1d = 0.0f;
+                if (!(qg1d > R1)) qg1d = 0.0f;
+                if (live) th_level_finish(T, dt, h, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d);
+                if (on) {
+                    qv[c] = (qv1d < 1.E-7f) ? 1.E-7f : qv1d;          // :997-1010
+                    qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
+                    th[c] = t1d / pi_;
+                }
+            }
+        }
+    }
+    if (on) {
+        const int c2 = ii + d.nx * jj;
+        const float rainnc = 0.f + pptrain + pptsnow + pptgraul + pptice;
+        const float snownc = 0.f + pptsnow + pptice;
+        const float graupelnc = 0.f + pptgraul;
+        rain_acc[c2] = rain_acc[c2] + rainnc;
+        snow_acc[c2] = snow_acc[c2] + snownc;
+        graupel_acc[c2] = graupel_acc[c2] + graupelnc;
+    }
+}
+
 // arguments come from the host so that nothing is folded at compile time: the value must be what a level computes at run time
 __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
 {
@@ -390,6 +596,29 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
     }
     if (nt_ == 0) return 0;
     ScopedTimer tm(c, "mp");
+    // One column per lane (k_thompson_march) only on request (icar_hip_thompson_layout(ctx, 2)): measured on MI355X at
+    // 512 x 512 x 40 it executes 23 % fewer VALU instructions at 67 % instead of 61 % active lanes (neighbouring columns of a
+    // level still diverge in the +-1 % noise of the benchmark state) but runs 2.40 ms against 1.77 ms for the packed
+    // level-per-thread kernel: two waves per SIMD do not hide its instruction-fetch and memory latencies
+    // (profiles/r04_thompson_layout.md).
+    if (nt_ == 1 && nk >= 2 && c->th_layout == 2) {
+        const int ni_ = T4[0][1] - T4[0][0] + 1, nj_ = T4[0][3] - T4[0][2] + 1;
+        const long ncol = (long)ni_ * nj_;
+        {
+            MarchArgs a; a.i0 = T4[0][0] - c->ims; a.ni = ni_; a.j0 = T4[0][2] - c->jms; a.ncol = (int)ncol;
+            a.ncolp = (int)((ncol + 63) / 64) * 64; a.k0 = kts - c->kms; a.nk = nk;
+            const size_t need = (size_t)TH_NHAND * a.ncolp * nk;
+            if (c->th_ws_floats < need) {
+                if (c->th_ws) { (void)hipFree(c->th_ws); c->th_ws = nullptr; c->th_ws_floats = 0; }
+                HIPCHK(hipMalloc(&c->th_ws, need * sizeof(float)));
+                c->th_ws_floats = need;
+            }
+            hipLaunchKernelGGL(k_thompson_march, dim3(a.ncolp / 64), dim3(64), 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr,
+                               th, pii, p, dz, pa, sa, ga, dt, a, c->th_ws);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
+    }
     // Packed layout (column_comm.h) unless one column per 64-lane wave fills the lanes as well (52 <= nk <= 64).
     int cpb = 0, nt = 0;
     if (nk >= 2) {

@@ -19,7 +19,7 @@ module icar_hip
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative, &
             hip_step_config_t, hip_step_configure, hip_update_dt, hip_compute_dt, hip_substep, hip_step, hip_step_n, hip_mp, hip_advect_step, hip_mp_reset, &
             hip_model_time, hip_set_model_time, hip_comm_unique_id, hip_comm_init, hip_comm_init_local, hip_comm_init_host, hip_comm_destroy, &
-            hip_halo_send, hip_halo_retrieve, hip_co_min, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
+            hip_halo_send, hip_halo_retrieve, hip_co_min, hip_comm_ranks, hip_halo_selfcheck, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
@@ -237,6 +237,12 @@ module icar_hip
      integer(c_int) function icar_hip_co_min(ctx, v) bind(C, name="icar_hip_co_min")
        import; type(c_ptr), value :: ctx; real(c_double), intent(inout) :: v
      end function
+     integer(c_int) function icar_hip_comm_ranks(ctx, nranks) bind(C, name="icar_hip_comm_ranks")
+       import; type(c_ptr), value :: ctx; integer(c_int), intent(out) :: nranks
+     end function
+     integer(c_int) function icar_hip_halo_selfcheck(ctx, halo, n_bad) bind(C, name="icar_hip_halo_selfcheck")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: halo; integer(c_int), intent(out) :: n_bad
+     end function
      integer(c_int) function icar_hip_step_configure(ctx, cfg, dz_levels) bind(C, name="icar_hip_step_configure")
        import; type(c_ptr), value :: ctx; type(hip_step_config_t), intent(in) :: cfg; real(c_float), intent(in) :: dz_levels(*)
      end function
@@ -413,6 +419,24 @@ contains
     real(c_double), intent(inout) :: v
     call check(icar_hip_co_min(ctx%p, v), "co_min")
   end subroutine
+
+  !> num_images() as the transport reports it (ncclCommCount / the shared segment's header)
+  integer function hip_comm_ranks(ctx) result(n)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer(c_int) :: nr
+    call check(icar_hip_comm_ranks(ctx%p, nr), "comm_ranks")
+    n = int(nr)
+  end function
+
+  !> one exchange of a rank-stamped field, verified on the device (exchangeable_obj.f90:138-356); returns the number of halo
+  !! cells that do not carry their neighbour's stamp.  Collective.
+  integer function hip_halo_selfcheck(ctx, halo) result(n_bad)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: halo
+    integer(c_int) :: nb
+    call check(icar_hip_halo_selfcheck(ctx%p, int(halo,c_int), nb), "halo_selfcheck")
+    n_bad = int(nb)
+  end function
 
   subroutine check(rc, what)
     integer(c_int), intent(in) :: rc

@@ -165,6 +165,13 @@ int icar_hip_thompson(icar_hip_ctx *ctx, float dt,
  * {its,ite,jts,jte} (as icar_hip_mp_tiles returns them) in ONE launch.  Tiles must not overlap. */
 int icar_hip_thompson_tiles(icar_hip_ctx *ctx, float dt, int ntiles, const int tiles[][4], int kts, int kte,
                             int ids, int ide, int jds, int jde, int kds, int kde);
+/* Thread layout of the Thompson column physics (mp_thompson.f90:1057-2844 is a 1-D column routine; how its levels map to
+ * lanes is the device's business).  0 / 1 (default): one level per thread, whole columns packed into 256-thread blocks.
+ * 2: one column per LANE marching down its levels in two sweeps (point physics, then sedimentation + update), for single
+ * tiles; the same bits, slower on MI355X today (profiles/r04_thompson_layout.md) -- kept for profiling and as the
+ * starting point of north_star's layout. */
+int icar_hip_thompson_layout(icar_hip_ctx *ctx, int layout);
+
 
 /* Download one Thompson lookup table by its reference name (tcg_racg ... t_Efsw, Fortran order) for
  * cross-checks against ICAR's own qr_acr_qg_mpt.dat / qr_acr_qs_mpt.dat / freezeH2O_mpt.dat caches
@@ -363,6 +370,13 @@ int icar_hip_comm_init(icar_hip_ctx *ctx, int nranks, int rank, const char uid[1
 int icar_hip_comm_init_host(icar_hip_ctx *ctx, int nranks, int rank, const char *shm_name, size_t slot_bytes, const int neighbors[4]);
 int icar_hip_comm_destroy(icar_hip_ctx *ctx);
 int icar_hip_comm_kind(icar_hip_ctx *ctx);                      /* ICAR_COMM_* */
+/* num_images() as the transport itself reports it (ncclCommCount / the shared segment's header; 1 without a transport) */
+int icar_hip_comm_ranks(icar_hip_ctx *ctx, int *nranks);
+/* A self-test of exchangeable_t%send / %retrieve (src/objects/exchangeable_obj.f90:138-356) on this communicator: one
+ * exchange of a field stamped with this image's number, verified on the device -- every halo cell must carry the stamp of
+ * the neighbour on its side (corner cells aside).  The field used (water vapour) is restored.  n_bad = offending cells.
+ * Collective: every image of the communicator calls it. */
+int icar_hip_halo_selfcheck(icar_hip_ctx *ctx, int halo, int *n_bad);
 int icar_hip_halo_send(icar_hip_ctx *ctx, int halo, const int *fields, int nfields);
 int icar_hip_halo_retrieve(icar_hip_ctx *ctx, int halo, const int *fields, int nfields);
 /* in/out: *value becomes the minimum (maximum) over the images; one image: unchanged */

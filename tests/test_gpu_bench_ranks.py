@@ -33,6 +33,8 @@ def test_bench_gpus_n_spawns_n_ranks_on_the_fixed_global_grid(n, decomp):
     assert r.returncode == 0, r.stderr[-3000:]
     out = _line(r)
     assert out["n_gpus"] == n and out["config"]["decomposition"] == decomp and out["config"]["backend"].startswith("host-staged")
+    # the transport proved itself before the timed region: it connects n images and every halo cell got its neighbour's stamp
+    assert out["config"]["ranks_seen"] == n and out["config"]["halo_check"] == "ok"
     assert out["scaling"] == "strong" and out["config"]["global_grid"] == [64, 48, 12]
     # value = cells all ranks own (the interior of the GLOBAL grid, whatever N) x steps / time
     cells = out["value"] * out["ms_per_step"] * 1e-3
@@ -57,6 +59,7 @@ def test_bench_north_star_grid_on_eight_images():
 def test_bench_single_rank_times_the_same_path():
     out = _line(_run(["--gpus", "1"] + SMALL, {}))
     assert out["n_gpus"] == 1 and out["config"]["decomposition"] == "1x1"
+    assert out["config"]["ranks_seen"] == 1 and out["config"]["halo_check"].startswith("not applicable")
     assert "second stream" in out["config"]["halo"] and "self-exchange" in out["config"]["halo"]
 
 
@@ -82,11 +85,14 @@ def test_bench_under_the_launcher_with_one_rank_initialises_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     out = _line(r)
     assert out["n_gpus"] == 1 and out["config"]["backend"] == "rccl" and out["value"] > 0
+    assert out["config"]["ranks_seen"] == 1 and out["config"]["halo_check"] == "ok"      # ncclCommCount, self-ring exchange checked
 
 
-def test_bench_falls_back_to_the_host_transport_when_rccl_init_fails():
+def test_bench_refuses_a_degraded_transport_when_a_gpu_per_rank_is_there():
     """An image whose ncclCommInitRank fails must not leave the others in a different transport: the outcome is agreed on over the
-    launcher's process group, every image drops its communicator, all open the host-staged one, and the line says so."""
+    launcher's process group, every image drops its communicator and all open the host-staged one (icar_amd/halo.py) -- and the
+    BENCH then refuses to time it: with a GPU per rank a host-staged number must never pass for an RCCL one.  It prints an error
+    line and exits non-zero."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
@@ -96,6 +102,7 @@ def test_bench_falls_back_to_the_host_transport_when_rccl_init_fails():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_rccl_fallback_child.py"), "--gpus", "1"] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode != 0
     out = _line(r)
-    assert out["config"]["backend"].startswith("host-staged") and "simulated" in out["config"]["transport_note"] and out["value"] > 0
+    assert out["error"] == "transport self-check failed" and out["degraded_to_host_staged"] is True and "value" not in out
+    assert out["halo_check"] == "ok" and out["ranks_seen"] == 1          # the host-staged transport itself works; it is refused for what it is

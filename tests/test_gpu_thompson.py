@@ -49,7 +49,7 @@ def test_lookup_tables_bit_identical(th_oracle):
     d.close()
 
 
-def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, mp_options=None):
+def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, mp_options=None, layout=0):
     c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, uniform_dz=uniform_dz)
     c["water_vapor"] = (c["water_vapor"] * np.float32(moist)).astype(np.float32)
     s = {k: c[k].copy() for k in list(FIELDS) + ["exner", "pressure", "dz_mass"]}
@@ -59,6 +59,7 @@ def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, 
     if mp_options is not None:
         opt.mp_options = mp_options
     mp_init(opt, d)
+    check(lib().icar_hip_thompson_layout(d.ctx, layout), "thompson_layout")
     oracle.set_math_mode(mode)
     try:
         for _ in range(steps):
@@ -114,6 +115,48 @@ def test_thompson_bit_exact_vs_reference_math(th_oracle, case):
         assert ref["snow"].max() > 1e-4 and ref["graupel"].max() > 1e-5 and ref["cloud_ice"].max() > 1e-6
     assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
     check_close(out, ref, rtol=1e-5, label=case + "/mode0", **EXACT)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_thompson_column_per_lane_bit_exact(th_oracle, case):
+    """k_thompson_march (one column per lane, levels marched top-down, ThHand parked in the HBM workspace between the two
+    sweeps, sedimentation flux history in LDS) forced on the small cases: the same bits as the oracle in the reference's math."""
+    out, ref = run_case(th_oracle, mode=0, layout=2, **CASES[case])
+    assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
+    check_close(out, ref, rtol=1e-5, label=case + "/march/mode0", **EXACT)
+
+
+def test_thompson_column_per_lane_chunked_substeps(th_oracle):
+    """A time step long enough that a wave's sub-step counts (2 nstep_rain + 2 nstep_ice + nstep_snow + nstep_graupel) exceed
+    its 64 LDS rows: the sedimentation then runs in chunks of sub-steps, one sweep over the workspace per chunk."""
+    out, ref = run_case(th_oracle, mode=0, layout=2, nx=70, ny=9, nz=40, steps=6, cool=3.0, moist=2.5, dt=400.0)
+    assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
+    check_close(out, ref, rtol=1e-5, label="march_chunked/mode0", **EXACT)
+
+
+def test_thompson_layouts_agree_with_quiet_columns():
+    """Columns with nothing to do (:1363) beside active ones, both layouts, bit for bit (the dry half of the domain keeps
+    its inputs except for what the column routine does before it returns)."""
+    nx, ny, nz = 140, 11, 40
+    c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.01)
+    qv = c["water_vapor"].copy(); qv[:, :, : nx // 2] *= np.float32(0.05); qv[:, :, nx // 2:] *= np.float32(2.0)
+    c["water_vapor"] = qv.astype(np.float32)
+    c["cloud_water"][:, 3, 5:9] = np.float32(5e-13)          # below R1: zeroed even where the column returns early
+    outs = []
+    for layout in (1, 2):
+        d = single_image_domain(c)
+        opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+        mp_init(opt, d)
+        check(lib().icar_hip_thompson_layout(d.ctx, layout), "thompson_layout")
+        for _ in range(4):
+            mp(d, opt, 60.0); d.model_time_seconds += 60.0
+            d.set("potential_temperature", d.get("potential_temperature") - np.float32(1.5))
+        outs.append({k: d.get(m) for k, m in FIELDS.items()} | {"acc": d.get("accumulated_precipitation")})
+        d.close()
+    dry = outs[0]["cloud_water"].max(axis=1) == 0.0                      # (ny, nx): columns without any cloud water
+    assert dry.any() and (~dry).any() and outs[0]["cloud_water"][1:-1, 3, 5:9].max() == 0.0
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
 def test_thompson_excludes_last_global_row_and_column(th_oracle):
