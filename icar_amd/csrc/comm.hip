@@ -119,6 +119,10 @@ struct IcarComm {
     std::string shm_name; void *shm = nullptr; size_t shm_bytes = 0, slot_bytes = 0;
     float *hs[4] = {nullptr, nullptr, nullptr, nullptr}, *hr[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging
     uint64_t msg_no = 0, red_no = 0;
+    // exchange_u / exchange_v messages (one per neighbour, both fields): device send / receive buffers, pinned staging
+    float *uvs[4] = {nullptr, nullptr, nullptr, nullptr}, *uvr[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *uvhs[4] = {nullptr, nullptr, nullptr, nullptr}, *uvhr[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t uvcap_s[4] = {0, 0, 0, 0}, uvcap_r[4] = {0, 0, 0, 0};
 
     ShmBox *box(int r, int d) const { return (ShmBox *)((char *)shm + 64 + ((size_t)r * 5 + d) * 64); }
     ShmRed *red(int r) const { return (ShmRed *)((char *)shm + 64 + ((size_t)r * 5 + 4) * 64); }
@@ -234,6 +238,118 @@ int icar_comm_halo_retrieve(icar_hip_ctx *c, int h, const int *fields, int nf)
     return icar_halo_pack_dirs(c, nd, dirs, h, fields, nf, bufs, true);
 }
 
+// ---- exchange_u / exchange_v (exchangeable_obj.f90:158-229) ------------------------------------------------------------
+// `call domain%u%exchange_u(); call domain%v%exchange_v()` (wind.f90:404-405, :482-483) as ONE message per neighbour: the two
+// fields are independent, every box is packed before any is unpacked (the PUTs precede `sync images`), N / S are unpacked
+// before E / W like the reference's retrieve order.  A box is (field, i0, ni, j0, nj), 0-based in the field's own memory
+// extents (u has nx+1 columns, v has ny+1 rows):
+//   u: N / S like exchange (put_north / put_south over the full staggered width, :160-161); the east PUT is halo+1 columns
+//      n-2h..n-h (:166) landing in the neighbour's columns start..start+h (:188); the west PUT is columns start+h+1..start+2h
+//      (:172) landing in the neighbour's last h columns;   v: the same with rows (:202-221).
+namespace {
+struct UvBox { int f, i0, ni, j0, nj; };
+void uv_plan(int nx, int ny, int h, int dir, UvBox send[2], UvBox recv[2])
+{
+    const int X = nx + 1, Y = ny + 1, U = ICAR_F_U, V = ICAR_F_V;
+    switch (dir) {
+    case 0: send[0] = {U, 0, X, ny - 2 * h, h}; send[1] = {V, 0, nx, Y - 1 - 2 * h, h + 1};
+            recv[0] = {U, 0, X, ny - h, h};     recv[1] = {V, 0, nx, Y - h, h}; break;
+    case 1: send[0] = {U, 0, X, h, h};          send[1] = {V, 0, nx, h + 1, h};
+            recv[0] = {U, 0, X, 0, h};          recv[1] = {V, 0, nx, 0, h + 1}; break;
+    case 2: send[0] = {U, X - 1 - 2 * h, h + 1, 0, ny}; send[1] = {V, nx - 2 * h, h, 0, Y};
+            recv[0] = {U, X - h, h, 0, ny};             recv[1] = {V, nx - h, h, 0, Y}; break;
+    default: send[0] = {U, h + 1, h, 0, ny};    send[1] = {V, h, h, 0, Y};
+             recv[0] = {U, 0, h + 1, 0, ny};    recv[1] = {V, 0, h, 0, Y}; break;
+    }
+}
+size_t uv_count(const UvBox b[2], int nz) { return ((size_t)b[0].ni * b[0].nj + (size_t)b[1].ni * b[1].nj) * nz; }
+}  // namespace
+
+bool icar_comm_has_peers(icar_hip_ctx *c)
+{
+    if (!c->comm) return false;
+    for (int d = 0; d < 4; ++d) if (has_peer(c->comm, d)) return true;
+    return false;
+}
+
+int icar_comm_exchange_uv(icar_hip_ctx *c, int h, int which)
+{
+    IcarComm *m = c->comm;
+    if (!m) return 0;
+    bool peers = false;
+    for (int d = 0; d < 4; ++d) peers = peers || has_peer(m, d);
+    if (!peers) return 0;                                   // (edges that wrap to the tile itself are not exchanged: the reference has none)
+    if (m->in_flight) { icar_set_error("exchange_uv between a halo_send and its halo_retrieve"); return 1; }
+    if (m->kind != ICAR_COMM_RCCL && m->kind != ICAR_COMM_HOST) { icar_set_error("exchange_uv: neighbours given but no transport"); return 1; }
+    const Dims &dd = c->d;
+    if (h < 1 || 2 * h + 1 > dd.nx || 2 * h + 1 > dd.ny) { icar_set_error("exchange_uv: bad halo width"); return 1; }
+    UvBox sb[4][2], rb[4][2]; size_t ns[4] = {0, 0, 0, 0}, nr[4] = {0, 0, 0, 0};
+    for (int d = 0; d < 4; ++d) if (has_peer(m, d)) {
+        uv_plan(dd.nx, dd.ny, h, d, sb[d], rb[d]);
+        ns[d] = uv_count(sb[d], dd.nz); nr[d] = uv_count(rb[d], dd.nz);
+        if (ns[d] > m->uvcap_s[d]) {
+            if (m->uvs[d]) { (void)hipFree(m->uvs[d]); m->uvs[d] = nullptr; }
+            if (m->uvhs[d]) { (void)hipHostFree(m->uvhs[d]); m->uvhs[d] = nullptr; }
+            m->uvcap_s[d] = 0;
+            HIPCHK(hipMalloc(&m->uvs[d], ns[d] * sizeof(float)));
+            if (m->kind == ICAR_COMM_HOST) HIPCHK(hipHostMalloc((void **)&m->uvhs[d], ns[d] * sizeof(float), hipHostMallocDefault));
+            m->uvcap_s[d] = ns[d];
+        }
+        if (nr[d] > m->uvcap_r[d]) {
+            if (m->uvr[d]) { (void)hipFree(m->uvr[d]); m->uvr[d] = nullptr; }
+            if (m->uvhr[d]) { (void)hipHostFree(m->uvhr[d]); m->uvhr[d] = nullptr; }
+            m->uvcap_r[d] = 0;
+            HIPCHK(hipMalloc(&m->uvr[d], nr[d] * sizeof(float)));
+            if (m->kind == ICAR_COMM_HOST) HIPCHK(hipHostMalloc((void **)&m->uvhr[d], nr[d] * sizeof(float), hipHostMallocDefault));
+            m->uvcap_r[d] = nr[d];
+        }
+        size_t off = 0;
+        for (int b = 0; b < 2; ++b) {
+            const UvBox &x = sb[d][b];
+            if (icar_box_copy(c, x.f, which, x.i0, x.ni, x.j0, x.nj, m->uvs[d] + off, false)) return 1;
+            off += (size_t)x.ni * x.nj * dd.nz;
+        }
+    }
+    if (m->kind == ICAR_COMM_RCCL) {
+        ScopedTimer t(c, "halo_transport");
+        NCHK(g_rccl.GroupStart());
+        for (int d = 0; d < 4; ++d) if (has_peer(m, d)) NCHK(g_rccl.Send(m->uvs[d], ns[d], ncclFloat, m->nb[d], m->nccl, c->stream));
+        for (int d = 0; d < 4; ++d) { const int o = opposite(d); if (has_peer(m, o)) NCHK(g_rccl.Recv(m->uvr[o], nr[o], ncclFloat, m->nb[o], m->nccl, c->stream)); }
+        NCHK(g_rccl.GroupEnd());
+    } else {
+        for (int d = 0; d < 4; ++d) if (has_peer(m, d)) {
+            if (ns[d] * sizeof(float) > m->slot_bytes) { icar_set_error("exchange_uv: message larger than the slot_bytes given to icar_hip_comm_init_host"); return 1; }
+            HIPCHK(hipMemcpyAsync(m->uvhs[d], m->uvs[d], ns[d] * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ++m->msg_no;
+        for (int d = 0; d < 4; ++d) if (has_peer(m, d)) {
+            const int p = m->nb[d], o = opposite(d);
+            ShmBox *b = m->box(p, o);
+            const uint64_t want = m->msg_no - 1;
+            if (spin_until([&] { return b->ack.load(std::memory_order_acquire) >= want; }, "exchange_uv")) return 1;
+            memcpy(m->slot(p, o), m->uvhs[d], ns[d] * sizeof(float));
+            b->seq.store(m->msg_no, std::memory_order_release);
+        }
+        for (int d = 0; d < 4; ++d) if (has_peer(m, d)) {
+            ShmBox *b = m->box(m->rank, d);
+            if (spin_until([&] { return b->seq.load(std::memory_order_acquire) >= m->msg_no; }, "exchange_uv")) return 1;
+            memcpy(m->uvhr[d], m->slot(m->rank, d), nr[d] * sizeof(float));
+            b->ack.store(m->msg_no, std::memory_order_release);
+            HIPCHK(hipMemcpyAsync(m->uvr[d], m->uvhr[d], nr[d] * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    for (int d = 0; d < 4; ++d) if (has_peer(m, d)) {       // north, south, then east, west
+        size_t off = 0;
+        for (int b = 0; b < 2; ++b) {
+            const UvBox &x = rb[d][b];
+            if (icar_box_copy(c, x.f, which, x.i0, x.ni, x.j0, x.nj, m->uvr[d] + off, true)) return 1;
+            off += (size_t)x.ni * x.nj * dd.nz;
+        }
+    }
+    return 0;
+}
+
 // ---- co_min (time_step.f90:413) and the device-side maximum used by update_dt ----------------------------------------
 static int host_reduce(IcarComm *m, double *v, bool take_min)
 {
@@ -287,6 +403,10 @@ void icar_comm_free(icar_hip_ctx *c)
         if (m->rbuf[d]) hipFree(m->rbuf[d]);
         if (m->hs[d]) hipHostFree(m->hs[d]);
         if (m->hr[d]) hipHostFree(m->hr[d]);
+        if (m->uvs[d]) hipFree(m->uvs[d]);
+        if (m->uvr[d]) hipFree(m->uvr[d]);
+        if (m->uvhs[d]) hipHostFree(m->uvhs[d]);
+        if (m->uvhr[d]) hipHostFree(m->uvhr[d]);
     }
     if (m->d_red) hipFree(m->d_red);
     if (m->h_red) hipHostFree(m->h_red);
@@ -402,6 +522,15 @@ int icar_hip_halo_retrieve(icar_hip_ctx *c, int halo, const int *fields, int nfi
     if (!c || (nfields > 0 && !fields)) { icar_set_error("halo_retrieve: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_comm_halo_retrieve(c, halo, fields, nfields);
+}
+
+int icar_hip_exchange_uv(icar_hip_ctx *c, int halo, int update)
+{
+    if (!c) { icar_set_error("exchange_uv: null ctx"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    const int r = icar_comm_exchange_uv(c, halo, update ? 1 : 0);
+    if (!r && !update) icar_winds_changed(c);
+    return r;
 }
 
 int icar_hip_co_min(icar_hip_ctx *c, double *value)

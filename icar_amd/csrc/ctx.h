@@ -37,6 +37,7 @@ struct IcarStepState {
     double mp_last_model_time = -999.0;      // mp_driver.f90:44 last_model_time
     int winds_scheme = 0, winds_dens = 0; float winds_dt = 0.f;   // what the Courant winds on the device were set up for
     float *h_val = nullptr;                  // pinned: the reduced CFL maximum
+    bool winds_first = true;                 // wind.f90:297 `.not. allocated(domain%sintheta)`: update_winds has not run yet
 };
 
 struct icar_hip_ctx {

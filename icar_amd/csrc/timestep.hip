@@ -260,7 +260,53 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
     return 0;
 }
 
+// ---- update_winds (wind.f90:289-369) and iterative_winds (:371-498) -----------------------------------------------------
+// windtype: src/constants/icar_constants.f90:368-377
+enum { kWIND_LINEAR = 1, kCONSERVE_MASS = 2, kITERATIVE_WINDS = 3, kLINEAR_ITERATIVE_WINDS = 5 };
+
+static int iterative_winds(icar_hip_ctx *c, float dx, int wind_iterations, int halo, int update)
+{
+    // :404-405 exchange_u / exchange_v, :407-415 balance_uvw, :430-441 the model-top w spread over the column, then
+    // `do it = 0, wind_iterations`: one sweep (:455-481) and the exchanges (:482-483)
+    if (icar_comm_exchange_uv(c, halo, update)) return 1;
+    if (icar_balance_uvw_run(c, dx, update)) return 1;
+    if (icar_iterative_winds_correct_w(c, update)) return 1;
+    const int n = wind_iterations + 1;
+    if (!icar_comm_has_peers(c)) return icar_iterative_winds_sweep(c, dx, n, update);        // no neighbour to talk to: the whole loop in one call
+    for (int it = 0; it < n; ++it) {
+        if (icar_iterative_winds_sweep(c, dx, 1, update)) return 1;
+        if (icar_comm_exchange_uv(c, halo, update)) return 1;
+    }
+    return 0;
+}
+
+int icar_update_winds(icar_hip_ctx *c, int windtype, int wind_iterations, float dx, int halo, int update)
+{
+    if (windtype != 0 && windtype != kWIND_LINEAR && windtype != kCONSERVE_MASS && windtype != kITERATIVE_WINDS && windtype != kLINEAR_ITERATIVE_WINDS) {
+        icar_set_error("update_winds: windtype is 0, 1 (linear), 2 (conserve mass), 3 (iterative) or 5 (linear + iterative)"); return 1;
+    }
+    if (icar_make_winds_grid_relative(c, update)) return 1;                                              // :300 / :338
+    if ((windtype == kWIND_LINEAR || windtype == kLINEAR_ITERATIVE_WINDS) && icar_spatial_winds_run(c, update)) return 1;   // linear_perturb
+    if (windtype == kCONSERVE_MASS && icar_mass_conservative_acceleration(c, update)) return 1;
+    if ((windtype == kITERATIVE_WINDS || windtype == kLINEAR_ITERATIVE_WINDS) && iterative_winds(c, dx, wind_iterations, halo, update)) return 1;
+    return icar_balance_uvw_run(c, dx, update);                                                          // :329-331 / :357-363
+}
+
 extern "C" {
+
+// update_winds(domain, options): the first call works on u, v, w (update = 0), every later one on their dqdt_3d (the next
+// forcing step's winds); update < 0 = as the reference decides it (first call of this context or not, wind.f90:297).
+int icar_hip_update_winds(icar_hip_ctx *c, int windtype, int wind_iterations, float dx, int halo, int update)
+{
+    if (!c) { icar_set_error("update_winds: null ctx"); return 1; }
+    if (wind_iterations < 0 || halo < 1) { icar_set_error("update_winds: wind_iterations >= 0, halo >= 1"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    const int upd = update < 0 ? (c->step.winds_first ? 0 : 1) : (update ? 1 : 0);
+    if (icar_update_winds(c, windtype, wind_iterations, dx, halo, upd)) return 1;
+    c->step.winds_first = false;
+    if (!upd) icar_winds_changed(c);
+    return 0;
+}
 
 int icar_hip_step_configure(icar_hip_ctx *c, const icar_hip_step_config *cfg, const float *dz_levels)
 {

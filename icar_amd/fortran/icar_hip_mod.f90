@@ -19,7 +19,7 @@ module icar_hip
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative, &
             hip_step_config_t, hip_step_configure, hip_update_dt, hip_compute_dt, hip_substep, hip_step, hip_step_n, hip_mp, hip_advect_step, hip_mp_reset, &
             hip_model_time, hip_set_model_time, hip_comm_unique_id, hip_comm_init, hip_comm_init_local, hip_comm_init_host, hip_comm_destroy, &
-            hip_halo_send, hip_halo_retrieve, hip_co_min, hip_comm_ranks, hip_halo_selfcheck, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
+            hip_halo_send, hip_halo_retrieve, hip_co_min, hip_comm_ranks, hip_halo_selfcheck, hip_update_winds, hip_exchange_uv, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
@@ -236,6 +236,12 @@ module icar_hip
      end function
      integer(c_int) function icar_hip_co_min(ctx, v) bind(C, name="icar_hip_co_min")
        import; type(c_ptr), value :: ctx; real(c_double), intent(inout) :: v
+     end function
+     integer(c_int) function icar_hip_update_winds(ctx, windtype, wind_iterations, dx, halo, update) bind(C, name="icar_hip_update_winds")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: windtype, wind_iterations, halo, update; real(c_float), value :: dx
+     end function
+     integer(c_int) function icar_hip_exchange_uv(ctx, halo, update) bind(C, name="icar_hip_exchange_uv")
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: halo, update
      end function
      integer(c_int) function icar_hip_comm_ranks(ctx, nranks) bind(C, name="icar_hip_comm_ranks")
        import; type(c_ptr), value :: ctx; integer(c_int), intent(out) :: nranks
@@ -778,6 +784,32 @@ contains
     end if
     call check(icar_hip_iterative_winds_correct_w(ctx%p, upd), "iterative_winds_correct_w")
     call check(icar_hip_iterative_winds_sweep(ctx%p, real(dx,c_float), int(wind_iterations+1,c_int), upd), "iterative_winds_sweep")
+  end subroutine
+
+  !> update_winds(domain, options) (wind.f90:289-369) as one call, on any number of images: make_winds_grid_relative ->
+  !! linear_perturb (windtype 1, 5) -> mass_conservative_acceleration (2) -> iterative_winds with its exchange_u / exchange_v
+  !! per sweep (3, 5) -> balance_uvw.  The first call of a context works on u, v, w, later ones on their dqdt_3d, like the
+  !! reference (`update` forces either).  windtype = options%physics%windtype, halo = grid%halo_size.
+  subroutine hip_update_winds(ctx, windtype, wind_iterations, dx, halo, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: windtype, wind_iterations, halo
+    real, intent(in) :: dx
+    logical, intent(in), optional :: update
+    integer(c_int) :: upd
+    upd = -1
+    if (present(update)) upd = merge(1, 0, update)
+    call check(icar_hip_update_winds(ctx%p, int(windtype,c_int), int(wind_iterations,c_int), real(dx,c_float), int(halo,c_int), upd), "update_winds")
+  end subroutine
+
+  !> call domain%u%exchange_u(); call domain%v%exchange_v() (exchangeable_obj.f90:158-229), one message per neighbour
+  subroutine hip_exchange_uv(ctx, halo, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    integer, intent(in) :: halo
+    logical, intent(in), optional :: update
+    integer(c_int) :: upd
+    upd = 0
+    if (present(update)) upd = merge(1, 0, update)
+    call check(icar_hip_exchange_uv(ctx%p, int(halo,c_int), upd), "exchange_uv")
   end subroutine
 
   !> setup_linwinds (linear_winds.f90:1180): terrain spectrum, wavenumber axes, zeroed perturbation state

@@ -3,7 +3,9 @@
 !! library's own transport (hip_comm_init* + the halo_send / halo_retrieve inside the sub-step), dt reduced over the images
 !! (co_min) inside hip_update_dt.  The reference starts N coarray images of one program; this image has no coarray runtime
 !! (SURVEY 8c), so the test starts N OS processes of this program and passes the image number on the command line:
-!!     icar_hip_tiles_demo <dir> <rank 0..N-1> <N> <shm name>
+!!     icar_hip_tiles_demo <dir> <rank 0..N-1> <N> <shm name> [wind_iterations]
+!! With the fifth argument update_winds(domain, options) runs first with windtype = kITERATIVE_WINDS (wind.f90:289-369,
+!! :371-498: one library call, exchange_u / exchange_v per sweep over the same transport) and u, v, w are written out too.
 !! With a coarray runtime the two lines marked (*) become this_image()-1 / num_images(), and the host-staged transport becomes
 !!     if (this_image()==1) call hip_comm_unique_id(uid);  call co_broadcast(uid, 1);  call hip_comm_init(ctx, N, rank, uid, nb)
 !! (RCCL over xGMI, one GPU per image; INTEGRATION.md section 4).  Reads the tile written by tests/test_gpu_fortran_host.py
@@ -14,14 +16,14 @@ program icar_hip_tiles_demo
   implicit none
   type(hip_ctx_t) :: ctx
   type(hip_step_config_t) :: cfg
-  integer :: rank, nranks, u, i, nsteps, nz
+  integer :: rank, nranks, u, i, nsteps, nz, wind_iterations
   integer :: ims, ime, jms, jme, its, ite, jts, jte, ids, ide, jds, jde, bnd(4)
   integer(c_int) :: nb(4)
   integer(c_size_t) :: slot_bytes
   real :: dx
   double precision :: end_time, clock
   real(c_float), allocatable, target :: a(:,:,:), au(:,:,:), av(:,:,:), dz_levels(:)
-  real(c_double), allocatable, target :: acc(:,:)
+  real(c_double), allocatable, target :: acc(:,:), theta(:,:)
   character(len=512) :: dir, arg, shm
   integer, parameter :: n3 = 13
   integer(c_int), parameter :: f3(n3) = [ICAR_F_W, ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, &
@@ -34,6 +36,10 @@ program icar_hip_tiles_demo
   call get_command_argument(2, arg); read(arg,*) rank            ! (*) this_image() - 1
   call get_command_argument(3, arg); read(arg,*) nranks          ! (*) num_images()
   call get_command_argument(4, shm)
+  wind_iterations = -1
+  if (command_argument_count() >= 5) then
+     call get_command_argument(5, arg); read(arg,*) wind_iterations
+  end if
   open(newunit=u, file=trim(dir)//"/meta.txt", status="old")
   read(u,*) ims, ime, jms, jme, nz                               ! grid_t of this image (grid_obj.f90:39-255), global index space
   read(u,*) its, ite, jts, jte
@@ -68,6 +74,16 @@ program icar_hip_tiles_demo
   cfg%n_advect = 5; cfg%advect_fields(1:5) = adv
   cfg%n_exchange = 5; cfg%exchange_fields(1:5) = adv
   call hip_step_configure(ctx, cfg, dz_levels)
+  if (wind_iterations >= 0) then
+     ! init_winds (wind.f90:512-590) on an unrotated grid: sintheta = 0, costheta = 1; then update_winds (first call: on u, v, w)
+     allocate(theta(ims:ime,jms:jme))
+     theta = 0.0d0; call hip_upload_2dd(ctx, ICAR_F_SINTHETA, theta)
+     theta = 1.0d0; call hip_upload_2dd(ctx, ICAR_F_COSTHETA, theta)
+     call hip_update_winds(ctx, 3, wind_iterations, dx, 1)
+     call hip_download(ctx, ICAR_F_U, au); call wr(trim(dir)//"/out_u.bin", au)
+     call hip_download(ctx, ICAR_F_V, av); call wr(trim(dir)//"/out_v.bin", av)
+     call hip_download(ctx, ICAR_F_W, a);  call wr(trim(dir)//"/out_w.bin", a)
+  end if
   call hip_mp_reset(ctx)                                         ! mp_init
   call hip_set_model_time(ctx, 0.0d0)
 

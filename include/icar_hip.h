@@ -278,6 +278,20 @@ int icar_hip_iterative_winds_sweep(icar_hip_ctx *ctx, float dx, int nsweeps, int
  * (update == 0) or on their meta_data%dqdt_3d (update != 0), as update_winds does for windtype kCONSERVE_MASS */
 int icar_hip_mass_conservative_acceleration(icar_hip_ctx *ctx, int update);
 
+/* ---- update_winds (src/physics/wind.f90:289-369) in ONE call ------------------------------------
+ * make_winds_grid_relative -> [linear_perturb (windtype 1, 5)] -> [mass_conservative_acceleration (2)] ->
+ * [iterative_winds (3, 5): exchange_u / exchange_v, balance_uvw, correct_w, wind_iterations+1 x { sweep; exchange_u;
+ * exchange_v } (:371-498)] -> balance_uvw, on u, v, w (update = 0: the first call of a run) or on their
+ * meta_data%dqdt_3d (update = 1: every later forcing step); update < 0 lets the context decide like the reference's
+ * `if (.not.allocated(domain%sintheta))`.  The staggered exchanges use the context's communicator (icar_hip_comm_init /
+ * _init_host), so a multi-image host gets the same winds as a single-image one on the cells it owns.  dx = domain%dx,
+ * halo = grid%halo_size, wind_iterations = options%parameters%wind_iterations.  Needs what the parts need: SINTHETA /
+ * COSTHETA uploaded (init_winds, :512-590), the linear-wind LUT built for windtype 1 / 5, ZR_U / ZR_V for 2. */
+int icar_hip_update_winds(icar_hip_ctx *ctx, int windtype, int wind_iterations, float dx, int halo, int update);
+/* `call domain%u%exchange_u(); call domain%v%exchange_v()` (src/objects/exchangeable_obj.f90:158-229) on u, v
+ * (update = 0) or their dqdt_3d (1): one message per neighbour through the context's communicator.  Collective. */
+int icar_hip_exchange_uv(icar_hip_ctx *ctx, int halo, int update);
+
 /* ---- W3: linear-theory wind look-up table (src/physics/linear_winds.f90) ----------------------
  * options%lt_options (src/objects/options_obj.f90:1400-1530; defaults there: buffer 50, stability_window_size 10,
  * vert_smooth 10, max/min_stability 6e-4/1e-7, N_squared 3e-5, linear_contribution 1, linear_update_fraction 0.2,
