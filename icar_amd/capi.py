@@ -23,7 +23,7 @@ SYMBOLS = [
     "icar_hip_apply_forcing", "icar_hip_enforce_limits", "icar_hip_halo_count", "icar_hip_halo_pack",
     "icar_hip_halo_unpack", "icar_hip_halo_pack_dirs", "icar_hip_halo_unpack_dirs", "icar_hip_timing_enable", "icar_hip_timing_read", "icar_hip_timing_reset",
     "icar_hip_last_error", "icar_hip_version",
-    "icar_hip_comm_unique_id", "icar_hip_comm_init", "icar_hip_comm_init_host", "icar_hip_comm_destroy", "icar_hip_comm_kind", "icar_hip_comm_ranks", "icar_hip_halo_selfcheck",
+    "icar_hip_comm_unique_id", "icar_hip_comm_init", "icar_hip_comm_init_host", "icar_hip_comm_destroy", "icar_hip_comm_kind", "icar_hip_comm_ranks", "icar_hip_comm_timeout", "icar_hip_halo_selfcheck",
     "icar_hip_halo_send", "icar_hip_halo_retrieve", "icar_hip_co_min", "icar_hip_co_max",
     "icar_hip_step_configure", "icar_hip_model_time_set", "icar_hip_model_time", "icar_hip_mp_reset", "icar_hip_compute_dt",
     "icar_hip_update_dt", "icar_hip_mp", "icar_hip_advect_step", "icar_hip_substep", "icar_hip_step", "icar_hip_step_n",

@@ -292,7 +292,9 @@ bool icar_cfl_prefetched_global(icar_hip_ctx *c, float dx, const float *dz_level
 {
     if (!cfl_prefetched(c, dx, dz_levels) || !c->cfl_pre.reduced) return false;
     c->cfl_pre.valid = false;
-    if (hipEventSynchronize(c->cfl_ev) != hipSuccess) return false;
+    // (a failed wait is an error of this image alone; falling back to a fresh reduction here would issue an all-reduce the other
+    // images do not pair -- the value is handed out as NaN and compute_dt reports it)
+    if (hipEventSynchronize(c->cfl_ev) != hipSuccess) { *value = __builtin_nanf(""); return true; }
     *value = *c->h_cfl_pre;
     return true;
 }

@@ -79,7 +79,7 @@ struct alignas(64) ShmBox { std::atomic<uint64_t> seq; std::atomic<uint64_t> ack
 struct alignas(64) ShmRed { std::atomic<uint64_t> seq; double val[2]; };
 struct ShmHeader { uint64_t magic, nranks, slot_bytes; };
 constexpr uint64_t kMagic = 0x4943415248495031ull;          // "ICARHIP1"
-constexpr double kWaitSeconds = 60.0;                        // a lost neighbour is an error, not a hang
+double g_wait_seconds = 60.0;                                // a lost neighbour is an error, not a hang (icar_hip_comm_timeout)
 
 inline int opposite(int d) { return d ^ 1; }                 // north 0 <-> south 1, east 2 <-> west 3
 
@@ -141,6 +141,7 @@ static int ensure_buffers(icar_hip_ctx *c, IcarComm *m, int h, int nf)
         if (n <= m->cap[d]) continue;
         if (m->sbuf[d]) { hipFree(m->sbuf[d]); m->sbuf[d] = nullptr; }
         if (m->rbuf[d]) { hipFree(m->rbuf[d]); m->rbuf[d] = nullptr; }
+        m->cap[d] = 0;                                       // nothing usable until every allocation below has succeeded
         HIPCHK(hipMalloc(&m->sbuf[d], n * sizeof(float)));
         if (has_peer(m, d)) HIPCHK(hipMalloc(&m->rbuf[d], n * sizeof(float)));
         if (m->kind == ICAR_COMM_HOST && has_peer(m, d)) {
@@ -160,8 +161,8 @@ static int spin_until(Pred p, const char *what)
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 0; !p(); ++it) {
         if ((it & 1023) == 1023) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kWaitSeconds) {
-                icar_set_error(std::string(what) + ": no answer from a neighbouring image within 60 s"); return 1;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > g_wait_seconds) {
+                icar_set_error(std::string(what) + ": no answer from a neighbouring image within the wait limit (icar_hip_comm_timeout)"); return 1;
             }
             std::this_thread::yield();
         }
@@ -548,6 +549,13 @@ int icar_hip_co_max(icar_hip_ctx *c, double *value)
 }
 
 int icar_hip_comm_kind(icar_hip_ctx *c) { return (c && c->comm) ? c->comm->kind : ICAR_COMM_NONE; }
+
+int icar_hip_comm_timeout(double seconds)
+{
+    if (!(seconds > 0.0)) { icar_set_error("comm_timeout: seconds > 0"); return 1; }
+    g_wait_seconds = seconds;
+    return 0;
+}
 
 // How many images the transport itself says it connects: ncclCommCount of the RCCL communicator, the header of the shared
 // segment of the host-staged transport, 1 without a transport.

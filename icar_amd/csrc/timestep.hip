@@ -48,9 +48,11 @@ int icar_mp_run(icar_hip_ctx *c, double dt_in, int halo, int subset)
     const icar_hip_step_config &g = c->step.cfg;
     if (g.microphysics == 0) return 0;
     IcarStepState &st = c->step;
+    // the reference passes real(dt%seconds()) -- a REAL(4) -- into this arithmetic (time_step.f90:512, mp_driver.f90:673)
+    const double dt4 = (double)(float)dt_in;
     const double upd = (double)g.mp_update_interval, now = st.model_time;
-    if (st.mp_last_model_time == -999.0) st.mp_last_model_time = now - (upd > dt_in ? upd : dt_in);       // :698-702
-    if (((now + dt_in) - st.mp_last_model_time) < upd) return 0;                                          // :705
+    if (st.mp_last_model_time == -999.0) st.mp_last_model_time = now - (upd > dt4 ? upd : dt4);           // :698-702
+    if (((now + dt4) - st.mp_last_model_time) < upd) return 0;                                            // :705
     const float mp_dt = (float)(now - st.mp_last_model_time);                                             // :708
     if (halo < 0) st.mp_last_model_time = now;                                                             // :711-713 (not on the halo pass)
     int kte = g.kte;
@@ -142,6 +144,7 @@ static int compute_dt(icar_hip_ctx *c, float *dt_out, bool *on_device)
             maxwind3d = fmaxf(maxwind1d, maxwind3d);
         } else if (strict == 4) maxwind3d = maxwind3d * sqrt3;                                                  // :302-305
     }
+    if (!(maxwind3d == maxwind3d)) { icar_set_error("compute_dt: the prefetched CFL maximum could not be read (HIP event wait failed)"); return 1; }
     const float dt = g.cfl_reduction_factor / maxwind3d;                                                       // :313
     if (dt < 1e-1f) { icar_set_error("ERROR time step too small"); return 1; }                                 // :322-328 `stop`
     *dt_out = dt;
@@ -190,7 +193,17 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
     if (!stepping) return 0;
 
     // :512-526  mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
-    if (g.microphysics != 0) {
+    if (g.microphysics != 0 && g.halo_size > 1) {
+        // halo_send packs the first halo_size owned rows / columns, mp(halo=1) only processes the outermost one: with a halo wider
+        // than 1 the message carries cells the interior pass has not touched yet (the reference sends them in that state,
+        // time_step.f90:512-523).  Beside the interior launch the pack would read them while they are written, so this
+        // configuration keeps the reference's order on one stream.
+        if (icar_mp_run(c, dt, 1, -1)) return 1;                                  // :512
+        if (halo_send(c)) return 1;                                               // :515
+        if (icar_mp_run(c, dt, -1, 1)) return 1;                                  // :523
+        if (face_later && icar_diagnostic_update_run(c, ICAR_DIAG_FACE)) return 1;
+        if (halo_retrieve(c)) return 1;                                           // :526
+    } else if (g.microphysics != 0) {
         // The interior launch is the critical path of this block, so IT stays on the main stream (diag -> interior -> unpack ->
         // advect are then same-stream neighbours); the side work -- strips, pack + transfer, and the wind setup of the advect()
         // that follows -- goes to the second stream and has finished long before the join.  (Rounds 1-2 had it the other way
@@ -317,6 +330,7 @@ int icar_hip_step_configure(icar_hip_ctx *c, const icar_hip_step_config *cfg, co
     for (int m = 0; m < cfg->n_exchange; ++m) if (cfg->exchange_fields[m] < 0 || cfg->exchange_fields[m] >= ICAR_N_ADVECTABLE) { icar_set_error("step_configure: exchange_fields holds advectable scalars"); return 1; }
     if (cfg->cfl_strictness < 1 || cfg->cfl_strictness > 5) { icar_set_error("step_configure: cfl_strictness is 1..5"); return 1; }
     if (cfg->halo_size < 1) { icar_set_error("step_configure: halo_size >= 1"); return 1; }
+    if (c->d.nz > 4096) { icar_set_error("step_configure: the CFL reduction holds dz_levels of at most 4096 levels"); return 1; }
     if (cfg->its < c->ims || cfg->ite > c->ime || cfg->jts < c->jms || cfg->jte > c->jme || cfg->kts < c->kms || cfg->kte > c->kme) {
         icar_set_error("step_configure: its..kte outside the ims..kme of the context"); return 1;
     }

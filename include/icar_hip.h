@@ -384,6 +384,9 @@ int icar_hip_comm_init(icar_hip_ctx *ctx, int nranks, int rank, const char uid[1
 int icar_hip_comm_init_host(icar_hip_ctx *ctx, int nranks, int rank, const char *shm_name, size_t slot_bytes, const int neighbors[4]);
 int icar_hip_comm_destroy(icar_hip_ctx *ctx);
 int icar_hip_comm_kind(icar_hip_ctx *ctx);                      /* ICAR_COMM_* */
+/* how long the host-staged transport waits for a neighbouring image before it reports an error (default 60 s; a debugger or
+ * a long host pause on a neighbour wants more).  Process-wide. */
+int icar_hip_comm_timeout(double seconds);
 /* num_images() as the transport itself reports it (ncclCommCount / the shared segment's header; 1 without a transport) */
 int icar_hip_comm_ranks(icar_hip_ctx *ctx, int *nranks);
 /* A self-test of exchangeable_t%send / %retrieve (src/objects/exchangeable_obj.f90:138-356) on this communicator: one
