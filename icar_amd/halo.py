@@ -263,8 +263,10 @@ def co_min(value, group=None, device=None):
     """time_step.f90:413 `call co_min(seconds)`: all-reduce(min) of one REAL(8)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(value)
-    if device is None:                                  # RCCL reduces device memory only; callers with a device tile pass its device
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    if device is None:
+        if dist.get_backend(group) == "nccl":           # RCCL reduces device memory only: the caller names its tile's device (domain.device)
+            raise ValueError("co_min over RCCL needs device=domain.device (the product path is domain_t.co_min -> icar_hip_co_min)")
+        device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return float(t.item())

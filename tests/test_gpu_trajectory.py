@@ -44,6 +44,10 @@ def _advect_oracle(orc, s, c, dt, names):
 # half an ulp (6e-8) of the local value after every advection diverges from itself by the same amounts
 # (tests/test_oracle_trajectory_sensitivity.py).  Bounds = 2x measured.
 TRAJ_BOUNDS = {"thompson": dict(beyond=0.26, absmax=0.22), "simple": dict(beyond=0.38, absmax=0.29)}
+# round 4: the guard bites earlier.  Measured after sub-steps 2 and 3 (MI355X, worst field): Thompson 0.053 / 0.082 and 0.102 / 0.142
+# (fraction beyond 1e-5 / max |d| over the field maximum), mp_simple 0.091 / 7.4e-5 and 0.112 / 0.029; bounds = 2x measured.
+EARLY_BOUNDS = {"thompson": {2: dict(beyond=0.11, absmax=0.17), 3: dict(beyond=0.21, absmax=0.29)},
+                "simple": {2: dict(beyond=0.19, absmax=1.5e-4), 3: dict(beyond=0.23, absmax=0.058)}}
 FIRST_STEP_BOUNDS = dict(beyond=1.3e-5, absmax=6e-7)
 
 
@@ -76,7 +80,7 @@ def test_trajectory_ten_unsynchronised_substeps(th_oracle, oracle, scheme):
                           s["rain"], s["snow"], rain, snow, dt, c["dz_mass"], 2, nx - 1, 2, ny - 1, 1, nz)
             acc += rain
         _advect_oracle(orc, s, c, dt, names)
-        if it in (0, 4, nsteps - 1):
+        if it in (0, 1, 2, 4, nsteps - 1):
             stats = {}
             for n in names:
                 got = d.get(MEMBER[n])
@@ -92,7 +96,8 @@ def test_trajectory_ten_unsynchronised_substeps(th_oracle, oracle, scheme):
     b = TRAJ_BOUNDS[scheme]
     assert worst[1]["beyond_rtol_frac"] <= FIRST_STEP_BOUNDS["beyond"] and worst[1]["max_abs_over_max"] <= FIRST_STEP_BOUNDS["absmax"], (scheme, worst[1])
     for it, w in worst.items():
-        assert w["beyond_rtol_frac"] <= b["beyond"] and w["max_abs_over_max"] <= b["absmax"], (scheme, it, w)
+        bb = EARLY_BOUNDS[scheme].get(it, b)
+        assert w["beyond_rtol_frac"] <= bb["beyond"] and w["max_abs_over_max"] <= bb["absmax"], (scheme, it, w)
     assert rel_p <= 1e-3, rel_p
     d.close()
 
