@@ -80,6 +80,7 @@ def build_tile(args, rank, world, device):
 
 # the kernels one advect() call launches, per scheme (the roofline's `kernel` label; also the key of profiles/advect_traffic.json)
 ADVECT_KERNELS = {"mpdata": "k_mpdata_fused", "upwind": "k_upwind_pass"}
+SETUP_KERNELS = ("k_setup_winds", "k_mpdata_coef")      # launched once per step for the advect() call (timer group "winds")
 # bumped whenever the advection kernels change what they read or write: profiles/advect_traffic.json (PMC passes) belongs to one
 KERNEL_GENERATION = "r03: scalar-independent MPDATA coefficients precomputed (k_mpdata_coef)"
 
@@ -281,20 +282,28 @@ def probe_traffic(args):
         try:
             subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
                            cwd="/tmp", env=env, timeout=90, capture_output=True)      # (a child takes ~12 s; a stuck profiler costs the line 90 s, not the run)
-            vals = []
+            vals = []; setup = {k: [] for k in SETUP_KERNELS}
             for fn in glob.glob(os.path.join(out, "**", "p_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(fn)):
-                    if ADVECT_KERNELS[args.adv] in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                    if r["Counter_Name"] != ctr:
+                        continue
+                    if ADVECT_KERNELS[args.adv] in r["Kernel_Name"]:
                         vals.append(float(r["Counter_Value"]))
+                    for k in SETUP_KERNELS:
+                        if k in r["Kernel_Name"]:
+                            setup[k].append(float(r["Counter_Value"]))
             if not vals:
                 return None
             got[ctr] = sum(vals) / len(vals)
+            # the once-per-step setup of the advection (Courant winds; the scalar-independent MPDATA coefficients): mean per dispatch each
+            got[ctr + "_setup"] = sum(sum(v) / len(v) for k, v in setup.items() if v and (args.adv == "mpdata" or k == "k_setup_winds"))
         except Exception:
             return None
         finally:
             shutil.rmtree(out, ignore_errors=True)
     rd, wr = 2.0 * 1024.0 * got["FETCH_SIZE"], 1024.0 * got["WRITE_SIZE"]          # KiB units; x2: see above
-    return rd + wr, rd, wr
+    setup_bytes = 2.0 * 1024.0 * got["FETCH_SIZE_setup"] + 1024.0 * got["WRITE_SIZE_setup"]
+    return rd + wr, rd, wr, setup_bytes
 
 
 def spawn_ranks(n):
@@ -509,6 +518,10 @@ def main():
                          # the once-per-step setup of the advection (Courant winds + the scalar-independent MPDATA coefficients),
                          # issued beside the interior microphysics; not part of avg_ms
                          "setup_ms_per_step": winds_ms,
+                         # the advection GROUP of a step = advect() + its setup kernels, whatever they run beside: same algorithmic
+                         # bytes (the setup reads nothing the 8N+16 model does not already count) over the sum of the two timers
+                         "group_ms": adv_ms + winds_ms,
+                         "frac_group": (alg_bytes / ((adv_ms + winds_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if adv_ms + winds_ms > 0 else None,
                          # informational: scalar-cell updates/s of the advection alone, and the measured
                          # streaming-copy bandwidth of this box beside the spec peak that `frac` uses
                          "advect_scalar_cell_updates_per_s": (mem_cells * nscal / (adv_ms * 1e-3)) if adv_ms > 0 else None,
@@ -524,6 +537,8 @@ def main():
             t = probe_traffic(args)
             if t is not None:
                 out["roofline"].update({"traffic": t[0], "traffic_read_bytes": t[1], "traffic_write_bytes": t[2],
+                                        "traffic_setup_bytes": t[3], "traffic_group": t[0] + t[3],
+                                        "traffic_group_over_algorithmic": (t[0] + t[3]) / alg_bytes,
                                         "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x 2 for gfx950) over "
                                                           "3-step child runs of this configuration, mean per dispatch of " + ADVECT_KERNELS[args.adv]})
         if not args.no_cpu_baseline and world == 1:          # the CPU legs are timed at N=1 only (the other ranks would idle at the barrier)

@@ -16,6 +16,7 @@ the Schaer blob), linear interpolation in height, the terrain-following coordina
 import numpy as np
 from scipy.io import netcdf_file
 from . import ideal
+from ._netcdf import open_classic, FORMAT_NOTE
 
 G, RD, CP = 9.81, 287.058, 1003.5                       # Forcing.py:352-356
 
@@ -58,6 +59,7 @@ def write_init(path, nx, ny, dx=1000.0, dy=1000.0, hill_height=1000.0, n_hills=1
     lat, lon = lat_lon(nx, ny, dx, dy, lat0, lon0)
     lon2, lat2 = np.meshgrid(lon, lat)
     with netcdf_file(path, "w", version=2) as f:
+        f.format_note = FORMAT_NOTE
         f.TITLE = "OUTPUT FROM CONTINUOUS INTEGRATION TEST"; f.GRIDTYPE = "C"; f.DX = float(dx); f.DY = float(dy)   # Topography.py:213-222
         f.createDimension("lat", ny); f.createDimension("lon", nx)
         for name, arr, units, desc in (("lat_hi", lat2, "degrees latitude", "Latitude on mass grid"),
@@ -77,6 +79,7 @@ def write_forcing(path, nt, nz, nx, ny, dz_value=500.0, dx=1000.0, dy=1000.0, u_
     theta = calc_wk_theta(z1); p = calc_pressure_from_sea(sealevel_pressure, z1)
     temp = theta * (p / 100000.0) ** (RD / CP)                                          # Forcing.py:382-383
     with netcdf_file(path, "w", version=2) as f:
+        f.format_note = FORMAT_NOTE
         f.createDimension("time", None); f.createDimension("level", nz); f.createDimension("lat", ny); f.createDimension("lon", nx)
         f.createDimension("x_m", nx)
         d4 = ("time", "level", "lat", "lon")
@@ -98,7 +101,7 @@ def read_ideal_case(init_file, forcing_file, dz_levels, dx, time_index=0, n_hydr
     range); exner / density from the interpolated pressure and potential temperature; u, v staggered from the mass-point winds;
     w from balance_uvw.  dz_levels = options%parameters%dz_levels, dx = options%parameters%dx."""
     f32 = np.float32
-    with netcdf_file(init_file, "r", mmap=False) as f:
+    with open_classic(init_file) as f:
         terrain = np.array(f.variables["hgt_hi"][:], f32)
         lat_hi = np.array(f.variables["lat_hi"][:]); lon_hi = np.array(f.variables["lon_hi"][:])
     ny, nx = terrain.shape
@@ -108,7 +111,7 @@ def read_ideal_case(init_file, forcing_file, dz_levels, dx, time_index=0, n_hydr
     if uniform is None and not np.array_equal(dzl32, ideal.dz_levels(nz)):
         raise ValueError("read_ideal_case: dz_levels must be uniform or the default level table (icar_amd.ideal.dz_levels)")
     case = ideal.make_case(nx, ny, nz, dx=dx, terrain=terrain, n_hydro=n_hydro, uniform_dz=uniform)     # the geometry: jacobians, dz
-    with netcdf_file(forcing_file, "r", mmap=False) as f:
+    with open_classic(forcing_file) as f:
         lat_m = np.array(f.variables["lat_m"][:]); lon_m = np.array(f.variables["lon_m"][:])
         fz = np.array(f.variables["z"][time_index]); fields = {k: np.array(f.variables[k][time_index]) for k in ("u", "v", "theta", "qv", "pressure")}
     # geographic look-up: nearest forcing column (geo.f90's bilinear weights reduce to it where the two grids coincide)

@@ -162,6 +162,8 @@ def write_LUT(filename, domain, options):
         for k, val in _lut_attr_values(options.lt_options).items():
             setattr(f, k, val)
         f.lt_LUT_version = LT_LUT_VERSION
+        from ._netcdf import FORMAT_NOTE
+        f.format_note = FORMAT_NOTE
 
 
 def read_LUT(filename, domain, options):
@@ -172,7 +174,8 @@ def read_LUT(filename, domain, options):
     if not os.path.exists(filename):
         return 1
     error = 0
-    with netcdf_file(filename, "r", mmap=False) as f:
+    from ._netcdf import open_classic
+    with open_classic(filename) as f:
         ver = getattr(f, "lt_LUT_version", b"")
         error += (ver.decode() if isinstance(ver, bytes) else str(ver)) != LT_LUT_VERSION
         for k, val in _lut_attr_values(options.lt_options).items():

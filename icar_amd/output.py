@@ -107,6 +107,8 @@ class output_t:
                 f.git = self.version
                 for k, val in self.attributes:
                     setattr(f, k, val)
+                from ._netcdf import FORMAT_NOTE
+                f.format_note = FORMAT_NOTE
                 f.history = "Created:" + datetime.datetime.now().strftime("%Y/%m/%d %H:%M:%S")
                 f.image = np.int32(self.image)
             rec = current_step - 1
@@ -124,9 +126,9 @@ class output_t:
 
 def read_file(filename):
     """{file variable name: array} (+ "_dimensions", "_attributes") -- restart-style reader of the files above."""
-    from scipy.io import netcdf_file
+    from ._netcdf import open_classic
     out = {}
-    with netcdf_file(filename, "r", mmap=False) as f:
+    with open_classic(filename) as f:
         out["_dimensions"] = {k: (None if v is None else int(v)) for k, v in f.dimensions.items()}
         out["_attributes"] = {k: getattr(f, k) for k in f._attributes}
         for k, v in f.variables.items():

@@ -19,8 +19,8 @@ def read_restart_data(domain, dataset, filename, time_step):
     """restart.f90:22-81.  time_step is the 1-based record (restart_step_in_file).  3-D variables come back from the
     file's (level, lat, lon) to data_3d(i,k,j) like `reshape(data_3d, order=[1,3,2])` (:52); sizes must match the
     current decomposition or the run stops like restart_domain_error (:102-110)."""
-    from scipy.io import netcdf_file
-    with netcdf_file(filename, "r", mmap=False) as f:
+    from ._netcdf import open_classic
+    with open_classic(filename) as f:
         for n in dataset.variables:
             name, dims, _ = METADATA[n]
             if name not in f.variables:

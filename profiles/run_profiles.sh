@@ -6,7 +6,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
-RND=${1:-r03}
+RND=${1:-r04}
 O=gpurun_out/$RND; rm -rf $O; mkdir -p $O
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err      # the driver's command
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"

@@ -4,6 +4,7 @@ interpolation against the generating formulas.  The run from these files is test
 import os
 import sys
 import numpy as np
+import pytest
 from scipy.io import netcdf_file
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
@@ -55,3 +56,27 @@ def test_reader_builds_the_domain_members(tmp_path):
     assert abs(z[j, 0, i] - (M.HILL_HEIGHT + 0.5 * dzl[0] * c["jacobian"][j, 0, i])) < 1e-2
     assert np.abs(c["w"]).max() > 0.05                      # flow over the hill has vertical motion (balance_uvw)
     assert np.abs(c["w"][0]).max() < 0.1 * np.abs(c["w"]).max()      # nearly flat at the domain edge
+
+
+def test_netcdf4_files_are_refused_with_advice(tmp_path):
+    """The reference's generators (xarray) and its own output / LUT writers produce NetCDF-4 / HDF5; this build has no HDF5
+    library.  Every reader must say so -- with the conversion that makes the file readable -- instead of failing inside scipy."""
+    from icar_amd.capi import IcarHipError
+    from icar_amd import ideal_io, output
+    from icar_amd._netcdf import HDF5_SIGNATURE, FORMAT_NOTE
+    h5 = tmp_path / "init.nc"
+    h5.write_bytes(HDF5_SIGNATURE + b"\0" * 512)
+    ok = tmp_path / "forcing.nc"
+    ideal_io.write_forcing(str(ok), 1, 4, 6, 5)
+    for call in (lambda: ideal_io.read_ideal_case(str(h5), str(ok), [200.0] * 4, 1000.0),
+                 lambda: output.read_file(str(h5))):
+        with pytest.raises(IcarHipError) as e:
+            call()
+        assert "NetCDF-4" in str(e.value) and "nccopy -k classic" in str(e.value)
+    junk = tmp_path / "junk.nc"; junk.write_bytes(b"not a netcdf file")
+    with pytest.raises(IcarHipError):
+        output.read_file(str(junk))
+    # and what this package writes says what it is
+    back = output.read_file(str(ok))
+    note = back["_attributes"]["format_note"]
+    assert (note.decode() if isinstance(note, bytes) else note) == FORMAT_NOTE
