@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-later-window", action="store_true", help="skip the second (untimed-region) window 100 steps later")
     ap.add_argument("--no-traffic-probe", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
+    ap.add_argument("--thompson-layout", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="profiling: thread layout of the Thompson interior launch (icar_hip_thompson_layout; 0 = the library's default)")
     ap.add_argument("--ref-child", default=None, help=argparse.SUPPRESS)      # internal: cpu_reference()'s child process
     ap.add_argument("--ref-nscal", type=int, default=9, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -372,6 +374,8 @@ def main():
     from icar_amd import capi
     d, opt, case, g = build_tile(args, rank, world, dev_index)
     lib = capi.lib()
+    if args.thompson_layout:
+        capi.check(lib.icar_hip_thompson_layout(d.ctx, args.thompson_layout), "icar_hip_thompson_layout")
     kind = int(lib.icar_hip_comm_kind(d.ctx))
     nscal = sum(1 for v in opt.vars_to_advect.values() if v > 0)
 

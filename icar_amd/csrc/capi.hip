@@ -591,7 +591,7 @@ int icar_hip_thompson_tiles(icar_hip_ctx *c, float dt, int ntiles, const int til
 
 int icar_hip_thompson_layout(icar_hip_ctx *c, int layout)
 {
-    if (!c || layout < 0 || layout > 2) { icar_set_error("thompson_layout: ctx and layout in 0..2"); return 1; }
+    if (!c || layout < 0 || layout > 3) { icar_set_error("thompson_layout: ctx and layout in 0..3"); return 1; }
     c->th_layout = layout;
     return 0;
 }

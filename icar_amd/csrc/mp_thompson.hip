@@ -281,6 +281,45 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 //           keeps that history in LDS (one 256-B row per sub-step and moment), reads row n, overwrites it with its own flux.
 // No barriers, no cross-lane traffic.  If a wave's sub-step counts do not fit its LDS rows the sub-steps are done in chunks,
 // one extra sweep over the workspace per chunk.
+/* :2660-2770, the sub-steps n of one chunk for one level; `up` = what left the level above in the same sub-step (row r of the
+ * species' flux history), overwritten with this level's own flux.  Two-moment (rain, cloud ice) and one-moment (snow, graupel) forms. */
+#define TH_SED2(S, HM, HN, VM, VN, QM, QN, TM, TN, FLOORN, PPT)                                                      \
+    for (int n = sw * C[S] + 1, r = 0; r < C[S] && n <= nw[S]; ++n, ++r) {                                          \
+        if (n <= nstep[S]) {                                                                                         \
+            const float sed_m = VM * QM, sed_n = VN * QN;                                                            \
+            const float up_m = (k < kte) ? HM[64 * r] : 0.f, up_n = (k < kte) ? HN[64 * r] : 0.f;                    \
+            if (k == kte) {                                                                                          \
+                TM = TM - sed_m * odzq * onstep[S] * orho;                                                           \
+                TN = TN - sed_n * odzq * onstep[S] * orho;                                                           \
+                QM = fmaxf(R1, QM - sed_m * odzq * dt * onstep[S]);                                                  \
+                QN = fmaxf(FLOORN, QN - sed_n * odzq * dt * onstep[S]);                                              \
+            } else if (k <= ksed1[S]) {                                                                              \
+                TM = TM + (up_m - sed_m) * odzq * onstep[S] * orho;                                                  \
+                TN = TN + (up_n - sed_n) * odzq * onstep[S] * orho;                                                  \
+                QM = fmaxf(R1, QM + (up_m - sed_m) * odzq * dt * onstep[S]);                                         \
+                QN = fmaxf(FLOORN, QN + (up_n - sed_n) * odzq * dt * onstep[S]);                                     \
+            }                                                                                                        \
+            if (k == 0 && QM > R1 * 10.f) PPT = PPT + sed_m * dt * onstep[S];                                        \
+            HM[64 * r] = sed_m; HN[64 * r] = sed_n;                                                                  \
+        }                                                                                                            \
+    }
+#define TH_SED1(S, HM, VM, QM, TM, PPT)                                                                               \
+    for (int n = sw * C[S] + 1, r = 0; r < C[S] && n <= nw[S]; ++n, ++r) {                                          \
+        if (n <= nstep[S]) {                                                                                         \
+            const float sed_m = VM * QM;                                                                             \
+            const float up_m = (k < kte) ? HM[64 * r] : 0.f;                                                         \
+            if (k == kte) {                                                                                          \
+                TM = TM - sed_m * odzq * onstep[S] * orho;                                                           \
+                QM = fmaxf(R1, QM - sed_m * odzq * dt * onstep[S]);                                                  \
+            } else if (k <= ksed1[S]) {                                                                              \
+                TM = TM + (up_m - sed_m) * odzq * onstep[S] * orho;                                                  \
+                QM = fmaxf(R1, QM + (up_m - sed_m) * odzq * dt * onstep[S]);                                         \
+            }                                                                                                        \
+            if (k == 0 && QM > R1 * 10.f) PPT = PPT + sed_m * dt * onstep[S];                                        \
+            HM[64 * r] = sed_m;                                                                                      \
+        }                                                                                                            \
+    }
+
 struct MarchComm {
     int k; bool active;
     double run_min[2]; float ca[2][4];
@@ -396,48 +435,10 @@ k_thompson_march(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, 
                 h.qcten = hv[18]; h.qvten = hv[19]; h.tten = hv[20]; h.rho = hv[21]; h.temp = hv[22]; h.ocp = hv[23]; h.lvap = hv[24];
                 const float odzq = 1.f / dz[c], orho = 1.f / h.rho;
                 /* :2660-2770, sub-steps n of this chunk; `up` = what left the level above in the same sub-step */
-#define TH_SED2(S, HM, HN, VM, VN, QM, QN, TM, TN, FLOORN, PPT)                                                          \
-                for (int n = sw * C[S] + 1, r = 0; r < C[S] && n <= nw[S]; ++n, ++r) {                                \
-                    if (n <= nstep[S]) {                                                                               \
-                        const float sed_m = VM * QM, sed_n = VN * QN;                                                  \
-                        const float up_m = (k < kte) ? HM[64 * r] : 0.f, up_n = (k < kte) ? HN[64 * r] : 0.f;          \
-                        if (k == kte) {                                                                                \
-                            TM = TM - sed_m * odzq * onstep[S] * orho;                                                 \
-                            TN = TN - sed_n * odzq * onstep[S] * orho;                                                 \
-                            QM = fmaxf(R1, QM - sed_m * odzq * dt * onstep[S]);                                        \
-                            QN = fmaxf(FLOORN, QN - sed_n * odzq * dt * onstep[S]);                                    \
-                        } else if (k <= ksed1[S]) {                                                                    \
-                            TM = TM + (up_m - sed_m) * odzq * onstep[S] * orho;                                        \
-                            TN = TN + (up_n - sed_n) * odzq * onstep[S] * orho;                                        \
-                            QM = fmaxf(R1, QM + (up_m - sed_m) * odzq * dt * onstep[S]);                               \
-                            QN = fmaxf(FLOORN, QN + (up_n - sed_n) * odzq * dt * onstep[S]);                           \
-                        }                                                                                              \
-                        if (k == 0 && QM > R1 * 10.f) PPT = PPT + sed_m * dt * onstep[S];                              \
-                        HM[64 * r] = sed_m; HN[64 * r] = sed_n;                                                        \
-                    }                                                                                                  \
-                }
-#define TH_SED1(S, HM, VM, QM, TM, PPT)                                                                                 \
-                for (int n = sw * C[S] + 1, r = 0; r < C[S] && n <= nw[S]; ++n, ++r) {                                \
-                    if (n <= nstep[S]) {                                                                               \
-                        const float sed_m = VM * QM;                                                                   \
-                        const float up_m = (k < kte) ? HM[64 * r] : 0.f;                                               \
-                        if (k == kte) {                                                                                \
-                            TM = TM - sed_m * odzq * onstep[S] * orho;                                                 \
-                            QM = fmaxf(R1, QM - sed_m * odzq * dt * onstep[S]);                                        \
-                        } else if (k <= ksed1[S]) {                                                                    \
-                            TM = TM + (up_m - sed_m) * odzq * onstep[S] * orho;                                        \
-                            QM = fmaxf(R1, QM + (up_m - sed_m) * odzq * dt * onstep[S]);                               \
-                        }                                                                                              \
-                        if (k == 0 && QM > R1 * 10.f) PPT = PPT + sed_m * dt * onstep[S];                              \
-                        HM[64 * r] = sed_m;                                                                            \
-                    }                                                                                                  \
-                }
                 TH_SED2(0, H0, H1, h.vtrk, h.vtnrk, h.rr, h.nr, h.qrten, h.nrten, R2, pptrain)
                 TH_SED2(1, H2, H3, h.vtik, h.vtnik, h.ri, h.ni, h.qiten, h.niten, R2, pptice)
                 TH_SED1(2, H4, h.vtsk, h.rs, h.qsten, pptsnow)
                 TH_SED1(3, H5, h.vtgk, h.rg, h.qgten, pptgraul)
-#undef TH_SED2
-#undef TH_SED1
                 if (!last) {                                             /* park what the sub-steps moved for the next chunk */
                     float *wr = ws + (size_t)k * TH_NHAND * a.ncolp + col;
                     const float back[12] = {h.rr, h.nr, h.ri, h.ni, h.rs, h.rg, h.qrten, h.nrten, h.qiten, h.niten, h.qsten, h.qgten};
@@ -464,6 +465,245 @@ k_thompson_march(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, 
         }
     }
     if (on) {
+        const int c2 = ii + d.nx * jj;
+        const float rainnc = 0.f + pptrain + pptsnow + pptgraul + pptice;
+        const float snownc = 0.f + pptsnow + pptice;
+        const float graupelnc = 0.f + pptgraul;
+        rain_acc[c2] = rain_acc[c2] + rainnc;
+        snow_acc[c2] = snow_acc[c2] + snownc;
+        graupel_acc[c2] = graupel_acc[c2] + graupelnc;
+    }
+}
+
+
+// ---- 64 columns x 4 levels per block ("slab"), marching down the column in slabs (round 4) ---------------------------------------
+// The lane mapping of k_thompson_march (a wave = 64 neighbouring columns of ONE level) with the register budget and the
+// parallelism of k_thompson_pack: a 256-thread block owns 64 columns; wave w works on level kte - (4 s + w) of slab s, so a
+// thread still holds ONE level at a time (168 VGPRs, 3 waves per SIMD) and four levels of a column advance together.  The
+// vertical couplings stay top-down: inside a slab they go through LDS (4 waves that work on ADJACENT levels of the same
+// columns: balanced, their barriers are short); what a column carries from slab to slab -- the two running minima of the
+// graupel intercept, the fall speeds of the nearest level above, the sub-step counts -- lives in LDS, not in registers.
+//   sweep 1  per slab: point physics (:1240-2650), ThHand -> HBM workspace (as k_thompson_march)
+//   sweep 2a wave w sediments species w (rain, cloud ice, snow, graupel: independent of each other, :2660-2770) down the whole
+//            column, flux history of the level above in LDS rows, final tendencies back to the workspace
+//   sweep 2b per slab: melt / freeze / update (:2777-2842) and the stores of the fields
+struct SlabLds {
+    double sm[4][64];                 // suffix_min exchange of a slab
+    double carry_min[2][64];          // running minimum of each chain over the slabs above
+    float cdv[4][4][64]; int cdh[4][2][64];
+    float carry_vt[2][4][64];         // fall speeds of the nearest level above that holds the species (after its carry-down)
+    int ns[4][64], ks[4][64];         // per column: max sub-step count, highest level with a sedimenting particle
+    int quiet[64];
+    float ppt[4][64];
+    float hist[TH_MARCH_ROWS * 64];
+};
+
+struct SlabComm {
+    SlabLds *L; int w, lane, k; bool active;
+    __device__ __forceinline__ bool any(bool) { return true; }
+    __device__ __forceinline__ double suffix_min(double v, int which)
+    {
+        L->sm[w][lane] = v;
+        __syncthreads();
+        double r = L->carry_min[which][lane];
+        for (int ww = 0; ww <= w; ++ww) r = fmin(r, L->sm[ww][lane]);         // wave 0 is the highest level of the slab
+        __syncthreads();
+        if (w == 3) L->carry_min[which][lane] = r;
+        return r;
+    }
+    __device__ __forceinline__ void carry_down2x2(float &a0, float &b0, int has0, float &a1, float &b1, int has1, int which)
+    {
+        L->cdv[w][0][lane] = a0; L->cdv[w][1][lane] = b0; L->cdv[w][2][lane] = a1; L->cdv[w][3][lane] = b1;
+        L->cdh[w][0][lane] = has0; L->cdh[w][1][lane] = has1;
+        __syncthreads();
+        if (!has0) {
+            int ww = w - 1;
+            while (ww >= 0 && !L->cdh[ww][0][lane]) --ww;
+            if (ww >= 0) { a0 = L->cdv[ww][0][lane]; b0 = L->cdv[ww][1][lane]; }
+            else { a0 = L->carry_vt[which][0][lane]; b0 = L->carry_vt[which][1][lane]; }
+        }
+        if (!has1) {
+            int ww = w - 1;
+            while (ww >= 0 && !L->cdh[ww][1][lane]) --ww;
+            if (ww >= 0) { a1 = L->cdv[ww][2][lane]; b1 = L->cdv[ww][3][lane]; }
+            else { a1 = L->carry_vt[which][2][lane]; b1 = L->carry_vt[which][3][lane]; }
+        }
+        __syncthreads();
+        if (w == 3) { L->carry_vt[which][0][lane] = a0; L->carry_vt[which][1][lane] = b0; L->carry_vt[which][2][lane] = a1; L->carry_vt[which][3][lane] = b1; }
+    }
+};
+
+// one level of sweep 1 of k_thompson_slab
+__device__ __forceinline__ void
+th_slab_level(Dims d, const ThState *__restrict__ T, const float *__restrict__ qv, const float *__restrict__ qc, const float *__restrict__ qr,
+              const float *__restrict__ qi, const float *__restrict__ qs, const float *__restrict__ qg, const float *__restrict__ ni, const float *__restrict__ nr,
+              const float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
+              float dt, MarchArgs a, float *__restrict__ ws, SlabLds *L, int k, int w, int lane, int col, int base)
+{
+    SlabComm x; x.L = L; x.w = w; x.lane = lane;
+    x.active = k >= 0; x.k = x.active ? k : 0;
+    const int c = base + x.k * d.nx, nk = a.nk;
+    const float pi_ = pii[c];
+    float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
+          qg1d = qg[c], ni1d = ni[c], nr1d = nr[c];
+    ThHand h;
+    th_level_physics(T, x, nk, dt, dz1d, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d, p1d, h);
+    if (x.active) {
+        for (int sp = 0; sp < 4; ++sp) {
+            if (h.c4[sp]) atomicMax(&L->ks[sp][lane], k);                  /* :2548 the highest level with a sedimenting particle */
+            if (h.ns4[sp] > 0) atomicMax(&L->ns[sp][lane], h.ns4[sp]);
+        }
+        /* (wave-uniform row address + the lane's column as a 32-bit offset: per-lane 64-bit addresses of the 25 rows would be
+         * hoisted out of the slab loop and cost ~50 VGPRs) */
+        float *wrow = ws + (size_t)__builtin_amdgcn_readfirstlane(k) * TH_NHAND * a.ncolp;
+        const unsigned ucol = (unsigned)col;
+        const float hv[TH_NHAND] = {h.vtrk, h.vtnrk, h.vtik, h.vtnik, h.vtsk, h.vtgk, h.rr, h.nr, h.ri, h.ni, h.rs, h.rg,
+                                    h.qrten, h.nrten, h.qiten, h.niten, h.qsten, h.qgten, h.qcten, h.qvten, h.tten,
+                                    h.rho, h.temp, h.ocp, h.lvap};
+#pragma unroll
+        for (int v = 0; v < TH_NHAND; ++v) (wrow + (size_t)v * a.ncolp)[ucol] = hv[v];
+    }
+}
+
+// sedimentation of ONE species (S = 0 rain, 1 cloud ice, 2 snow, 3 graupel) down a whole column from the workspace of sweep 1:
+// its fall speeds, contents and tendencies are read level by level, the final tendencies (and, between chunks of sub-steps,
+// the contents) written back.  Returns what reached the ground (pptrain / pptice / pptsnow / pptgraul).
+template <int S>
+__device__ __forceinline__ float th_sed_species(float *__restrict__ ws, const MarchArgs &a, const float *__restrict__ dz, int base, int sk, int col,
+                                                int kte, float dt, const int nstep[4], const int ksed1[4], const float onstep[4],
+                                                const int nw[4], const int C[4], float *HM, float *HN)
+{
+    const float R1 = TH_R1, R2 = TH_R2;
+    /* workspace slots (ThHand order): fall speeds (mass, number), contents (mass, number), tendencies (mass, number) */
+    constexpr int vV = S == 0 ? 0 : S == 1 ? 2 : S == 2 ? 4 : 5, vVn = S == 0 ? 1 : 3;
+    constexpr int vQ = S == 0 ? 6 : S == 1 ? 8 : S == 2 ? 10 : 11, vQn = S == 0 ? 7 : 9;
+    constexpr int vT = S == 0 ? 12 : S == 1 ? 14 : S == 2 ? 16 : 17, vTn = S == 0 ? 13 : 15;
+    const int nsweep = C[S] > 0 ? (nw[S] + C[S] - 1) / C[S] : 1;
+    float ppt = 0.f;
+    for (int sw = 0; sw < nsweep; ++sw) {
+        const bool last = (sw == nsweep - 1);
+        for (int k = kte; k >= 0; --k) {
+            float *wp = ws + (size_t)k * TH_NHAND * a.ncolp + col;
+            const float odzq = 1.f / dz[base + k * sk], orho = 1.f / wp[(size_t)21 * a.ncolp];
+            float vm = wp[(size_t)vV * a.ncolp], qm = wp[(size_t)vQ * a.ncolp], tm = wp[(size_t)vT * a.ncolp];
+            if (S < 2) {
+                float vn = wp[(size_t)vVn * a.ncolp], qn = wp[(size_t)vQn * a.ncolp], tn = wp[(size_t)vTn * a.ncolp];
+                TH_SED2(S, HM, HN, vm, vn, qm, qn, tm, tn, R2, ppt)
+                wp[(size_t)vTn * a.ncolp] = tn;
+                if (!last) wp[(size_t)vQn * a.ncolp] = qn;
+            } else {
+                TH_SED1(S, HM, vm, qm, tm, ppt)
+            }
+            wp[(size_t)vT * a.ncolp] = tm;
+            if (!last) wp[(size_t)vQ * a.ncolp] = qm;
+        }
+    }
+    return ppt;
+}
+
+__global__ void __launch_bounds__(256, 3)
+k_thompson_slab(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
+                float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
+                float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
+                double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
+                float dt, MarchArgs a, float *__restrict__ ws)
+{
+    __shared__ SlabLds L;
+    gf_lds_init(threadIdx.x, 256);
+    const float R1 = TH_R1, eps = TH_eps;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane, nk = a.nk, kte = nk - 1;
+    const int nslab = (nk + 3) / 4;
+    const bool on = col < a.ncol;
+    const int colc = on ? col : a.ncol - 1;
+    const int jj = a.j0 + colc / a.ni, ii = a.i0 + colc % a.ni;
+    const int base = d.idx(ii, a.k0, jj), sk = d.nx;
+    if (w == 0) {
+        L.quiet[lane] = 1;
+        for (int c2 = 0; c2 < 2; ++c2) { L.carry_min[c2][lane] = __builtin_inf(); for (int v = 0; v < 4; ++v) L.carry_vt[c2][v][lane] = 0.f; }
+        for (int s = 0; s < 4; ++s) { L.ns[s][lane] = 0; L.ks[s][lane] = -1; L.ppt[s][lane] = 0.f; }
+    }
+    __syncthreads();
+    /* ---- which columns have nothing to do (:1240-1363): each wave looks at every fourth level ---- */
+    {
+        bool quiet = true;
+        for (int k = w; k < nk; k += 4) {
+            const int c = base + k * sk;
+            const bool wet = (qc[c] > R1) || (qi[c] > R1) || (qr[c] > R1) || (qs[c] > R1) || (qg[c] > R1);
+            const float temp = th[c] * pii[c], pres = p[c], qv_ = fmaxf(1.E-10f, qv[c]);
+            const float qvs_ = rslf(pres, temp);
+            const float qvsi_ = (temp - 273.15f <= 0.0f) ? rsif(pres, temp) : qvs_;
+            float ssati_ = qv_ / qvsi_ - 1.f;
+            if (fabsf(ssati_) < eps) ssati_ = 0.0f;
+            if (wet || ssati_ > 0.0f) quiet = false;
+            if (!__any(quiet && on)) break;
+        }
+        if (!quiet) L.quiet[lane] = 0;
+    }
+    __syncthreads();
+    const bool live = on && !L.quiet[lane];
+    int nstep[4] = {0, 0, 0, 0}, ksed1[4] = {0, 0, 0, 0};
+    float onstep[4] = {1.f, 1.f, 1.f, 1.f};
+    const bool any_live = __syncthreads_or(live);
+
+    if (any_live) {
+        /* ---- sweep 1: point physics, slab by slab from the model top ---- */
+        for (int s = 0; s < nslab; ++s)
+            th_slab_level(d, T, qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, dt, a, ws, &L, kte - (4 * s + w), w, lane, col, base);
+        __syncthreads();
+        for (int sp = 0; sp < 4; ++sp) {                                      /* the plan: BlockComm::sed_plan4 for one column */
+            const int n = live ? L.ns[sp][lane] : 0;
+            int kk = L.ks[sp][lane] < 0 ? 0 : L.ks[sp][lane];
+            if (kk == kte) kk = kte - 1;
+            ksed1[sp] = kk; onstep[sp] = (n > 0) ? 1.f / (float)n : 1.0f;
+            nstep[sp] = live ? (int)lroundf(1.f / onstep[sp]) : 0;
+        }
+    }
+    /* ---- sweep 2a: wave w sediments species w down the whole column; chunks of sub-steps that fit the LDS rows ---- */
+    int nw[4], C[4];
+    for (int s = 0; s < 4; ++s) nw[s] = th_wave_max(nstep[s]);
+    if (2 * nw[0] + 2 * nw[1] + nw[2] + nw[3] <= TH_MARCH_ROWS) { for (int s = 0; s < 4; ++s) C[s] = nw[s]; }
+    else { for (int s = 0; s < 4; ++s) C[s] = min(nw[s], TH_MARCH_ROWS / 6); }
+    float *H0 = L.hist + lane, *H1 = H0 + 64 * C[0], *H2 = H1 + 64 * C[0], *H3 = H2 + 64 * C[1], *H4 = H3 + 64 * C[1], *H5 = H4 + 64 * C[2];
+    if (any_live && live) {
+        float ppt = 0.f;
+        if (w == 0) ppt = th_sed_species<0>(ws, a, dz, base, sk, col, kte, dt, nstep, ksed1, onstep, nw, C, H0, H1);
+        else if (w == 1) ppt = th_sed_species<1>(ws, a, dz, base, sk, col, kte, dt, nstep, ksed1, onstep, nw, C, H2, H3);
+        else if (w == 2) ppt = th_sed_species<2>(ws, a, dz, base, sk, col, kte, dt, nstep, ksed1, onstep, nw, C, H4, H4);
+        else ppt = th_sed_species<3>(ws, a, dz, base, sk, col, kte, dt, nstep, ksed1, onstep, nw, C, H5, H5);
+        L.ppt[w][lane] = ppt;
+    }
+    __syncthreads();            /* (block-wide: the tendencies the four waves wrote are read by all of them below) */
+    /* ---- sweep 2b: melt / freeze / update, four levels at a time ---- */
+    for (int s = 0; s < nslab; ++s) {
+        const int k = kte - (4 * s + w);
+        if (k < 0) continue;
+        const int c = base + k * sk;
+        const float pi_ = pii[c];
+        float t1d = th[c] * pi_, qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c], qg1d = qg[c],
+              ni1d = ni[c], nr1d = nr[c];
+        /* :1240-1319 what the column routine does to its arguments before anything else */
+        if (!(qc1d > R1)) qc1d = 0.0f;
+        if (!(qi1d > R1)) { qi1d = 0.0f; ni1d = 0.0f; }
+        if (!(qr1d > R1)) { qr1d = 0.0f; nr1d = 0.0f; }
+        if (!(qs1d > R1)) qs1d = 0.0f;
+        if (!(qg1d > R1)) qg1d = 0.0f;
+        if (live) {
+            const float *wp = ws + (size_t)k * TH_NHAND * a.ncolp + col;
+            ThHand h;
+            h.qrten = wp[(size_t)12 * a.ncolp]; h.nrten = wp[(size_t)13 * a.ncolp]; h.qiten = wp[(size_t)14 * a.ncolp]; h.niten = wp[(size_t)15 * a.ncolp];
+            h.qsten = wp[(size_t)16 * a.ncolp]; h.qgten = wp[(size_t)17 * a.ncolp]; h.qcten = wp[(size_t)18 * a.ncolp]; h.qvten = wp[(size_t)19 * a.ncolp];
+            h.tten = wp[(size_t)20 * a.ncolp]; h.rho = wp[(size_t)21 * a.ncolp]; h.temp = wp[(size_t)22 * a.ncolp]; h.ocp = wp[(size_t)23 * a.ncolp];
+            h.lvap = wp[(size_t)24 * a.ncolp];
+            th_level_finish(T, dt, h, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d);
+        }
+        if (on) {
+            qv[c] = (qv1d < 1.E-7f) ? 1.E-7f : qv1d;          // :997-1010
+            qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
+            th[c] = t1d / pi_;
+        }
+    }
+    if (w == 0 && on) {
+        const float pptrain = L.ppt[0][lane], pptice = L.ppt[1][lane], pptsnow = L.ppt[2][lane], pptgraul = L.ppt[3][lane];
         const int c2 = ii + d.nx * jj;
         const float rainnc = 0.f + pptrain + pptsnow + pptgraul + pptice;
         const float snownc = 0.f + pptsnow + pptice;
@@ -596,12 +836,12 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
     }
     if (nt_ == 0) return 0;
     ScopedTimer tm(c, "mp");
-    // One column per lane (k_thompson_march) only on request (icar_hip_thompson_layout(ctx, 2)): measured on MI355X at
+    // Lanes along i (k_thompson_march = layout 2, k_thompson_slab = layout 3) only on request (icar_hip_thompson_layout): measured on MI355X at
     // 512 x 512 x 40 it executes 23 % fewer VALU instructions at 67 % instead of 61 % active lanes (neighbouring columns of a
     // level still diverge in the +-1 % noise of the benchmark state) but runs 2.40 ms against 1.77 ms for the packed
     // level-per-thread kernel: two waves per SIMD do not hide its instruction-fetch and memory latencies
     // (profiles/r04_thompson_layout.md).
-    if (nt_ == 1 && nk >= 2 && c->th_layout == 2) {
+    if (nt_ == 1 && nk >= 2 && (c->th_layout == 2 || c->th_layout == 3)) {
         const int ni_ = T4[0][1] - T4[0][0] + 1, nj_ = T4[0][3] - T4[0][2] + 1;
         const long ncol = (long)ni_ * nj_;
         {
@@ -613,8 +853,12 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
                 HIPCHK(hipMalloc(&c->th_ws, need * sizeof(float)));
                 c->th_ws_floats = need;
             }
-            hipLaunchKernelGGL(k_thompson_march, dim3(a.ncolp / 64), dim3(64), 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr,
-                               th, pii, p, dz, pa, sa, ga, dt, a, c->th_ws);
+            if (c->th_layout == 3)
+                hipLaunchKernelGGL(k_thompson_slab, dim3(a.ncolp / 64), dim3(256), 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr,
+                                   th, pii, p, dz, pa, sa, ga, dt, a, c->th_ws);
+            else
+                hipLaunchKernelGGL(k_thompson_march, dim3(a.ncolp / 64), dim3(64), 0, c->stream, c->d, T, qv, qc, qr, qi, qs, qg, ni, nr,
+                                   th, pii, p, dz, pa, sa, ga, dt, a, c->th_ws);
             HIPCHK(hipGetLastError());
             return 0;
         }

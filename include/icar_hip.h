@@ -167,9 +167,10 @@ int icar_hip_thompson_tiles(icar_hip_ctx *ctx, float dt, int ntiles, const int t
                             int ids, int ide, int jds, int jde, int kds, int kde);
 /* Thread layout of the Thompson column physics (mp_thompson.f90:1057-2844 is a 1-D column routine; how its levels map to
  * lanes is the device's business).  0 / 1 (default): one level per thread, whole columns packed into 256-thread blocks.
- * 2: one column per LANE marching down its levels in two sweeps (point physics, then sedimentation + update), for single
- * tiles; the same bits, slower on MI355X today (profiles/r04_thompson_layout.md) -- kept for profiling and as the
- * starting point of north_star's layout. */
+ * 2: one column per LANE marching down its levels in two sweeps (point physics, then sedimentation + update); 3: 64 columns
+ * x 4 levels per block, slabs marched top-down (a wave = 64 neighbouring columns of one level, one level per thread).  Both
+ * for single tiles, both the same bits; on MI355X 2 is slower and 3 on a par with the default
+ * (profiles/r04_thompson_layout.md) -- kept for profiling and as the starting point of north_star's layout. */
 int icar_hip_thompson_layout(icar_hip_ctx *ctx, int layout);
 
 

@@ -115,21 +115,25 @@ def test_thompson_bit_exact_vs_reference_math(th_oracle, case):
     check_close(out, ref, rtol=1e-5, label=case + "/mode0", **EXACT)
 
 
+@pytest.mark.parametrize("layout", [2, 3])
 @pytest.mark.parametrize("case", list(CASES))
-def test_thompson_column_per_lane_bit_exact(th_oracle, case):
-    """k_thompson_march (one column per lane, levels marched top-down, ThHand parked in the HBM workspace between the two
-    sweeps, sedimentation flux history in LDS) forced on the small cases: the same bits as the oracle in the reference's math."""
-    out, ref = run_case(th_oracle, mode=0, layout=2, **CASES[case])
+def test_thompson_column_per_lane_bit_exact(th_oracle, case, layout):
+    """Lanes along i (a wave = 64 neighbouring columns of one level) forced on the small cases: layout 2 = k_thompson_march (one
+    column per lane, levels marched top-down), layout 3 = k_thompson_slab (64 columns x 4 levels per block, slabs marched
+    top-down); ThHand parked in the HBM workspace between the sweeps, sedimentation flux history in LDS.  The same bits as the
+    oracle in the reference's math."""
+    out, ref = run_case(th_oracle, mode=0, layout=layout, **CASES[case])
     assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
-    check_close(out, ref, rtol=1e-5, label=case + "/march/mode0", **EXACT)
+    check_close(out, ref, rtol=1e-5, label=f"{case}/layout{layout}/mode0", **EXACT)
 
 
-def test_thompson_column_per_lane_chunked_substeps(th_oracle):
+@pytest.mark.parametrize("layout", [2, 3])
+def test_thompson_column_per_lane_chunked_substeps(th_oracle, layout):
     """A time step long enough that a wave's sub-step counts (2 nstep_rain + 2 nstep_ice + nstep_snow + nstep_graupel) exceed
     its 64 LDS rows: the sedimentation then runs in chunks of sub-steps, one sweep over the workspace per chunk."""
-    out, ref = run_case(th_oracle, mode=0, layout=2, nx=70, ny=9, nz=40, steps=6, cool=3.0, moist=2.5, dt=400.0)
+    out, ref = run_case(th_oracle, mode=0, layout=layout, nx=70, ny=9, nz=40, steps=6, cool=3.0, moist=2.5, dt=400.0)
     assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
-    check_close(out, ref, rtol=1e-5, label="march_chunked/mode0", **EXACT)
+    check_close(out, ref, rtol=1e-5, label=f"chunked/layout{layout}/mode0", **EXACT)
 
 
 def test_thompson_layouts_agree_with_quiet_columns():
@@ -141,7 +145,7 @@ def test_thompson_layouts_agree_with_quiet_columns():
     c["water_vapor"] = qv.astype(np.float32)
     c["cloud_water"][:, 3, 5:9] = np.float32(5e-13)          # below R1: zeroed even where the column returns early
     outs = []
-    for layout in (1, 2):
+    for layout in (1, 2, 3):
         d = single_image_domain(c)
         opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
         mp_init(opt, d)
@@ -154,7 +158,7 @@ def test_thompson_layouts_agree_with_quiet_columns():
     dry = outs[0]["cloud_water"].max(axis=1) == 0.0                      # (ny, nx): columns without any cloud water
     assert dry.any() and (~dry).any() and outs[0]["cloud_water"][1:-1, 3, 5:9].max() == 0.0
     for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]), k
 
 
 def test_thompson_excludes_last_global_row_and_column(th_oracle):
