@@ -48,7 +48,11 @@ float *icar_field_f(icar_hip_ctx *c, int f, bool required)
 ScopedTimer::ScopedTimer(icar_hip_ctx *c_, const char *g) : c(c_), group(g)
 {
     if (!c->timing) return;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    // a timed event pair costs the stream ~5 us (two barrier packets with timestamps); a sub-step of a small tile has a dozen
+    // groups: icar_hip_timing_groups restricts the timers to the ones that are read
+    if (!c->timing_only.empty() && c->timing_only.find(std::string(",") + g + ",") == std::string::npos) return;
+    auto take = [&](hipEvent_t &e) { if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); } else hipEventCreate(&e); };
+    take(e0); take(e1);
     hipEventRecord(e0, c->stream);
 }
 ScopedTimer::~ScopedTimer()
@@ -66,7 +70,7 @@ static void drain_timers(icar_hip_ctx *c)
         hipEventElapsedTime(&ms, p.second.first, p.second.second);
         auto &t = c->timers[p.first];
         t.total_ms += ms; t.launches += 1;
-        hipEventDestroy(p.second.first); hipEventDestroy(p.second.second);
+        c->event_pool.push_back(p.second.first); c->event_pool.push_back(p.second.second);
     }
     c->pending.clear();
 }
@@ -456,6 +460,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     if (c->step.h_val) hipHostFree(c->step.h_val);
     if (c->on_aux) c->stream = c->main_saved;
     if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -976,6 +981,12 @@ int icar_hip_aux_join(icar_hip_ctx *c)
 }
 
 int icar_hip_timing_enable(icar_hip_ctx *c, int on) { if (!c) return 1; hipSetDevice(c->device); c->timing = on != 0; return 0; }
+int icar_hip_timing_groups(icar_hip_ctx *c, const char *csv)
+{
+    if (!c) return 1;
+    c->timing_only = (csv && *csv) ? std::string(",") + csv + "," : std::string();
+    return 0;
+}
 int icar_hip_timing_reset(icar_hip_ctx *c) { if (!c) return 1; hipSetDevice(c->device); hipStreamSynchronize(c->stream); drain_timers(c); c->timers.clear(); return 0; }
 int icar_hip_timing_read(icar_hip_ctx *c, const char *group, double *total_ms, int *launches)
 {

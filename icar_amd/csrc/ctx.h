@@ -82,6 +82,8 @@ struct icar_hip_ctx {
     IcarStepState step;                  // timestep.hip
     // timing
     bool timing = false;
+    std::string timing_only;             // ",group,group," or empty = every group (icar_hip_timing_groups)
+    std::vector<hipEvent_t> event_pool;  // timing events are reused, not created per scope
     std::map<std::string, TimingGroup> timers;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
 };

@@ -452,6 +452,9 @@ int icar_hip_step_n(icar_hip_ctx *ctx, int nsteps, double *dt_last);
 /* Average duration (ms) of the launches of a named kernel group since the last reset, measured
  * with HIP events on the context's stream (bench.py roofline block). group: "advect", "mp". */
 int icar_hip_timing_enable(icar_hip_ctx *ctx, int on);
+/* restrict the timers to a comma-separated list of groups ("advect", "advect,mp,winds"; NULL or "" = all): every timed
+ * scope costs its stream two timestamped barrier packets, ~5 us -- a dozen groups per sub-step are 10 % of a small tile's step */
+int icar_hip_timing_groups(icar_hip_ctx *ctx, const char *groups_csv);
 int icar_hip_timing_read(icar_hip_ctx *ctx, const char *group, double *total_ms, int *launches);
 int icar_hip_timing_reset(icar_hip_ctx *ctx);
 
