@@ -28,7 +28,7 @@ SYMBOLS = [
     "icar_hip_step_configure", "icar_hip_model_time_set", "icar_hip_model_time", "icar_hip_mp_reset", "icar_hip_compute_dt",
     "icar_hip_update_dt", "icar_hip_mp", "icar_hip_advect_step", "icar_hip_substep", "icar_hip_step", "icar_hip_step_n",
     "icar_hip_linwinds_setup", "icar_hip_linwinds_terrain_frequency", "icar_hip_linear_perturbation",
-    "icar_hip_linwinds_build_lut", "icar_hip_linwinds_build_lut_varying", "icar_hip_linwinds_lut_download", "icar_hip_linwinds_lut_upload",
+    "icar_hip_linwinds_build_lut", "icar_hip_linwinds_build_lut_varying", "icar_hip_linwinds_lut_download", "icar_hip_linwinds_lut_upload", "icar_hip_linwinds_lut_entry",
     "icar_hip_linwinds_perturbation_download", "icar_hip_linwinds_perturbation_upload", "icar_hip_spatial_winds",
 ]
 

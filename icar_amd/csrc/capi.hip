@@ -862,6 +862,13 @@ int icar_hip_linwinds_lut_download(icar_hip_ctx *c, int comp, float *host)
     return icar_linwinds_lut_copy(c, comp, host, 0);
 }
 
+int icar_hip_linwinds_lut_entry(icar_hip_ctx *c, int comp, int spd, int dir, int nsq, float *host)
+{
+    if (!c || !host) { icar_set_error("linwinds_lut_entry: null argument"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    return icar_linwinds_lut_entry(c, comp, spd, dir, nsq, host);
+}
+
 int icar_hip_linwinds_lut_upload(icar_hip_ctx *c, int comp, const float *host)
 {
     if (!c || !host) { icar_set_error("linwinds_lut_upload: null argument"); return 1; }

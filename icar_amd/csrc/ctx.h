@@ -150,6 +150,7 @@ int icar_linear_perturbation_run(icar_hip_ctx *c, float U, float V, float Nsq, f
 int icar_linwinds_build_lut_run(icar_hip_ctx *c, const float *zb, const float *zt, int nlev);
 int icar_linwinds_build_lut_varying_run(icar_hip_ctx *c, const float *zb3, const float *zt3, int nlev);
 int icar_linwinds_lut_copy(icar_hip_ctx *c, int comp, float *host, int to_dev);
+int icar_linwinds_lut_entry(icar_hip_ctx *c, int comp, int k, int i, int j, float *host);
 int icar_linwinds_pert_copy(icar_hip_ctx *c, int comp, float *host, int to_dev);
 int icar_linwinds_terrain_frequency(icar_hip_ctx *c, double *out, size_t cap, int *fnx, int *fny);
 int icar_spatial_winds_run(icar_hip_ctx *c, int update);

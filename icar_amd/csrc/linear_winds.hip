@@ -613,6 +613,20 @@ int icar_linwinds_lut_copy(icar_hip_ctx *c, int comp, float *host, int to_dev)
     return 0;
 }
 
+// one LUT entry (spd k, dir i, nsq j: 0-based) of component comp as the whole (nx[+1], nz, ny[+1]) field it is on the device
+int icar_linwinds_lut_entry(icar_hip_ctx *c, int comp, int k, int i, int j, float *host)
+{
+    LinWinds *w = c->linwinds;
+    if (!w || comp < 0 || comp > 1 || !w->lut[comp]) { icar_set_error("linwinds LUT entry: LUT not built / bad component"); return 1; }
+    const int nd = w->o.n_dir_values, ns = w->o.n_spd_values, nn = w->o.n_nsq_values;
+    if (k < 0 || k >= ns || i < 0 || i >= nd || j < 0 || j >= nn) { icar_set_error("linwinds LUT entry: index outside the LUT axes"); return 1; }
+    const size_t cells = icar_field_count(c, comp == 0 ? ICAR_F_U : ICAR_F_V);
+    const size_t combo = (size_t)k + (size_t)ns * ((size_t)i + (size_t)nd * j);
+    HIPCHK(hipMemcpyAsync(host, w->lut[comp] + combo * cells, cells * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int icar_linwinds_pert_copy(icar_hip_ctx *c, int comp, float *host, int to_dev)
 {
     LinWinds *w = c->linwinds;

@@ -102,6 +102,14 @@ def lut_download(domain, options, comp):
     return a
 
 
+def lut_entry(domain, comp, spd, dir_, nsq):
+    """hi_u_LUT(spd, dir, nsq, :, :, :) (0-based indices) as [ny(+1), nz, nx(+1)]: one entry instead of the whole LUT"""
+    shp = (domain.ny, domain.nz, domain.nx + 1) if comp == 0 else (domain.ny + 1, domain.nz, domain.nx)
+    a = np.empty(shp, np.float32)
+    check(lib().icar_hip_linwinds_lut_entry(domain.ctx, comp, int(spd), int(dir_), int(nsq), a.ctypes.data_as(ctypes.c_void_p)), "lut_entry")
+    return a
+
+
 def lut_upload(domain, options, comp, lut):
     a = np.ascontiguousarray(lut, np.float32)
     if a.shape != _lut_shape(domain, options, comp):

@@ -330,6 +330,9 @@ int icar_hip_linwinds_build_lut_varying(icar_hip_ctx *ctx, const float *z_bottom
  * disk cache src/io/lt_lut_io.f90 -- component 0 = u, 1 = v.  upload replaces read_LUT (:659). */
 int icar_hip_linwinds_lut_download(icar_hip_ctx *ctx, int component, float *host);
 int icar_hip_linwinds_lut_upload(icar_hip_ctx *ctx, int component, const float *host);
+/* one entry hi_u_LUT(spd, dir, nsq, :, :, :) / hi_v_LUT(...) (0-based indices) as a field of the tile's u / v shape (Fortran
+ * order (nx[+1], nz, ny[+1])): a production LUT is tens of GB, an entry 20-40 MB */
+int icar_hip_linwinds_lut_entry(icar_hip_ctx *ctx, int component, int spd, int dir, int nsq, float *host);
 /* hi_u_perturbation / hi_v_perturbation (the relaxed perturbation state, :1263-1268), for restarts and tests. */
 int icar_hip_linwinds_perturbation_download(icar_hip_ctx *ctx, int component, float *host);
 int icar_hip_linwinds_perturbation_upload(icar_hip_ctx *ctx, int component, const float *host);
