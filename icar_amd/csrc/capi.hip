@@ -292,6 +292,11 @@ int icar_max_courant_run(icar_hip_ctx *c, float dx, const float *dz_levels, floa
 
 // the prefetched maximum, if it is still valid AND was already reduced over the images on the device (allreduce = true below):
 // consumes it; the host waits for the second stream's copy only
+bool icar_cfl_prefetch_waiting(icar_hip_ctx *c)
+{
+    return c->step.configured && cfl_prefetched(c, c->step.cfg.dx, c->step.dz_levels.data());
+}
+
 bool icar_cfl_prefetched_global(icar_hip_ctx *c, float dx, const float *dz_levels, float *value)
 {
     if (!cfl_prefetched(c, dx, dz_levels) || !c->cfl_pre.reduced) return false;

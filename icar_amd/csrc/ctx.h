@@ -37,6 +37,7 @@ struct IcarStepState {
     double mp_last_model_time = -999.0;      // mp_driver.f90:44 last_model_time
     int winds_scheme = 0, winds_dens = 0; float winds_dt = 0.f;   // what the Courant winds on the device were set up for
     float *h_val = nullptr;                  // pinned: the reduced CFL maximum
+    bool early_open = false, early_wreal = false, early_face = false;   // a sub-step whose dt-independent opening is already in flight
     bool winds_first = true;                 // wind.f90:297 `.not. allocated(domain%sintheta)`: update_winds has not run yet
 };
 
@@ -127,6 +128,7 @@ int icar_thompson_math_probe_run(icar_hip_ctx *c, int op, int n, const double *x
 int icar_thompson_dec_index_run(icar_hip_ctx *c, const float *rf, const double *rd, int n, int n2, int which, int *out);
 int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels, bool allreduce);
 bool icar_cfl_prefetched_global(icar_hip_ctx *c, float dx, const float *dz_levels, float *value);
+bool icar_cfl_prefetch_waiting(icar_hip_ctx *c);      // a prefetched CFL maximum of the current winds is waiting for update_dt
 inline void icar_winds_changed(icar_hip_ctx *c) { c->winds_valid = false; ++c->wind_version; }   // u, v, w (or density / jacobians) rewritten
 int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);
 int icar_enforce_limits_run(icar_hip_ctx *c, const int *fields, int n);

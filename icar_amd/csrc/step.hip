@@ -209,7 +209,8 @@ int icar_diagnostic_update_run(icar_hip_ctx *c, int parts)
     const bool columns = ca.ivt || ca.iwv || ca.iwl || ca.iwi;
     ScopedTimer t(c, "diag");
     if (parts & ICAR_DIAG_CELL) {
-        icar_winds_changed(c);                                   // density is rewritten: Courant winds (advect_density) are stale
+        c->winds_valid = false;                                  // density is rewritten: Courant winds (advect_density) are stale -- u, v, w are
+                                                                 // not: a prefetched CFL maximum of them stays valid (wind_version untouched)
         const size_t n4 = c->n3 / 4, rest = c->n3 - 4 * n4, nthr = n4 + rest;
         hipLaunchKernelGGL(k_diag_cell, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, n4, c->n3, p, th, ex, T, rho);
     }

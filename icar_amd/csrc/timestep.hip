@@ -173,6 +173,58 @@ struct AuxScope {          // entry points called while this object lives launch
     ~AuxScope() { end(); }
 };
 
+// The opening of a sub-step does not depend on its dt: diagnostic_update, the interior microphysics (its own time step is
+// model_time - last_model_time, mp_driver.f90:708) and, on the second stream, the strips, the pack + halo transfer and the
+// interface diagnostics.  The step loops issue it BEFORE they wait for the CFL maximum of update_dt -- which the previous
+// sub-step left reducing beside its advection -- so that the device has ~the whole microphysics queued while the host reads dt
+// (otherwise every step starts with the host's wake-up + launch latency, ~20 us: 4 % of the 8-GPU tile's step).  Same launches,
+// same operands, same results; only the order of issue changes.  Possible when nothing of the opening needs dt: no
+// mp_update_interval gating, not the first microphysics call, halo_size 1, a prefetched CFL maximum waiting (update_dt will not
+// launch anything on the main stream) and no end-time clamp in reach (the caller checks the last one).
+bool icar_substep_can_open_early(icar_hip_ctx *c)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    return g.microphysics != 0 && g.halo_size == 1 && g.mp_update_interval == 0.0f && c->step.mp_last_model_time != -999.0
+        && g.prefetch_dt && (g.cfl_strictness == 3 || g.cfl_strictness == 4) && icar_cfl_prefetch_waiting(c) && !c->on_aux;
+}
+
+static int substep_open(icar_hip_ctx *c, double dt, bool dt_known, bool &wreal_later, bool &face_later)
+{
+    const icar_hip_step_config &g = c->step.cfg;
+    const bool adv = (g.advection == ICAR_ADV_UPWIND || g.advection == ICAR_ADV_MPDATA);
+    wreal_later = false; face_later = false;
+    if (g.diagnostics) {
+        if (g.microphysics != kMP_WSM3) {
+            face_later = true;
+            if (icar_diagnostic_update_run(c, ICAR_DIAG_CELL)) return 1;
+            wreal_later = true;
+        } else if (icar_diagnostic_update_run(c, 3)) return 1;
+    }
+    if (icar_hip_aux_fork(c)) return 1;
+    const double mp_last_before = c->step.mp_last_model_time;
+    if (icar_mp_run(c, dt, -1, 1)) return 1;                                      // :523 interior
+    const double mp_last_after = c->step.mp_last_model_time;
+    c->step.mp_last_model_time = mp_last_before;
+    {
+        AuxScope aux(c);
+        if (aux.begin()) return 1;
+        if (icar_mp_run(c, dt, 1, -1)) return 1;                                  // :512 strips
+        if (halo_send(c)) return 1;                                               // :515 pack + RCCL send / recv
+        if (face_later && icar_diagnostic_update_run(c, ICAR_DIAG_FACE)) return 1;
+        if (dt_known && adv && setup_winds(c, (float)dt)) return 1;
+    }
+    c->step.mp_last_model_time = mp_last_after;
+    return 0;
+}
+
+int icar_substep_open_early(icar_hip_ctx *c)
+{
+    bool wl, fl;
+    if (substep_open(c, 0.0, false, wl, fl)) return 1;
+    c->step.early_open = true; c->step.early_wreal = wl; c->step.early_face = fl;
+    return 0;
+}
+
 int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
 {
     const icar_hip_step_config &g = c->step.cfg;
@@ -180,6 +232,20 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
     const bool adv = (g.advection == ICAR_ADV_UPWIND || g.advection == ICAR_ADV_MPDATA);
     const bool stepping = dt > 1e-3;                                              // :483
     bool wreal_later = false, face_later = false;
+    const bool early = c->step.early_open;
+    c->step.early_open = false;
+    if (early) {
+        // the opening is in flight (icar_substep_open_early); what it left out: the wind setup of the advect() below, on the second stream
+        wreal_later = c->step.early_wreal; face_later = c->step.early_face;
+        if (!stepping) { icar_set_error("substep: opened early but dt <= 1e-3"); return 1; }
+        if (adv) {
+            AuxScope aux(c);
+            if (aux.begin()) return 1;
+            if (setup_winds(c, dtf)) return 1;
+        }
+        if (icar_hip_aux_join(c)) return 1;
+        if (halo_retrieve(c)) return 1;                                           // :526
+    } else
     if (g.diagnostics) {                                                          // :474
         if (g.microphysics != kMP_WSM3) {                                         // WSM3 reads w_real
             // exner / T / density now; the interface values and mass-point winds (nothing the microphysics reads or writes)
@@ -193,7 +259,8 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
     if (!stepping) return 0;
 
     // :512-526  mp(halo=1) -> halo_send -> mp(subset=1) -> halo_retrieve
-    if (g.microphysics != 0 && g.halo_size > 1) {
+    if (early) {
+    } else if (g.microphysics != 0 && g.halo_size > 1) {
         // halo_send packs the first halo_size owned rows / columns, mp(halo=1) only processes the outermost one: with a halo wider
         // than 1 the message carries cells the interior pass has not touched yet (the reference sends them in that state,
         // time_step.f90:512-523).  Beside the interior launch the pack would read them while they are written, so this
@@ -401,6 +468,7 @@ int icar_hip_step_n(icar_hip_ctx *c, int nsteps, double *dt_last)
     HIPCHK(hipSetDevice(c->device));
     double dt = 0.0;
     for (int n = 0; n < nsteps; ++n) {
+        if (icar_substep_can_open_early(c) && icar_substep_open_early(c)) return 1;
         if (icar_update_dt(c, &dt)) return 1;
         if (icar_substep(c, dt, false)) return 1;
         c->step.model_time += dt;
@@ -418,6 +486,8 @@ int icar_hip_step(icar_hip_ctx *c, double end_time_seconds, int *nsteps)
     int n = 0;
     while (c->step.model_time < end_time_seconds) {                              // :462
         double dt;
+        // (update_dt caps dt at 120 s, :417: farther than that from the end no clamp can shorten this step)
+        if (end_time_seconds - c->step.model_time > 120.0 && icar_substep_can_open_early(c) && icar_substep_open_early(c)) return 1;
         if (icar_update_dt(c, &dt)) return 1;                                    // :465
         if (c->step.model_time + dt > end_time_seconds) dt = end_time_seconds - c->step.model_time;       // :469-471
         if (icar_substep(c, dt, (end_time_seconds - c->step.model_time) < dt * 2)) return 1;               // :474-539
