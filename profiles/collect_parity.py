@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """gpurun_out/parity/*.jsonl (written by the -m gpu parity tests on the MI355X box, tests/util.py:parity_record) ->
-profiles/r03_parity.json: per test label and field the MEASURED deviation from the CPU oracle
+profiles/<round>_parity.json: per test label and field the MEASURED deviation from the CPU oracle
 (bit-different fraction / cells, fraction beyond rtol 1e-5, max |d| / max|field|, max |d| / local scale), plus the worst
-value per label.  The bounds asserted in tests/ are <= 2.5x these.  usage: python profiles/collect_parity.py"""
-import glob, json, os
+value per label.  The bounds asserted in tests/ are <= 2.5x these.  usage: python profiles/collect_parity.py [round, default r04]"""
+import glob, json, os, sys
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "parity", "*.jsonl"))):
@@ -21,7 +22,7 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "parity", "*.jsonl"))
                     w[k] = max(w.get(k, 0), v)
         summary[lab] = w
     out[name] = {"worst_per_label": summary, "per_field": recs}
-json.dump(out, open(os.path.join(root, "profiles", "r03_parity.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(root, "profiles", RND + "_parity.json"), "w"), indent=1, sort_keys=True)
 for name, v in out.items():
     for lab, w in v["worst_per_label"].items():
         print(f"{name:10s} {lab:70s} " + "  ".join(f"{k}={x:.3g}" for k, x in sorted(w.items())))

@@ -74,7 +74,7 @@ def adv_args(c):
 
 def parity_record(test, label, stats):
     """Append the MEASURED deviation of a parity test to gpurun_out/parity/<test>.jsonl (merged back from the GPU box;
-    profiles/collect_parity.py turns the files into the tracked profiles/r03_parity.json).  Never raises."""
+    profiles/collect_parity.py turns the files into the tracked profiles/r0N_parity.json).  Never raises."""
     import json, os
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
