@@ -216,12 +216,14 @@ def test_halo_strips_in_one_launch_equal_four_launches():
     assert inner.max() == 0.0, "only the halo ring is processed"
 
 
-def test_thompson_full_size_every_column_bit_exact(th_oracle):
+@pytest.mark.parametrize("layout", [0, 2, 3])
+def test_thompson_full_size_every_column_bit_exact(th_oracle, layout):
     """The BASELINE tile (512 x 512 x 40): EVERY column of two microphysics calls, device vs the CPU oracle in the reference's own
-    math, bit for bit (the column subset above only samples 3000 of the 260 100)."""
-    out, ref = run_case(th_oracle, mode=0, nx=512, ny=512, nz=40, steps=2, cool=1.5, moist=1.8, dt=60.0)
+    math, bit for bit (the column subset above only samples 3000 of the 260 100) -- the product layout and the two lanes-along-i
+    layouts."""
+    out, ref = run_case(th_oracle, mode=0, nx=512, ny=512, nz=40, steps=2, cool=1.5, moist=1.8, dt=60.0, layout=layout)
     assert ref["rain"].max() > 1e-5 and ref["cloud_water"].max() > 1e-5 and ref["acc_rain"].max() > 0
-    check_close(out, ref, rtol=1e-5, label="full_size_every_column/mode0", **EXACT)
+    check_close(out, ref, rtol=1e-5, label=f"full_size_every_column/layout{layout}/mode0", **EXACT)
 
 
 @pytest.mark.parametrize("mode", [0])
