@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicar_hip.so")
-SOURCES = ["capi.hip", "advect.hip", "mpdata.hip", "mp_simple.hip", "mp_thompson.hip", "thompson_tables.hip", "step.hip", "linear_winds.hip", "iterative_winds.hip", "mp_wsm3.hip", "mp_wsm6.hip", "comm.hip", "timestep.hip"]
+SOURCES = ["capi.hip", "advect.hip", "mpdata.hip", "mpdata_exact.hip", "mp_simple.hip", "mp_thompson.hip", "thompson_tables.hip", "step.hip", "linear_winds.hip", "iterative_winds.hip", "mp_wsm3.hip", "mp_wsm6.hip", "comm.hip", "timestep.hip"]
 NO_SCRATCH = {"mp_thompson.hip": ["k_thompson_march"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # finite data only: drop the NaN-canonicalisation v_max x,x,x in front of every fmin/fmax (no effect on finite results)

@@ -133,6 +133,21 @@ static dim3 grid3(const Dims &d) { return dim3((d.nx + BX - 1) / BX, (d.nz + BY 
 
 int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv);   // mpdata.hip
 int icar_mpdata_coef_run(icar_hip_ctx *c, bool rho_on);                                                                       // mpdata.hip
+int icar_mpdata_exact_run(icar_hip_ctx *c, bool rho_on, bool fct, int order, const CVarPtrs &q, const VarPtrs &alt, int nv);   // mpdata_exact.hip
+
+// donor-cell pass in -> out (distinct buffers) with the given face velocities (U_m, V_m, W_m, or one scalar's limited pseudo-velocities)
+int icar_upwind_pass_run(icar_hip_ctx *c, bool rho_on, const CVarPtrs &in, const VarPtrs &out, int nv,
+                         const float *U, const float *V, const float *W)
+{
+    const float *rho = rho_on ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
+    const float *jaco = icar_field_f(c, ICAR_F_JACOBIAN), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
+    if (!jaco || !dz || (rho_on && !rho)) return 1;
+    dim3 g = grid3(c->d), b(BX, BY);
+    if (rho_on) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, in, out, nv, U, V, W, rho, jaco, dz);
+    else        hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, in, out, nv, U, V, W, rho, jaco, dz);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 static int ensure_adv_scratch(icar_hip_ctx *c)
 {
@@ -199,10 +214,13 @@ int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_
     };
     if (order == 1) {
         // q -> alt, swap  (upwind; or mpdata_order=1: adv_mpdata.f90:374,404-411)
-        dim3 g = grid3(c->d), b(BX, BY);
-        if (advect_density) hipLaunchKernelGGL((k_upwind_pass<true>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz);
-        else                hipLaunchKernelGGL((k_upwind_pass<false>), g, b, 0, c->stream, c->d, q, alt, n, c->U, c->V, c->W, rho, jaco, dz);
-        HIPCHK(hipGetLastError());
+        if (icar_upwind_pass_run(c, advect_density != 0, q, alt, n, c->U, c->V, c->W)) return 1;
+        swap_fields();
+        return 0;
+    }
+    if (c->mpdata_exact) {
+        // the reference's own operation order, four launches per scalar (mpdata_exact.hip): bit-identical to the CPU reference
+        if (icar_mpdata_exact_run(c, advect_density != 0, fct != 0, order, q, alt, n)) return 1;
         swap_fields();
         return 0;
     }

@@ -449,7 +449,7 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->field[f]) hipFree(c->field[f]);
     for (int f = 0; f < ICAR_N_ADVECTABLE; ++f) if (c->alt[f]) hipFree(c->alt[f]);
     for (int f = 0; f < ICAR_N_FIELDS; ++f) if (c->dqdt[f]) hipFree(c->dqdt[f]);
-    float *scr[] = {c->U, c->V, c->W, c->Wdz, c->d_red, c->mpc};
+    float *scr[] = {c->U, c->V, c->W, c->Wdz, c->d_red, c->mpc, c->mpx_buf};
     for (float *p : scr) if (p) hipFree(p);
     if (c->d_flag) hipFree(c->d_flag);
     if (c->h_cfl_pre) hipHostFree(c->h_cfl_pre);
@@ -560,6 +560,13 @@ int icar_hip_advect(icar_hip_ctx *c, int scheme, int mpdata_order, int fct, int 
     if (!c || (!fields && nfields > 0)) { icar_set_error("advect: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_advect_run(c, scheme, mpdata_order, fct, advect_density, fields, nfields);
+}
+
+int icar_hip_mpdata_exact(icar_hip_ctx *c, int on)
+{
+    if (!c || (on != 0 && on != 1)) { icar_set_error("mpdata_exact: ctx and on = 0 / 1"); return 1; }
+    c->mpdata_exact = on;
+    return 0;
 }
 
 int icar_hip_mp_simple(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_count)

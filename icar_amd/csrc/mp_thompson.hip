@@ -347,7 +347,9 @@ __device__ __forceinline__ int th_wave_max(int v) { for (int o = 32; o > 0; o >>
 // level loop spills ~60 VGPRs on top of ~200 SGPRs parked in VGPR lanes, and that build returned wrong rain numbers at
 // the top rain level of some columns (same source; with -DTH_MARCH_WAVES=2 every test is bit-exact) -- icar_amd/build.py
 // refuses a build of this kernel that needs scratch.
+#ifndef TH_MARCH_WAVES
 #define TH_MARCH_WAVES 2
+#endif
 __global__ void __launch_bounds__(64, TH_MARCH_WAVES)
 k_thompson_march(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
                  float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,

@@ -135,6 +135,13 @@ int icar_hip_setup_winds(icar_hip_ctx *ctx, int scheme, float dt, float dx, int 
  * use 1-ulp reciprocals and agree with it to 1e-5 of the local field scale (tests/test_gpu_advect.py). */
 int icar_hip_advect(icar_hip_ctx *ctx, int scheme, int mpdata_order, int fct, int advect_density,
                     const int *fields, int nfields);
+
+/* Corrective iterations of MPDATA in the reference's own operation order (on = 1): donor cell, mpdata_fluxes, flux_limiter +
+ * FCT core and the final donor cell as separate launches per scalar, IEEE division, no contraction -- the advected fields are
+ * then BIT-IDENTICAL to src/physics/adv_mpdata.f90:356-418 on the CPU, and so is a whole sub-step sequence
+ * (tests/test_gpu_advect.py, tests/test_gpu_trajectory.py).  Costs ~100 B of HBM traffic per scalar-cell instead of 8; the
+ * default (on = 0) is the fused kernel.  No counterpart in the reference (it has one arithmetic). */
+int icar_hip_mpdata_exact(icar_hip_ctx *ctx, int on);
 /* 1 while the Courant winds of the last icar_hip_setup_winds still belong to the state (nothing has rewritten u, v, w, density
  * or a jacobian since), else 0: a host that launches the setup early -- beside the interior microphysics, see INTEGRATION.md --
  * asks before it skips the setup in advect(). */

@@ -9,18 +9,21 @@ import pytest
 from icar_amd import ideal
 from icar_amd.options import options_t
 from icar_amd.advection import advect
+from icar_amd.capi import lib, check
 from icar_amd.constants import kADV_UPWIND, kADV_MPDATA
 from util import SCALARS, MEMBER, KVAR, bits_equal, nbitdiff, single_image_domain, adv_args, assert_fields_close, local_rel_err, parity_record
 
 pytestmark = pytest.mark.gpu
 
 
-def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2, fct=True, nsteps=2, noise=0.01):
+def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2, fct=True, nsteps=2, noise=0.01, exact_mode=False):
     c = ideal.make_case(nx, ny, nz, hill_height=hill, noise=noise, n_hydro=1)
     dt = ideal.cfl_dt(c)
     q = np.stack([c[n] for n in names]).copy()
     oracle.advect(scheme, q, *adv_args(c), dt, advect_density=dens, mpdata_order=order, fct=fct, nsteps=nsteps)
     d = single_image_domain(c)
+    if exact_mode:
+        check(lib().icar_hip_mpdata_exact(d.ctx, 1), "mpdata_exact")
     opt = options_t()
     opt.physics.advection = scheme
     opt.parameters.advect_density = dens
@@ -31,7 +34,7 @@ def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2
         advect(d, opt, dt)
     out = {n: d.get(MEMBER[n]) for n in names}
     d.close()
-    exact = (scheme == kADV_UPWIND) or order == 1
+    exact = (scheme == kADV_UPWIND) or order == 1 or exact_mode
     worst = 0.0; stats = {}
     for m, n in enumerate(names):
         assert np.abs(out[n] - c[n]).max() > 0, f"{n}: advection did nothing"
@@ -42,7 +45,7 @@ def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2
             err = assert_fields_close(out[n], q[m], n); worst = max(worst, err)
             stats[n] = {"max_local_rel": err, "bitdiff_cells": nbitdiff(out[n], q[m]), "cells": int(q[m].size),
                         "max_abs_over_max": float(np.abs(out[n].astype(np.float64) - q[m]).max() / max(float(np.abs(q[m]).max()), 1e-300))}
-    parity_record("advect", f"{'upwind' if scheme == kADV_UPWIND else 'mpdata'} {nx}x{ny}x{nz} order{order} fct{int(fct)} dens{int(dens)} steps{nsteps}", stats)
+    parity_record("advect", f"{'upwind' if scheme == kADV_UPWIND else ('mpdata(exact)' if exact_mode else 'mpdata')} {nx}x{ny}x{nz} order{order} fct{int(fct)} dens{int(dens)} steps{nsteps}", stats)
     return worst
 
 
@@ -59,6 +62,31 @@ def test_mpdata_vs_oracle(oracle, dens, fct, order):
     # (the tolerance is a per-step bound: one step for the higher orders, whose extra iterations compound the rounding)
     run_case(oracle, kADV_MPDATA, 70, 37, 12, ["water_vapor", "cloud_water", "potential_temperature"],
              dens=dens, fct=fct, order=order, nsteps=2 if order <= 2 else 1)
+
+
+@pytest.mark.parametrize("dens,fct,order", [(False, True, 2), (True, True, 2), (False, False, 2), (False, True, 3), (True, True, 3),
+                                            (False, False, 3), (False, True, 4)])
+def test_mpdata_exact_mode_bit_exact(oracle, dens, fct, order):
+    """icar_hip_mpdata_exact(ctx, 1): the corrective iterations in the reference's operation order (mpdata_exact.hip) --
+    EVERY cell of every scalar bit-identical to the CPU oracle (itself bit-identical to adv_mpdata.f90 compiled unmodified) over
+    several steps, for mpdata_order 2 .. 4, with and without the limiter and advect_density."""
+    run_case(oracle, kADV_MPDATA, 70, 37, 12, ["water_vapor", "cloud_water", "potential_temperature"],
+             dens=dens, fct=fct, order=order, nsteps=3, exact_mode=True)
+
+
+def test_mpdata_exact_mode_sizes(oracle):
+    """ragged sizes, the smallest lines the limiter is defined for (3 cells), all 9 Thompson scalars, config[1]'s grid"""
+    run_case(oracle, kADV_MPDATA, 5, 4, 3, ["water_vapor"], hill=0.0, nsteps=2, exact_mode=True)
+    run_case(oracle, kADV_MPDATA, 129, 3, 5, ["water_vapor", "cloud_water"], nsteps=2, exact_mode=True)
+    run_case(oracle, kADV_MPDATA, 66, 34, 10, SCALARS, nsteps=2, exact_mode=True)
+    run_case(oracle, kADV_MPDATA, 256, 256, 40, ["water_vapor", "cloud_water", "rain"], nsteps=2, exact_mode=True)
+
+
+def test_mpdata_exact_mode_full_size_every_cell(oracle):
+    """512x512x40 (BASELINE metric size), the 9 Thompson scalars, two steps: every cell bit-identical to the CPU oracle; and the
+    fused kernel (the default) within its 1e-5 of THIS result, i.e. the two device paths agree with each other as they do with
+    the reference"""
+    run_case(oracle, kADV_MPDATA, 512, 512, 40, SCALARS, nsteps=2, exact_mode=True)
 
 
 @pytest.mark.parametrize("nx,ny,nz", [(61, 70, 41), (64, 40, 80), (200, 130, 40), (100, 100, 30), (70, 46, 7)])

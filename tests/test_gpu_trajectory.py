@@ -15,8 +15,9 @@ from icar_amd import ideal
 from icar_amd.options import options_t
 from icar_amd.microphysics import mp, mp_init, mp_var_request
 from icar_amd.advection import advect, adv_init
+from icar_amd.capi import lib, check
 from icar_amd.constants import kADV_MPDATA, kMP_THOMPSON, kMP_SB04
-from util import single_image_domain, field_stats, parity_record, local_rel_err, assert_fields_close, SCALARS, MEMBER
+from util import single_image_domain, field_stats, parity_record, local_rel_err, assert_fields_close, bits_equal, nbitdiff, SCALARS, MEMBER
 
 pytestmark = pytest.mark.gpu
 ADV_ORDER = ["water_vapor", "cloud_water", "rain", "snow", "potential_temperature", "cloud_ice", "graupel", "ice_number", "rain_number"]
@@ -99,6 +100,49 @@ def test_trajectory_ten_unsynchronised_substeps(th_oracle, oracle, scheme):
         bb = EARLY_BOUNDS[scheme].get(it, b)
         assert w["beyond_rtol_frac"] <= bb["beyond"] and w["max_abs_over_max"] <= bb["absmax"], (scheme, it, w)
     assert rel_p <= 1e-3, rel_p
+    d.close()
+
+
+@pytest.mark.parametrize("scheme", ["thompson", "simple"])
+def test_trajectory_exact_mode_bit_identical_over_ten_substeps(th_oracle, oracle, scheme):
+    """The same ten unsynchronised [microphysics -> MPDATA] sub-steps with icar_hip_mpdata_exact(ctx, 1): the device trajectory
+    is BIT-IDENTICAL to the CPU oracle's after every sub-step -- every cell of every advected scalar and the accumulated
+    precipitation.  With the advection in the reference's operation order nothing on the path rounds differently from the CPU
+    reference, so the drift test_trajectory_ten_unsynchronised_substeps measures is the fused kernel's 1-ulp reciprocals
+    amplified by the case, and nothing else."""
+    nx, ny, nz, nsteps = 128, 96, 40, 10
+    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.6)).astype(np.float32)
+    dt = float(np.float32(min(ideal.cfl_dt(c), 60.0)))
+    opt = options_t(); opt.physics.advection = kADV_MPDATA
+    opt.physics.microphysics = kMP_THOMPSON if scheme == "thompson" else kMP_SB04
+    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"])
+    mp_var_request(opt)
+    names = ADV_ORDER if scheme == "thompson" else ADV_ORDER[:5]
+    d = single_image_domain(c)
+    check(lib().icar_hip_mpdata_exact(d.ctx, 1), "mpdata_exact")
+    mp_init(opt, d); adv_init(d, opt)
+    s = {n: c[n].copy() for n in names}
+    acc = np.zeros((ny, nx), np.float64)
+    orc = th_oracle if scheme == "thompson" else oracle
+    orc.set_math_mode(0)
+    for it in range(nsteps):
+        mp(d, opt, dt); d.model_time_seconds += dt
+        advect(d, opt, dt)
+        if scheme == "thompson":
+            acc += _thompson_oracle_step(orc, s, c, dt, nx, ny, nz)
+        else:
+            rain = np.zeros((ny, nx), np.float32); snow = rain.copy()
+            orc.mp_simple(c["pressure"], s["potential_temperature"], c["exner"], c["density"], s["water_vapor"], s["cloud_water"],
+                          s["rain"], s["snow"], rain, snow, dt, c["dz_mass"], 2, nx - 1, 2, ny - 1, 1, nz)
+            acc += rain
+        _advect_oracle(orc, s, c, dt, names)
+        for n in names:
+            got = d.get(MEMBER[n])
+            assert bits_equal(got, s[n]), f"{scheme} sub-step {it + 1}, {n}: {nbitdiff(got, s[n])} of {got.size} cells differ"
+    assert acc.max() > 0 and float(s["cloud_water"].max()) > 1e-6, "the case must have active microphysics"
+    assert np.array_equal(d.get("accumulated_precipitation"), acc)
+    parity_record("trajectory", f"{scheme}/128x96x40/exact_mode_{nsteps}_substeps", {n: {"bitdiff_cells": 0, "cells": int(s[n].size)} for n in names})
     d.close()
 
 
