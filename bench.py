@@ -337,6 +337,8 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true", help="profiling: leave the library's per-group HIP-event timers off (roofline.avg_ms is then 0)")
     ap.add_argument("--thompson-layout", type=int, default=0, choices=[0, 1, 2, 3],
                     help="profiling: thread layout of the Thompson interior launch (icar_hip_thompson_layout; 0 = the library's default)")
+    ap.add_argument("--mpdata-exact", action="store_true",
+                    help="advect with icar_hip_mpdata_exact(ctx, 1): MPDATA in the reference's operation order, bit-identical to the CPU reference")
     ap.add_argument("--ref-child", default=None, help=argparse.SUPPRESS)      # internal: cpu_reference()'s child process
     ap.add_argument("--ref-nscal", type=int, default=9, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -375,6 +377,8 @@ def main():
     from icar_amd import capi
     d, opt, case, g = build_tile(args, rank, world, dev_index)
     lib = capi.lib()
+    if args.mpdata_exact:
+        capi.check(lib.icar_hip_mpdata_exact(d.ctx, 1), "icar_hip_mpdata_exact")
     if args.thompson_layout:
         capi.check(lib.icar_hip_thompson_layout(d.ctx, args.thompson_layout), "icar_hip_thompson_layout")
     kind = int(lib.icar_hip_comm_kind(d.ctx))
@@ -511,7 +515,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.nx}x{args.ny}x{args.nz} global grid" if args.scaling == "strong" else
                                     f"{args.nx}x{args.ny}x{args.nz} owned cells per GPU ({g.nx_global}x{g.ny_global}x{args.nz} global)") +
-                                   f", {'mpdata order-2+FCT' if args.adv == 'mpdata' else 'upwind'} advection of "
+                                   f", {('mpdata order-2+FCT (reference operation order, bit-exact mode)' if args.mpdata_exact else 'mpdata order-2+FCT') if args.adv == 'mpdata' else 'upwind'} advection of "
                                    f"{nscal} scalars + {args.mp} microphysics, ideal hill case (SURVEY 8d)",
                        "global_grid": [g.nx_global, g.ny_global, args.nz],
                        "tile_memory": [d.nx, d.nz, d.ny], "decomposition": f"{g.ximages}x{g.yimages}",

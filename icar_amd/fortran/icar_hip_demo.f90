@@ -1,6 +1,6 @@
 !> icar_hip_demo.f90 -- Fortran host driving the device hot path through the C ABI.
 !! Reads a tile written by tests/test_gpu_fortran_host.py (raw little-endian REAL(4), Fortran order),
-!! runs `nsteps` x [mp_simple on the interior tile -> advection (scheme from meta.txt: 1 upwind, 2 MPDATA) of the 5 mp_simple scalars]
+!! runs `nsteps` x [mp_simple on the interior tile -> advection (scheme from meta.txt: 1 upwind, 2 MPDATA, 3 MPDATA in the reference's operation order = hip_mpdata_exact) of the 5 mp_simple scalars]
 !! exactly as time_step.f90:512-529 orders them for one image, and writes the fields back.
 program icar_hip_demo
   use iso_c_binding
@@ -30,9 +30,10 @@ program icar_hip_demo
   call rdu(trim(dir)//"/jacobian_u.bin", au); call hip_upload(ctx, ICAR_F_JACOBIAN_U, au)
   call rdu(trim(dir)//"/v.bin", av); call hip_upload(ctx, ICAR_F_V, av)
   call rdu(trim(dir)//"/jacobian_v.bin", av); call hip_upload(ctx, ICAR_F_JACOBIAN_V, av)
+  if (scheme == 3) call hip_mpdata_exact(ctx, .true.)
   do s = 1, nsteps
      call hip_mp_simple(ctx, dt, 2, nx-1, 2, ny-1, 1, nz)             ! mp()   time_step.f90:512-523
-     call hip_advect(ctx, scheme, 2, .true., .false., dt, dx, adv)    ! advect time_step.f90:529 (kADV_UPWIND / kADV_MPDATA)
+     call hip_advect(ctx, min(scheme, 2), 2, .true., .false., dt, dx, adv)    ! advect time_step.f90:529 (kADV_UPWIND / kADV_MPDATA)
   end do
   do i = 9, 13
      call hip_download(ctx, f3(i), a); call wr(trim(dir)//"/out_"//trim(n3(i))//".bin", a)

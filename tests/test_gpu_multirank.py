@@ -168,6 +168,10 @@ def _worker_oracle(rank, world, port, adv, q):
         opt = _options("mpdata", case)
         g = grid_t().set_grid_dimensions(NXG, NYG, NZ, world, rank + 1)
         d = _setup(case, g, opt, HaloComm(g, rank + 1), dev)
+        exact = adv == "mpdata-exact"                 # icar_hip_mpdata_exact: the reference's operation order -> bit for bit, never re-synchronised
+        if exact:
+            from icar_amd.capi import lib, check
+            check(lib().icar_hip_mpdata_exact(d.ctx, 1), "mpdata_exact")
         dt = 0.8 * ideal.cfl_dt(case)
         def tile_of(a):
             if a.ndim == 3 and a.shape[2] == NXG + 1: return np.ascontiguousarray(a[g.jms - 1:g.jme, :, g.ims - 1:g.ime + 1])
@@ -191,6 +195,9 @@ def _worker_oracle(rank, world, port, adv, q):
             # step; the oracle then continues from the device state so that the bound stays a per-step bound
             for f, n in zip(fids, NAMES):
                 a = d.get(n)
+                if exact:
+                    assert np.array_equal(a.view(np.int32), host[f].view(np.int32)), f"rank {rank} {n}: {(a != host[f]).sum()} cells of the tile differ from the tiled oracle"
+                    continue
                 assert_fields_close(a, host[f], f"rank {rank} {n}")
                 host[f][...] = a
         d.close()
@@ -274,6 +281,14 @@ def test_tiled_mpdata_equals_tiled_oracle():
     from oracle import orc
     orc.build()
     _run(_worker_oracle, 4, "mpdata")
+
+
+def test_tiled_mpdata_exact_mode_equals_tiled_oracle_bit_for_bit():
+    """four device tiles, [halo exchange -> MPDATA in the reference's operation order] x 3 without re-synchronising: every cell of
+    every tile (halo planes included) bit-identical to the CPU oracle run on host tiles with the same exchange"""
+    from oracle import orc
+    orc.build()
+    _run(_worker_oracle, 4, "mpdata-exact")
 
 
 def test_tiled_iterative_winds_equals_tiled_oracle():
