@@ -146,6 +146,77 @@ def test_trajectory_exact_mode_bit_identical_over_ten_substeps(th_oracle, oracle
     d.close()
 
 
+def test_whole_step_loop_exact_mode_equals_cpu_chain(th_oracle, oracle):
+    """icar_hip_step -- the library's own loop of time_step.f90:440-551: update_dt (CFL maximum on the device, prefetched beside the
+    advection) -> diagnostic_update -> Thompson (strips + interior on two streams) -> halo self-exchange -> MPDATA -> apply_forcing
+    of qv, theta, u, v, w, p -> enforce_limits in the last two sub-steps, the last sub-step shortened to the end time -- with
+    icar_hip_mpdata_exact(ctx, 1), against the SAME loop assembled on the CPU from the oracle's operators.  The winds and the
+    pressure are forced, so every sub-step has its own dt, exner and Courant winds.  Sub-step count, every dt, every prognostic
+    field, exner / density and the accumulated precipitation: bit for bit."""
+    from icar_amd.time_step import step
+    nx, ny, nz = 96, 64, 20
+    c = ideal.make_case(nx, ny, nz, hill_height=900.0, noise=0.01, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.35)).astype(np.float32)
+    rng = np.random.default_rng(5)
+    c["dzdx"] = (0.05 * rng.standard_normal(c["u"].shape)).astype(np.float32)
+    c["dzdy"] = (0.05 * rng.standard_normal(c["v"].shape)).astype(np.float32)
+    dq = {"water_vapor": 1e-8, "potential_temperature": 1e-4, "u": 5e-4, "v": -5e-4, "pressure": 1e-3, "w": 2e-6}
+    dq = {k: (sc * rng.standard_normal(c[k].shape)).astype(np.float32) for k, sc in dq.items()}
+    forced = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
+    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON
+    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"]); opt.parameters.ideal = True
+    mp_var_request(opt)
+    d = single_image_domain(c)
+    check(lib().icar_hip_mpdata_exact(d.ctx, 1), "mpdata_exact")
+    mp_init(opt, d); adv_init(d, opt)
+    for k, a in dq.items():
+        d.set_dqdt(k, a)
+    f32 = np.float32
+    dt0 = min(float(f32(0.9) / f32(oracle.max_courant(c["u"], c["v"], c["w"], c["dz_levels"], float(c["dx"])))), 120.0)
+    end = 6.4 * dt0                                           # ~7 sub-steps, the last one shortened
+    n_dev = step(d, end, opt, forced=forced, diagnostics=True)
+    # ---- the same loop on the CPU ----
+    s = {k: c[k].copy() for k in ADV_ORDER + ["u", "v", "w", "pressure"]}
+    acc = np.zeros((ny, nx), np.float64)
+    th_oracle.set_math_mode(0); oracle.set_math_mode(0)
+    t, n_cpu, dts, t_mp = 0.0, 0, [], None
+    while t < end:                                                                                      # :462
+        dt = min(float(f32(0.9) / f32(oracle.max_courant(s["u"], s["v"], s["w"], c["dz_levels"], float(c["dx"])))), 120.0)   # :465, :417
+        if t + dt > end: dt = end - t                                                                   # :469-471
+        enforce = (end - t) < dt * 2
+        dt4 = float(f32(dt))
+        diag = oracle.diagnostic_update(s["pressure"], s["potential_temperature"], s["u"], s["v"], s["w"], c["dzdx"], c["dzdy"], c["jacobian"])   # :474
+        z = [np.zeros((ny, nx), np.float32) for _ in range(5)]
+        # mp_driver.f90:698-713: the microphysics integrates over the time since ITS last call (= the previous sub-step's dt), the
+        # first call over this sub-step's
+        mp_dt = dt4 if t_mp is None else float(f32(t - t_mp)); t_mp = t
+        th_oracle.thompson(s["water_vapor"], s["cloud_water"], s["rain"], s["cloud_ice"], s["snow"], s["graupel"], s["ice_number"],
+                           s["rain_number"], s["potential_temperature"], diag["exner"], s["pressure"], c["dz_mass"], mp_dt, *z,
+                           1, nx, 1, ny, 1, nz, 2, nx - 1, 2, ny - 1, 1, nz)                             # :512-523
+        acc += z[0]
+        q = np.stack([s[n] for n in ADV_ORDER]).copy()
+        oracle.advect(2, q, s["u"], s["v"], s["w"], diag["density"], c["jacobian"], c["jacobian_u"], c["jacobian_v"], c["jacobian_w"],
+                      c["advection_dz"], c["dz_levels"], float(c["dx"]), dt4)                            # :529
+        for m, n in enumerate(ADV_ORDER): s[n] = q[m].copy()
+        for n, fb in forced:                                                                            # :534
+            oracle.apply_forcing(s[n], dq[n], dt, int(fb), 1, 1, 1, 1)
+        if enforce:
+            for n in ADV_ORDER: oracle.enforce_limits(s[n])
+        t += dt; n_cpu += 1; dts.append(dt)
+    assert n_dev == n_cpu and n_cpu >= 6, (n_dev, n_cpu)
+    assert all(np.isfinite(a).all() for a in s.values()) and float(s["potential_temperature"].max()) < 600.0, "the case must stay physical"
+    assert abs(d.model_time_seconds - t) == 0.0 or abs(d.model_time_seconds - end) < 1e-9
+    dev_name = dict(MEMBER); dev_name.update({"u": "u", "v": "v", "w": "w", "pressure": "pressure"})
+    for n in ADV_ORDER + ["u", "v", "w", "pressure"]:
+        got = d.get(dev_name[n])
+        assert bits_equal(got, s[n]), f"{n}: {nbitdiff(got, s[n])} of {got.size} cells differ after {n_cpu} sub-steps"
+    assert bits_equal(d.get("exner"), diag["exner"]) and bits_equal(d.get("density"), diag["density"])
+    assert acc.max() > 0 and np.array_equal(d.get("accumulated_precipitation"), acc)
+    assert len(set(dts)) == len(dts), "forced winds: every sub-step must have had its own dt"
+    parity_record("trajectory", f"whole_step_loop/96x64x20/exact_mode_{n_cpu}_substeps", {n: {"bitdiff_cells": 0, "cells": int(s[n].size)} for n in s})
+    d.close()
+
+
 def test_config1_256x256x40_mpdata_thompson_substep(th_oracle):
     """BASELINE configs[1] at its literal size: one [Thompson -> MPDATA order 2 + FCT of the 9 scalars] step on 256 x 256 x 40.
     Thompson: every column bit for bit (the device evaluates the C library's float functions).  MPDATA: every cell of every
