@@ -59,7 +59,8 @@ struct icar_hip_ctx {
     float *mpc = nullptr;                // MPDATA: the eleven scalar-independent coefficient arrays of this step's winds (mpdata.hip)
     int mpc_dens = -1;
     float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
-    float *mpx_buf = nullptr;            // mpdata_exact.hip: q2 (x2), u2, v2, w2 and their limited copies of ONE scalar (8 fields)
+    float *mpx_buf = nullptr;            // mpdata_exact.hip: q2 (x2), u2, v2, w2 of mpx_nv scalars and the limited velocities of one
+    int mpx_nv = 0;
     int mpdata_exact = 0;                // icar_hip_mpdata_exact: corrective iterations in the reference's operation order (bit-exact)
     bool winds_valid = false;
     // u / v / w bookkeeping for the prefetched CFL reduction (icar_hip_max_courant_prefetch): every entry point that writes a wind
