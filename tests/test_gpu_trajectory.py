@@ -217,8 +217,10 @@ def test_whole_step_loop_exact_mode_equals_cpu_chain(th_oracle, oracle):
     d.close()
 
 
-def test_config1_256x256x40_mpdata_thompson_substep(th_oracle):
-    """BASELINE configs[1] at its literal size: one [Thompson -> MPDATA order 2 + FCT of the 9 scalars] step on 256 x 256 x 40.
+@pytest.mark.parametrize("exact", [False, True])
+def test_config1_256x256x40_mpdata_thompson_substep(th_oracle, exact):
+    """(exact: with icar_hip_mpdata_exact(ctx, 1) the advected fields are bit-identical too)
+    BASELINE configs[1] at its literal size: one [Thompson -> MPDATA order 2 + FCT of the 9 scalars] step on 256 x 256 x 40.
     Thompson: every column bit for bit (the device evaluates the C library's float functions).  MPDATA: every cell of every
     scalar within 1e-5 of the local field scale, from the oracle's own post-microphysics state == the device's."""
     nx, ny, nz = 256, 256, 40
@@ -229,6 +231,7 @@ def test_config1_256x256x40_mpdata_thompson_substep(th_oracle):
     opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"])
     mp_var_request(opt)
     d = single_image_domain(c)
+    if exact: check(lib().icar_hip_mpdata_exact(d.ctx, 1), "mpdata_exact")
     mp_init(opt, d); adv_init(d, opt)
     s = {n: c[n].copy() for n in ADV_ORDER}
     th_oracle.set_math_mode(0)
@@ -241,11 +244,14 @@ def test_config1_256x256x40_mpdata_thompson_substep(th_oracle):
     advect(d, opt, dt)
     _advect_oracle(th_oracle, s, c, dt, ADV_ORDER)
     for n in ADV_ORDER:
-        assert_fields_close(d.get(MEMBER[n]), s[n], n, record=("trajectory", "config1/256x256x40/mpdata_after_thompson"))
+        if exact: assert bits_equal(d.get(MEMBER[n]), s[n]), f"{n}: {nbitdiff(d.get(MEMBER[n]), s[n])} cells differ"
+        else: assert_fields_close(d.get(MEMBER[n]), s[n], n, record=("trajectory", "config1/256x256x40/mpdata_after_thompson"))
+    if exact: parity_record("trajectory", "config1/256x256x40/exact_mode_substep", {n: {"bitdiff_cells": 0, "cells": int(s[n].size)} for n in ADV_ORDER})
     d.close()
 
 
-def test_config3_tile_update_winds_then_substep(th_oracle, oracle):
+@pytest.mark.parametrize("exact", [False, True])
+def test_config3_tile_update_winds_then_substep(th_oracle, oracle, exact):
     """The per-GPU workload of BASELINE configs[3] (1024 x 1024 x 40 on 2 x 4 images: a 512 x 256 x 40 tile): update_winds with
     windtype kWIND_LINEAR -- spatial_winds interpolating a look-up table (uploaded, 2 x 4 x 3 entries: the build is the init-time
     row W3, tests/test_gpu_winds.py) + balance_uvw -- then [Thompson -> MPDATA] with the new winds.  Winds and the microphysics
@@ -271,6 +277,7 @@ def test_config3_tile_update_winds_then_substep(th_oracle, oracle):
     lt = opt.lt_options
     mp_var_request(opt)
     d = domain_t(grid_t().set_grid_dimensions(nx, ny, nz, 1, 1), device=0, dx=dxf)
+    if exact: check(lib().icar_hip_mpdata_exact(d.ctx, 1), "mpdata_exact")     # MPDATA in the reference's operation order: bit for bit
     d.load_case(c)
     zc = (np.cumsum(c["dz_levels"]) - c["dz_levels"] / 2).astype(np.float32)
     z3 = np.ascontiguousarray(c["terrain"][:, None, :] + zc[None, :, None] * np.ones((ny, 1, nx), np.float32), np.float32)
@@ -310,5 +317,6 @@ def test_config3_tile_update_winds_then_substep(th_oracle, oracle):
     advect(d, opt, dt)
     _advect_oracle(th_oracle, s, cw, dt, ADV_ORDER)
     for n in ADV_ORDER:
-        assert_fields_close(d.get(MEMBER[n]), s[n], n, record=("trajectory", "config3_tile/512x256x40/mpdata_with_linear_winds"))
+        if exact: assert bits_equal(d.get(MEMBER[n]), s[n]), f"{n}: {nbitdiff(d.get(MEMBER[n]), s[n])} cells differ"
+        else: assert_fields_close(d.get(MEMBER[n]), s[n], n, record=("trajectory", "config3_tile/512x256x40/mpdata_with_linear_winds"))
     d.close()
