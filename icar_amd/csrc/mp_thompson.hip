@@ -17,6 +17,9 @@
 #include "fp64_math.h"
 #define GF_LDS_TABLES          // the look-up tables of expf / logf / powf in LDS: every kernel below starts with gf_lds_init()
 #include "glibc_flt32.h"
+#define GD_LDS_TABLES          // ... and those of the DOUBLE PRECISION pow / log / exp (7 KB): th_lds_init() = both
+#include "glibc_dbl64.h"
+__device__ __forceinline__ void th_lds_init(int tid, int nthreads) { gd_lds_init(tid, nthreads); gf_lds_init(tid, nthreads); }
 #include "column_comm.h"
 #include <cmath>
 #include <cstdlib>
@@ -26,35 +29,23 @@ const ThState *icar_thompson_device_state(icar_hip_ctx *c);
 const ThState *icar_thompson_host_state(icar_hip_ctx *c);
 
 namespace {
-// x**y for the positive bases the scheme uses: exp(y*log(x)) in FP64 (relative error ~1e-14, i.e. the
-// float result is the correctly rounded one with probability 1 - 1e-7).
-// every kernel below holds `const DK K_ = d_consts();` (fp64_math.h): the log / exp coefficients stay in scalar registers
-#define d_exp(x) d_exp_k(K_, (x))
-#define d_log(x) d_log_k(K_, (x))
-#define d_pow(x, y) d_pow_k(K_, (x), (y))
+// DOUBLE PRECISION x**y, log, exp: the C library's pow / log / exp bit for bit (glibc_dbl64.h), which is what the compiled reference
+// calls (round 4: until then exp(y log x) with FP64 polynomials of our own -- < 1 ulp of the double, and one float ulp away from
+// the reference in ~1e-7 of the cells of a step).  pow is log_inline (a function of the base alone: the powers of one base share
+// it, d_plog / d_pow_l -- the same bits as separate pow calls) followed by exp_inline.
+// every kernel below holds `const DK K_ = d_consts();` (fp64_math.h) for the REAL(4) helpers that still take it
+#define d_exp(x) gd_exp(x)
+#define d_log(x) gd_log(x)
+#define d_pow(x, y) gd_pow((x), (y))
+#define d_plog(x) gd_pow_log(gd_asuint64(x))          /* of a positive, normal DOUBLE PRECISION base */
 #define d_powf(x, y) d_powf_k(K_, (x), (y))
-#define d_pow_l(L, y) d_pow_l_k(K_, (L), (y))
+#define d_pow_l(L, y) d_pow_l_k((L), (y))
 #define d_powf_l(L, y) d_powf_l_k(K_, (L), (y))
 #define d_pow10f(y) d_pow10f_k(K_, (y))
 #define d_expf(x) d_expf_k(K_, (x))
 #define d_log10f(x) d_log10f_k(K_, (x))
-__device__ __forceinline__ double d_pow_k(const DK &K_, double x, double y)
-{
-    // every lane evaluates the positive-finite-base form (exp(0 * log x) is exactly 1, so y = 0 needs no case of its own);
-    // one never-taken branch then replaces the value where the base is not positive and finite -- not reached by the scheme's
-    // bases: 1 for y = 0, 0**y = 0 / +inf and (+inf)**y = +inf / 0 like libm, NaN for a negative base (Fortran: invalid for a
-    // REAL exponent) or a NaN.  (Written as if / else-if the special cases cost seven exec-mask instructions per call site.)
-    double r = d_exp(y * d_log(x));
-    if (!__builtin_amdgcn_class(x, 0x100 | 0x080)) {               // not (+normal or +subnormal)
-        if (y == 0.0) r = 1.0;
-        else if (x == 0.0) r = y > 0.0 ? 0.0 : __builtin_inf();
-        else if (x == __builtin_inf()) r = y > 0.0 ? __builtin_inf() : 0.0;
-        else r = __builtin_nan("");
-    }
-    return r;
-}
-// the same values from L = d_log(x) of a DOUBLE PRECISION base x > 0 that several powers share (one logarithm instead of one per power)
-__device__ __forceinline__ double d_pow_l_k(const DK &K_, double L, double y) { return (y == 0.0) ? 1.0 : d_exp(y * L); }
+// x**y from L = log_inline(x) for the scheme's exponents (finite, 2^-65 <= |y| < 2^63, or zero)
+__device__ __forceinline__ double d_pow_l_k(const GdLog &L, double y) { return (y == 0.0) ? 1.0 : gd_pow_exp(L, y, 0); }
 // REAL(4) x**y, exp, log10: the C library's powf / expf / log10f bit for bit (glibc_flt32.h), which is what the compiled
 // reference calls.  powf is exp2(y * log2 x) with the log2 part a function of the base alone: powers of one base share it
 // (PowBase; the same bits as separate powf calls, any base -- an unusual one takes powf itself).
@@ -184,7 +175,7 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
                 double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
                 float dt, int i0, int i1, int j0, int k0, int nk)
 {
-    gf_lds_init(threadIdx.x, blockDim.x);
+    th_lds_init(threadIdx.x, blockDim.x);
     const int lane = threadIdx.x & 63;
     const int i = i0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int j = j0 + blockIdx.y;
@@ -228,7 +219,7 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
                 float dt, ThTiles tl, int k0, int nk, int cpb)
 {
     extern __shared__ double lds_pack[];
-    gf_lds_init(threadIdx.x, blockDim.x);
+    th_lds_init(threadIdx.x, blockDim.x);
     // several (its..ite, jts..jte) tiles in one launch (process_halo's four strips): block -> tile by prefix offsets
     // XCD-aware order: workgroups go to the 8 XCDs round-robin; neighbouring column groups share 64-B lines (a group is
     // 24 B wide at nz = 40), so each XCD takes runs of XCD_RUN consecutive groups and the shared lines hit in its L2.
@@ -358,7 +349,7 @@ k_thompson_march(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, 
                  float dt, MarchArgs a, float *__restrict__ ws)
 {
     __shared__ float hist[TH_MARCH_ROWS * 64];
-    gf_lds_init(threadIdx.x, 64);
+    th_lds_init(threadIdx.x, 64);
     const float R1 = TH_R1, R2 = TH_R2, eps = TH_eps;
     const int lane = threadIdx.x, col = blockIdx.x * 64 + lane, nk = a.nk, kte = nk - 1;
     const bool on = col < a.ncol;
@@ -611,7 +602,7 @@ k_thompson_slab(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
                 float dt, MarchArgs a, float *__restrict__ ws)
 {
     __shared__ SlabLds L;
-    gf_lds_init(threadIdx.x, 256);
+    th_lds_init(threadIdx.x, 256);
     const float R1 = TH_R1, eps = TH_eps;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane, nk = a.nk, kte = nk - 1;
     const int nslab = (nk + 3) / 4;
@@ -719,21 +710,21 @@ k_thompson_slab(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 // arguments come from the host so that nothing is folded at compile time: the value must be what a level computes at run time
 __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
 {
-    gf_lds_init(threadIdx.x, blockDim.x);
+    th_lds_init(threadIdx.x, blockDim.x);
     const DK K_ = d_consts();
 
     T->N0_exp_default = th_graupel_N0_exp(rg, xslw1);
     T->pw_cgg_obmg = d_powf(T->cgg[2] * T->ogg2 * T->ogg1, T->obmg);
     T->pw_ccg_obmr = d_powf(T->ccg[2] * T->ocg2, T->obmr);
-    T->log_Dr_span = log(T->Dr[NBINS - 1] / T->Dr[0]);
-    T->log_Ds_span = log(T->Ds[NBINS - 1] / T->Ds[0]);
+    T->log_Dr_span = gd_log(T->Dr[NBINS - 1] / T->Dr[0]);
+    T->log_Ds_span = gd_log(T->Ds[NBINS - 1] / T->Ds[0]);
     for (int n = 0; n < TH_P10_N; ++n) T->p10[n] = powi10f(n - TH_P10_OFF);
 }
 // the decade index of the level code for n values: which = 0 the product's form (dec_index_f / dec_index_d with the table), 1 the
 // reference's loop alone -- so that a test can compare them value by value (icar_hip_thompson_dec_index)
 __global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__ rf, const double *__restrict__ rd, int n, int n2, int which, int *__restrict__ out)
 {
-    gf_lds_init(threadIdx.x, blockDim.x);
+    th_lds_init(threadIdx.x, blockDim.x);
     const DK K_ = d_consts();
 
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -747,7 +738,7 @@ __global__ void k_thompson_dec_index(const ThState *T, const float *__restrict__
 // (x, y) come from the host so that nothing is folded at compile time.
 __global__ void k_thompson_math_probe(int op, int n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
 {
-    gf_lds_init(threadIdx.x, blockDim.x);
+    th_lds_init(threadIdx.x, blockDim.x);
     const DK K_ = d_consts();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;

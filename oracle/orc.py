@@ -81,6 +81,14 @@ def libm_f(op, x, y=None):
     return out
 
 
+def libm_d(op, x, y=None):
+    """the host C library's double functions on arrays: op 0 log, 1 exp, 2 pow(x, y)"""
+    x = np.ascontiguousarray(x, np.float64); out = np.empty_like(x)
+    yy = x if y is None else np.ascontiguousarray(y, np.float64)
+    lib().orc_libm_d(_i(op), _i(x.size), x.ctypes.data_as(ctypes.c_void_p), yy.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 

@@ -14,9 +14,36 @@
  * the flang-compiled reference calls them (bit-identical to oracle/_ref).  Mode 1 = the same functions
  * evaluated in FP64 and rounded once, which is how the HIP kernel defines them. */
 extern int g_math_mode;
-static inline float M_powf(float x, float y) { return g_math_mode ? (float)pow((double)x, (double)y) : powf(x, y); }
-static inline float M_expf(float x) { return g_math_mode ? (float)exp((double)x) : expf(x); }
-static inline float M_log10f(float x) { return g_math_mode ? (float)log10((double)x) : log10f(x); }
+/* Optional trace of every transcendental call of the column physics (diagnostics for a device / oracle difference: which libm
+ * call does the device evaluate differently?).  orc_thompson_trace(1) starts a trace (run ONE column, one thread), the entries are
+ * (op, x, y, result) with op = the op codes of icar_hip_thompson_math_probe: 0 log, 1 exp, 2 pow (double); 3 powf, 4 expf,
+ * 6 log10f; 10 = log10 (double, no device probe). */
+#define TH_TRACE_MAX 65536
+static int g_tr_on = 0, g_tr_n = 0;
+static double g_tr[4 * TH_TRACE_MAX];
+void orc_thompson_trace(int on) { g_tr_on = on; if (on) g_tr_n = 0; }
+int orc_thompson_trace_read(double *out, int cap)
+{
+    const int n = g_tr_n < cap ? g_tr_n : cap;
+    memcpy(out, g_tr, sizeof(double) * 4 * (size_t)n);
+    return g_tr_n;
+}
+static inline double tr_rec(int op, double x, double y, double r)
+{
+    if (g_tr_on && g_tr_n < TH_TRACE_MAX) { double *e = g_tr + 4 * g_tr_n++; e[0] = op; e[1] = x; e[2] = y; e[3] = r; }
+    return r;
+}
+static inline float M_powf(float x, float y) { return (float)tr_rec(3, x, y, g_math_mode ? (float)pow((double)x, (double)y) : powf(x, y)); }
+static inline float M_expf(float x) { return (float)tr_rec(4, x, 0, g_math_mode ? (float)exp((double)x) : expf(x)); }
+static inline float M_log10f(float x) { return (float)tr_rec(6, x, 0, g_math_mode ? (float)log10((double)x) : log10f(x)); }
+static inline double T_pow(double x, double y) { return tr_rec(2, x, y, pow(x, y)); }
+static inline double T_log(double x) { return tr_rec(0, x, 0, log(x)); }
+static inline double T_exp(double x) { return tr_rec(1, x, 0, exp(x)); }
+static inline double T_log10(double x) { return tr_rec(10, x, 0, log10(x)); }
+#define pow(x, y) T_pow(x, y)
+#define log(x) T_log(x)
+#define exp(x) T_exp(x)
+#define log10(x) T_log10(x)
 #define IDX3(i,k,j) ((size_t)(i) + (size_t)nx*((size_t)(k) + (size_t)nz*(size_t)(j)))
 
 /* 10.**nn with an INTEGER exponent: flang calls __powisf2 (repeated squaring) */

@@ -146,6 +146,47 @@ def test_trajectory_exact_mode_bit_identical_over_ten_substeps(th_oracle, oracle
     d.close()
 
 
+def test_metric_grid_512x512x40_five_steps_exact_mode_bit_identical(th_oracle, oracle):
+    """BASELINE.json's metric configuration as bench.py builds it (512 x 512 x 40, hill 1000 m, 1 % noise, vapour x 1.4, MPDATA order 2
+    + FCT of the 9 scalars + Thompson), five steps of icar_hip_step_n (update_dt -> diagnostic_update -> Thompson strips + interior
+    -> MPDATA) with icar_hip_mpdata_exact(ctx, 1), against the same five steps of the CPU oracle's operators: all 9 x 10.5 M cells
+    and the accumulated precipitation bit for bit."""
+    from icar_amd.time_step import step_n
+    nx, ny, nz, nsteps = 512, 512, 40, 5
+    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, seed=1234, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.4)).astype(np.float32)
+    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON
+    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"]); opt.parameters.ideal = True
+    mp_var_request(opt)
+    d = single_image_domain(c)
+    check(lib().icar_hip_mpdata_exact(d.ctx, 1), "mpdata_exact")
+    mp_init(opt, d); adv_init(d, opt)
+    d.set("dzdx", np.zeros(c["u"].shape, np.float32)); d.set("dzdy", np.zeros(c["v"].shape, np.float32))
+    dt_dev = step_n(d, nsteps, opt, diagnostics=True)
+    f32 = np.float32
+    dt = min(float(f32(0.9) / f32(oracle.max_courant(c["u"], c["v"], c["w"], c["dz_levels"], float(c["dx"])))), 120.0)
+    assert dt_dev == dt
+    s = {n: c[n].copy() for n in ADV_ORDER}
+    acc = np.zeros((ny, nx), np.float64)
+    th_oracle.set_math_mode(0)
+    zero_x = np.zeros(c["u"].shape, np.float32); zero_y = np.zeros(c["v"].shape, np.float32)
+    for it in range(nsteps):
+        diag = oracle.diagnostic_update(c["pressure"], s["potential_temperature"], c["u"], c["v"], c["w"], zero_x, zero_y, c["jacobian"])
+        z = [np.zeros((ny, nx), np.float32) for _ in range(5)]
+        th_oracle.thompson(s["water_vapor"], s["cloud_water"], s["rain"], s["cloud_ice"], s["snow"], s["graupel"], s["ice_number"],
+                           s["rain_number"], s["potential_temperature"], diag["exner"], c["pressure"], c["dz_mass"], dt, *z,
+                           1, nx, 1, ny, 1, nz, 2, nx - 1, 2, ny - 1, 1, nz)
+        acc += z[0]
+        _advect_oracle(th_oracle, s, c, dt, ADV_ORDER)
+    for n in ADV_ORDER:
+        got = d.get(MEMBER[n])
+        assert bits_equal(got, s[n]), f"{n}: {nbitdiff(got, s[n])} of {got.size} cells differ after {nsteps} steps"
+        assert np.isfinite(got).all()
+    assert acc.max() > 0 and np.array_equal(d.get("accumulated_precipitation"), acc)
+    parity_record("trajectory", f"metric_grid/512x512x40/exact_mode_{nsteps}_steps", {n: {"bitdiff_cells": 0, "cells": int(s[n].size)} for n in ADV_ORDER})
+    d.close()
+
+
 def test_whole_step_loop_exact_mode_equals_cpu_chain(th_oracle, oracle):
     """icar_hip_step -- the library's own loop of time_step.f90:440-551: update_dt (CFL maximum on the device, prefetched beside the
     advection) -> diagnostic_update -> Thompson (strips + interior on two streams) -> halo self-exchange -> MPDATA -> apply_forcing
