@@ -28,21 +28,25 @@
 #endif
 #include "glibc_dbl64_tables.h"
 
-// Tables: GD_LDS_TABLES defined before the include -> the three look-up tables (7 KB) live in LDS (`gd_lds`; every kernel of that
+// Tables: GD_LDS_TABLES defined before the include -> the tables of exp and of pow's logarithm (5 KB) live in LDS (`gd_lds`; every kernel of that
 // translation unit that calls these functions runs gd_lds_init() and a barrier first); the 35 scalar coefficients stay in constant
 // global memory (scalar loads).  Otherwise the tables are read from constant global memory too.
 #ifdef GD_LDS_TABLES
-struct GdLds { uint64_t exp_tab[256]; double log_tab[256]; double powlog_tab[384]; };
+struct GdLds { uint64_t exp_tab[256]; double powlog_tab[384]; };      // (log's own table -- two call sites -- stays in global memory)
 __shared__ GdLds gd_lds;
 // every thread of the block calls this once at the top of the kernel; the CALLER's barrier must follow
 __device__ __forceinline__ void gd_lds_init(int tid, int nthreads)
 {
-    for (int t = tid; t < 256; t += nthreads) { gd_lds.exp_tab[t] = gd_data.exp_tab[t]; gd_lds.log_tab[t] = gd_data.log_tab[t]; }
-    for (int t = tid; t < 384; t += nthreads) gd_lds.powlog_tab[t] = gd_data.powlog_tab[t];
+    const double2 *se = (const double2 *)gd_data.exp_tab, *sp = (const double2 *)gd_data.powlog_tab;
+    double2 *de = (double2 *)gd_lds.exp_tab, *dp = (double2 *)gd_lds.powlog_tab;
+    for (int t = tid; t < 128; t += nthreads) de[t] = se[t];
+    for (int t = tid; t < 192; t += nthreads) dp[t] = sp[t];
 }
 #define GD_T gd_lds
+#define GD_TLOG gd_data
 #else
 #define GD_T gd_data
+#define GD_TLOG gd_data
 #endif
 
 GD_FN uint64_t gd_asuint64(double f) { uint64_t u; __builtin_memcpy(&u, &f, 8); return u; }
@@ -156,7 +160,7 @@ GD_FN double gd_log(double x)
     const int i = (int)((tmp >> 45) & 127);
     const int k = (int)((int64_t)tmp >> 52);
     const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
-    const double invc = GD_T.log_tab[2 * i], logc = GD_T.log_tab[2 * i + 1];
+    const double invc = GD_TLOG.log_tab[2 * i], logc = GD_TLOG.log_tab[2 * i + 1];
     const double z = gd_asdouble(iz);
     const double kd = (double)k;
     const double r = __builtin_fma(z, invc, -1.0);
