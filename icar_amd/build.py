@@ -49,6 +49,7 @@ def build(force=False, verbose=False):
                 for kern in NO_SCRATCH[s]:
                     blocks = [b for b in rep.split("Function Name: ")[1:] if kern in b.split("\n")[0] and "remark" in b]
                     if not blocks or any("ScratchSize [bytes/lane]: 0" not in b for b in blocks):
+                        os.remove(obj)                    # (a later build() must not take the object for up to date)
                         raise RuntimeError(f"{s}: {kern} must compile without scratch")
             else:
                 subprocess.check_call(cmd)

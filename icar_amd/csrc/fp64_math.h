@@ -1,4 +1,7 @@
-// icar_amd/csrc/fp64_math.h -- FP64 log / exp for REAL(4) transcendentals evaluated in double and rounded once.
+// icar_amd/csrc/fp64_math.h -- FP64 log / exp polynomials of rounds 1-3.  NOT on the product path any more: the REAL(4)
+// transcendentals are glibc's float functions (glibc_flt32.h, round 3) and the DOUBLE PRECISION ones glibc's double functions
+// (glibc_dbl64.h, round 4).  What is still used is `DK` / `d_consts()`, the by-reference constant block the level code's helper
+// signatures carry; the routines below are kept as the measured alternative the docs refer to (profiles/r04_steps.md).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -14,7 +14,7 @@
 // compiles this header for the CPU (every REAL(4) argument of expf / logf / log10f / atanf, 10^9 argument pairs of powf) and
 // tests/test_gpu_glibc_math.py runs it on the device.  Tables and coefficients are glibc's published constants (data).
 //
-// Cost per call (FP64 VALU instructions; the correctly rounded d_exp / d_log of fp64_math.h they replace: 20 / 38):
+// Cost per call (FP64 VALU instructions; the FP64 polynomial d_exp / d_log of rounds 1-2 they replaced: 20 / 38):
 // expf 8, logf 7, powf 17 (log2 part 9, shared by all powers of one base; exp2 part 8).
 #pragma once
 #include <stdint.h>
