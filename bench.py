@@ -459,7 +459,7 @@ def main():
             tj = json.load(open(tpath))
             want = {"nx": d.nx, "ny": d.ny, "nz": d.nz, "adv": args.adv, "nscalars": nscal, "kernels": ADVECT_KERNELS[args.adv],
                     "generation": KERNEL_GENERATION}
-            if tj.get("config") == want:
+            if tj.get("config") == want and not args.mpdata_exact:      # (the recorded passes are the fused kernel's)
                 traffic = tj.get("hbm_bytes_per_advect_call")
                 traffic_source = "profiles/advect_traffic.json (PMC passes of an earlier run of this configuration and kernel generation)"
         except Exception:
@@ -528,7 +528,8 @@ def main():
                        "ranks_seen": ranks_seen, "halo_check": halo_check,
                        "dt_s": dt, "mp_active_column_fraction": active},
             "later_window": later,
-            "roofline": {"bound": "hbm", "kernel": f"advect ({ADVECT_KERNELS[args.adv]})",
+            "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpx_velocities + k_mpx_limit_donor: icar_hip_mpdata_exact)" if (args.mpdata_exact and args.adv == "mpdata")
+                                                   else f"advect ({ADVECT_KERNELS[args.adv]})",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": alg_bytes, "avg_ms": adv_ms,
                          # mp_ms_per_step / setup_ms_per_step: over the `timer_window_steps` steps that FOLLOW the timed region (see above)
@@ -550,7 +551,7 @@ def main():
                              "ms_per_step": mp_ms_step,
                              "algorithmic_GBps": (mem_cells * (84 if args.mp == "thompson" else 56) / (mp_ms_step * 1e-3) / 1e9) if mp_ms_step > 0 else 0.0},
         }
-        if world == 1 and not args.no_traffic_probe and not args.no_cpu_baseline:        # (the full line only: profiling scripts pass --no-cpu-baseline)
+        if world == 1 and not args.no_traffic_probe and not args.no_cpu_baseline and not args.mpdata_exact:        # (the full line only: profiling scripts pass --no-cpu-baseline)
             # roofline.traffic measured NOW on this box (counters cannot be read inside this process: two child runs under rocprofv3)
             t = probe_traffic(args)
             if t is not None:
