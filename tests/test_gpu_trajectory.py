@@ -152,7 +152,8 @@ def test_metric_grid_512x512x40_five_steps_exact_mode_bit_identical(th_oracle, o
     -> MPDATA) with icar_hip_mpdata_exact(ctx, 1), against the same five steps of the CPU oracle's operators: all 9 x 10.5 M cells
     and the accumulated precipitation bit for bit."""
     from icar_amd.time_step import step_n
-    nx, ny, nz, nsteps = 512, 512, 40, 5
+    import os
+    nx, ny, nz, nsteps = 512, 512, 40, int(os.environ.get("ICAR_METRIC_STEPS", "5"))      # (run once per round with 40: profiles/r04_parity.json)
     c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, seed=1234, n_hydro=1)
     c["water_vapor"] = (c["water_vapor"] * np.float32(1.4)).astype(np.float32)
     opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON
