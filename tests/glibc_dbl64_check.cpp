@@ -77,6 +77,11 @@ int main(int argc, char **argv)
     run1("log_bits", n, [](uint64_t &s) { return gd_asdouble(splitmix(s)); }, l, L);
     run2("pow_physics", n, [](uint64_t &s, double &x, double &y) { x = std::pow(10.0, -40.0 + 80.0 * unif(s)); y = -12.0 + 24.0 * unif(s); });
     run2("pow_quarters", n, [](uint64_t &s, double &x, double &y) { x = std::pow(10.0, -20.0 + 40.0 * unif(s)); y = 0.25 * (double)((int)(splitmix(s) % 97) - 48); });
+    run2("pow_one", n, [](uint64_t &s, double &x, double &y) { x = gd_asdouble(splitmix(s)); y = 1.0; });       // and pow(x, 1) IS x:
+    { uint64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad)
+      for (int64_t t = 0; t < (int64_t)n; ++t) { uint64_t s = 0x51ull + 0x9e3779b97f4a7c15ull * (uint64_t)t; const double x = gd_asdouble(splitmix(s)); if (!same(pow(x, 1.0), x)) ++bad; }
+      printf("libm_pow_one_is_x %llu %llu\n", (unsigned long long)n, (unsigned long long)bad); }
     run2("pow_bits", n, [](uint64_t &s, double &x, double &y) { x = gd_asdouble(splitmix(s)); y = gd_asdouble(splitmix(s)); });
     run2("pow_posbits", n, [](uint64_t &s, double &x, double &y) { x = gd_asdouble(splitmix(s) >> 1); y = (unif(s) - 0.5) * std::ldexp(1.0, (int)(splitmix(s) % 24) - 10); });
     run2("pow_extreme", n, [](uint64_t &s, double &x, double &y) { x = std::ldexp(1.0 + unif(s), (int)(splitmix(s) % 2098) - 1074); y = (unif(s) - 0.5) * 2200.0 / std::fmax(1.0, std::fabs(std::log2(x))); });

@@ -1,5 +1,5 @@
 """icar_amd/csrc/glibc_dbl64.h (the device's DOUBLE PRECISION exp / log / pow = glibc 2.35's FMA builds restated) compiled for the
-CPU and compared with the host C library value by value: tests/glibc_dbl64_check.cpp.  In the suite: 2e7 arguments per class (11
+CPU and compared with the host C library value by value: tests/glibc_dbl64_check.cpp.  In the suite: 2e7 arguments per class (13
 classes: exp over its range / near 0 / all bit patterns, log over all binades / near 1 / all bit patterns, pow as the microphysics
 uses it, quarter-integer exponents, all bit patterns, positive bases, results near over- and underflow) and a grid of special
 values; `./check 1000000000` runs 1e9 per class (recorded in profiles/r04_parity.json: 0 mismatches)."""
@@ -24,4 +24,4 @@ def test_restated_double_functions_equal_libm(tmp_path):
         name, n, bad = line.split()[:3]
         seen[name] = (int(n), int(bad))
         assert int(bad) == 0, out
-    assert len(seen) == 12 and "pow_physics" in seen and "special" in seen, out
+    assert len(seen) == 14 and "libm_pow_one_is_x" in seen and "pow_physics" in seen and "special" in seen, out
