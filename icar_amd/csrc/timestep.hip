@@ -14,6 +14,7 @@
 //   forcing of the advected scalars (boundary ring) <----- join
 //   enforce_limits (last two sub-steps)
 #include "ctx.h"
+#include <chrono>
 #include "comm.h"
 #include <cmath>
 #include <cstring>
@@ -474,6 +475,50 @@ int icar_hip_step_n(icar_hip_ctx *c, int nsteps, double *dt_last)
         c->step.model_time += dt;
     }
     if (dt_last) *dt_last = dt;
+    return 0;
+}
+
+// Measurement only ("no captured step exists"): the same 2 x pairs sub-steps with a FIXED dt issued eagerly and as
+// replays of ONE hipGraph of two consecutive sub-steps (two: the advected scalars ping-pong between two buffers, so the kernel
+// arguments repeat with period 2), both streams and their fork / join events captured.  Wall-clock of each in ms; the device state
+// afterwards is that of 2 + 4 x pairs sub-steps (tests/test_gpu_step_rows.py compares it with the eager sequence bit for bit).  The CFL
+// prefetch is off inside (its host-side event wait has no place in a graph); the product loops stay eager -- profiles/r04_steps.md has
+// the numbers this produced.
+int icar_hip_substep_graph_probe(icar_hip_ctx *c, double dt, int pairs, double *ms_eager, double *ms_graph)
+{
+    if (!c || pairs < 1 || !ms_eager || !ms_graph) { icar_set_error("substep_graph_probe: ctx, pairs >= 1, two outputs"); return 1; }
+    if (!cfg_ok(c, "substep_graph_probe")) return 1;
+    if (c->on_aux || c->timing) { icar_set_error("substep_graph_probe: not between aux_begin / aux_end, timers off"); return 1; }
+    if (icar_comm_has_peers(c)) { icar_set_error("substep_graph_probe: one image only (the transports are not captured)"); return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    const int keep_prefetch = c->step.cfg.prefetch_dt;
+    c->step.cfg.prefetch_dt = 0;
+    struct Restore { icar_hip_ctx *c; int v; ~Restore() { c->step.cfg.prefetch_dt = v; } } restore{c, keep_prefetch};
+    auto run2 = [&](int n) { for (int i = 0; i < n; ++i) { if (icar_substep(c, dt, false)) return 1; c->step.model_time += dt; } return 0; };
+    auto sync = [&]() { if (c->aux) (void)hipStreamSynchronize(c->aux); return hipStreamSynchronize(c->stream); };
+    if (run2(2)) return 1;                                                        // every lazy allocation, the steady mp_dt
+    HIPCHK(sync());
+    auto t0 = std::chrono::steady_clock::now();
+    if (run2(2 * pairs)) return 1;
+    HIPCHK(sync());
+    auto t1 = std::chrono::steady_clock::now();
+    *ms_eager = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    const int rc = run2(2);
+    const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
+    c->step.model_time -= 2 * dt;                                                 // (captured, not executed)
+    if (rc || ec != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) icar_set_error("substep_graph_probe: capture failed"); return 1; }
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); icar_set_error("substep_graph_probe: hipGraphInstantiate failed"); return 1; }
+    if (hipGraphLaunch(exec, c->stream) != hipSuccess) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); icar_set_error("substep_graph_probe: hipGraphLaunch failed"); return 1; }
+    HIPCHK(sync());                                                               // first launch (upload) untimed ...
+    t0 = std::chrono::steady_clock::now();
+    for (int i = 1; i < pairs; ++i) if (hipGraphLaunch(exec, c->stream) != hipSuccess) { icar_set_error("substep_graph_probe: hipGraphLaunch failed"); return 1; }
+    HIPCHK(sync());
+    t1 = std::chrono::steady_clock::now();
+    *ms_graph = (pairs > 1) ? std::chrono::duration<double, std::milli>(t1 - t0).count() * pairs / (pairs - 1) : 0.0;      // ... scaled to `pairs` launches
+    c->step.model_time += 2.0 * pairs * dt;
+    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
     return 0;
 }
 

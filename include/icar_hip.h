@@ -458,6 +458,11 @@ int icar_hip_step(icar_hip_ctx *ctx, double end_time_seconds, int *nsteps);
  * enforce_limits: what a benchmark times as "K passes of the hot path".  dt_last (may be NULL) receives the last dt. */
 int icar_hip_step_n(icar_hip_ctx *ctx, int nsteps, double *dt_last);
 
+/* Measurement only: 2 x pairs sub-steps with a fixed dt issued eagerly, then the same number as replays of one hipGraph of two
+ * captured sub-steps (one image; the CFL prefetch off inside).  Wall-clock of each in ms.  The loops of this library stay eager:
+ * profiles/r04_steps.md has what this measured.  No counterpart in the reference. */
+int icar_hip_substep_graph_probe(icar_hip_ctx *ctx, double dt_seconds, int pairs, double *ms_eager, double *ms_graph);
+
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Average duration (ms) of the launches of a named kernel group since the last reset, measured
  * with HIP events on the context's stream (bench.py roofline block). group: "advect", "mp". */

@@ -8,7 +8,7 @@ from icar_amd import ideal
 from icar_amd.capi import lib, check
 from icar_amd.options import options_t
 from icar_amd.time_step import compute_dt
-from util import single_image_domain, bits_equal
+from util import single_image_domain, bits_equal, nbitdiff
 
 pytestmark = pytest.mark.gpu
 
@@ -370,4 +370,57 @@ def test_substep_equals_the_plain_sequence(mpname):
         for n in names:
             x, y = a.get(n), b.get(n)
             assert np.array_equal(x, y), f"{mpname} step {it} {n}: {(x != y).sum()} cells differ"
+    a.close(); b.close()
+
+
+def test_graph_replay_of_the_substep_equals_the_eager_launches():
+    """icar_hip_substep_graph_probe: two consecutive sub-steps (diagnostic_update -> Thompson strips + interior -> periodic halo ->
+    MPDATA -> forcing, both streams and their fork / join events) captured into ONE hipGraph and replayed; the state afterwards
+    must be the state of the same number of sub-steps issued eagerly, bit for bit -- i.e. the capture holds every launch of a
+    sub-step and its dependencies.  (Measurement entry; the loops of the library stay eager)"""
+    import ctypes
+    from icar_amd.capi import lib, check
+    from icar_amd.time_step import update_dt
+    from icar_amd.microphysics import mp_init, mp_var_request
+    from icar_amd.advection import adv_init, adv_var_request
+    from icar_amd.constants import kADV_MPDATA, kMP_THOMPSON, ADVECTION_ORDER
+    from icar_amd.grid import grid_t
+    from icar_amd.domain import domain_t
+    from icar_amd.halo import HaloComm
+    nx, ny, nz, pairs = 70, 44, 16, 3
+    c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.02, n_hydro=1)
+    c["water_vapor"] = (c["water_vapor"] * np.float32(1.6)).astype(np.float32)
+    rng = np.random.default_rng(3)
+    c["dzdx"] = (0.05 * rng.standard_normal(c["u"].shape)).astype(np.float32)
+    c["dzdy"] = (0.05 * rng.standard_normal(c["v"].shape)).astype(np.float32)
+    dq = {k: (s * rng.standard_normal(c[k].shape)).astype(np.float32) for k, s in {"water_vapor": 1e-8, "potential_temperature": 1e-4, "pressure": 1e-3}.items()}
+    forced = [("water_vapor", True), ("potential_temperature", True), ("pressure", False)]
+    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON
+    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"]); opt.parameters.ideal = True
+    mp_var_request(opt); adv_var_request(opt)
+
+    def fresh():
+        g = grid_t().set_grid_dimensions(nx, ny, nz, 1, 1)
+        d = domain_t(g, device=0, dx=float(c["dx"]), image=1, comm=HaloComm(g, 1, loopback=True))
+        d.load_case(c)
+        d.exchange_vars = [n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0]
+        mp_init(opt, d); adv_init(d, opt)
+        for k, a in dq.items():
+            d.set_dqdt(k, a)
+        d.configure(opt, forced=forced, diagnostics=True, prefetch_dt=False)
+        return d
+    a, b = fresh(), fresh()
+    dt = update_dt(a, opt)
+    a.configure(opt, forced=forced, diagnostics=True, prefetch_dt=False)
+    me, mg = ctypes.c_double(), ctypes.c_double()
+    check(lib().icar_hip_substep_graph_probe(a.ctx, dt, pairs, ctypes.byref(me), ctypes.byref(mg)), "substep_graph_probe")
+    for _ in range(2 + 4 * pairs):
+        check(lib().icar_hip_substep(b.ctx, dt, 0), "substep"); b.model_time_seconds += dt
+    assert a.model_time_seconds == pytest.approx(b.model_time_seconds, rel=1e-12) and me.value > 0 and mg.value > 0
+    for n in ("water_vapor", "cloud_water_mass", "rain_mass", "snow_mass", "potential_temperature", "cloud_ice_mass", "graupel_mass", "cloud_ice_number",
+              "rain_number", "pressure", "w_real", "density", "exner"):
+        x, y = a.get(n), b.get(n)
+        assert bits_equal(x, y), f"{n}: {nbitdiff(x, y)} cells differ between the graph replays and the eager sub-steps"
+    assert float(a.get("cloud_water_mass").max()) > 1e-6
+    assert np.array_equal(a.get("accumulated_precipitation"), b.get("accumulated_precipitation"))
     a.close(); b.close()
