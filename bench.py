@@ -379,6 +379,8 @@ def main():
     lib = capi.lib()
     if args.mpdata_exact:
         capi.check(lib.icar_hip_mpdata_exact(d.ctx, 1), "icar_hip_mpdata_exact")
+    if os.environ.get("ICAR_BENCH_GRAPH") == "1":       # profiling A/B (profiles/micro/graph_ab.sh): sub-steps as hipGraph replays with dt in device memory
+        capi.check(lib.icar_hip_graph_mode(d.ctx, 1), "icar_hip_graph_mode")
     if args.thompson_layout:
         capi.check(lib.icar_hip_thompson_layout(d.ctx, args.thompson_layout), "icar_hip_thompson_layout")
     kind = int(lib.icar_hip_comm_kind(d.ctx))
@@ -435,6 +437,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    nrep = ctypes.c_longlong(0)
+    lib.icar_hip_graph_replays(d.ctx, ctypes.byref(nrep))
+    graph_replays = int(nrep.value)           # sub-steps this rank launched as hipGraph replays so far (warm-up + timed + diagnostic window)
     own_cells = (g.ite - g.its + 1) * (g.jte - g.jts + 1) * args.nz
     cells_t = torch.tensor([float(own_cells)], dtype=torch.float64, device=red_device)
     if world > 1:
@@ -525,7 +530,7 @@ def main():
                        "halo": ("one ncclSend/ncclRecv group per step issued by the library (icar_hip_halo_send)" if kind == capi.COMM_RCCL else
                                 "one message per neighbour through pinned host memory (icar_hip_comm_init_host)") + ", strips+pack on the second stream beside the interior mp" if world > 1
                                else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips+pack on the second stream beside the interior mp",
-                       "ranks_seen": ranks_seen, "halo_check": halo_check,
+                       "ranks_seen": ranks_seen, "halo_check": halo_check, "graph_replays": graph_replays,
                        "dt_s": dt, "mp_active_column_fraction": active},
             "later_window": later,
             "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpx_velocities + k_mpx_limit_donor: icar_hip_mpdata_exact)" if (args.mpdata_exact and args.adv == "mpdata")

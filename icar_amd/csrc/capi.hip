@@ -317,8 +317,10 @@ int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_lev
     if (!c->h_cfl_pre) { HIPCHK(hipHostMalloc((void **)&c->h_cfl_pre, sizeof(float), hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&c->cfl_ev, hipEventDisableTiming)); }
     if (icar_max_courant_run(c, dx, dz_levels, nullptr, c->d_red + 8)) return 1;             // on the current stream, nothing waits
     if (allreduce && icar_comm_max_device(c, c->d_red + 8) != 0) return 1;
-    HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
+    if (!c->dt_dev) {               // (inside a captured sub-step the device reads the maximum itself; the host's copy follows the last replay)
+        HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
+    }
     c->cfl_pre.reduced = allreduce;
     c->cfl_pre.valid = true; c->cfl_pre.ver = c->wind_version; c->cfl_pre.dx = dx; c->cfl_pre.dzl.assign(dz_levels, dz_levels + c->d.nz);
     return 0;
@@ -463,6 +465,11 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     icar_linwinds_free(c);
     icar_comm_free(c);
     if (c->step.h_val) hipHostFree(c->step.h_val);
+    icar_graph_invalidate(c);
+    if (c->step.dtblk) hipFree(c->step.dtblk);
+    if (c->step.dt_ring) hipFree(c->step.dt_ring);
+    if (c->step.h_dtblk) hipHostFree(c->step.h_dtblk);
+    if (c->step.h_dt_ring) hipHostFree(c->step.h_dt_ring);
     if (c->on_aux) c->stream = c->main_saved;
     if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -566,6 +573,21 @@ int icar_hip_mpdata_exact(icar_hip_ctx *c, int on)
 {
     if (!c || (on != 0 && on != 1)) { icar_set_error("mpdata_exact: ctx and on = 0 / 1"); return 1; }
     c->mpdata_exact = on;
+    return 0;
+}
+
+int icar_hip_graph_mode(icar_hip_ctx *c, int on)
+{
+    if (!c || (on != 0 && on != 1)) { icar_set_error("graph_mode: ctx and on = 0 / 1"); return 1; }
+    c->graph_mode = on;
+    if (!on) icar_graph_invalidate(c);
+    return 0;
+}
+
+int icar_hip_graph_replays(icar_hip_ctx *c, long long *n)
+{
+    if (!c || !n) { icar_set_error("graph_replays: null argument"); return 1; }
+    *n = c->graph_launches;
     return 0;
 }
 

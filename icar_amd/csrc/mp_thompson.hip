@@ -222,8 +222,9 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
                 double *__restrict__ rain_acc, double *__restrict__ snow_acc, double *__restrict__ graupel_acc,
-                float dt, ThTiles tl, int k0, int nk, int cpb)
+                float dt, ThTiles tl, int k0, int nk, int cpb, const IcarDtBlock *__restrict__ blk)
 {
+    if (blk) dt = blk->mp_dt;                       // graph replay: model_time - last_model_time lives in device memory (timestep.hip)
     extern __shared__ double lds_pack[];
     th_lds_init(threadIdx.x, blockDim.x);
     // several (its..ite, jts..jte) tiles in one launch (process_halo's four strips): block -> tile by prefix offsets
@@ -841,6 +842,7 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
     // level-per-thread kernel: two waves per SIMD do not hide its instruction-fetch and memory latencies
     // (profiles/r04_thompson_layout.md).
     if (nt_ == 1 && nk >= 2 && (c->th_layout == 2 || c->th_layout == 3)) {
+        if (c->dt_dev) c->dt_bad = true;                 // (these layouts take dt by value only: no graph replay)
         const int ni_ = T4[0][1] - T4[0][0] + 1, nj_ = T4[0][3] - T4[0][2] + 1;
         const long ncol = (long)ni_ * nj_;
         {
@@ -881,14 +883,15 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
         }
         if (nt <= 512)
             hipLaunchKernelGGL(k_thompson_pack<512>, dim3(tl.off[nt_]), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
-                               qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb);
+                               qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb, c->dt_dev);
         else
             hipLaunchKernelGGL(k_thompson_pack<1024>, dim3(tl.off[nt_]), dim3(nt), BlockComm::lds_bytes(nt, cpb), c->stream, c->d, T,
-                               qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb);
+                               qv, qc, qr, qi, qs, qg, ni, nr, th, pii, p, dz, pa, sa, ga, dt, tl, kts - c->kms, nk, cpb, c->dt_dev);
         HIPCHK(hipGetLastError());
         return 0;
     }
     if (nk > 64) { icar_set_error("thompson: this many levels are not supported by this build"); return 1; }
+    if (c->dt_dev) c->dt_bad = true;
     for (int t = 0; t < nt_; ++t) {                      // one column per wave, level = lane
         const int its = T4[t][0], i_end = T4[t][1], jts = T4[t][2], j_end = T4[t][3];
         dim3 gl((i_end - its + 1 + 3) / 4, j_end - jts + 1), bl(256);

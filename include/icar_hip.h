@@ -458,6 +458,19 @@ int icar_hip_step(icar_hip_ctx *ctx, double end_time_seconds, int *nsteps);
  * enforce_limits: what a benchmark times as "K passes of the hot path".  dt_last (may be NULL) receives the last dt. */
 int icar_hip_step_n(icar_hip_ctx *ctx, int nsteps, double *dt_last);
 
+/* on = 1: icar_hip_step_n launches its sub-steps, in pairs, as replays of ONE captured hipGraph (two sub-steps: the advected
+ * scalars' ping-pong buffers are then back where they were) where it can: one image (no neighbouring images), group timers off,
+ * cfl_strictness 3 or 4 with prefetch_dt, mp_update_interval 0, halo_size 1, Thompson or no microphysics.  dt then lives in
+ * device memory -- a one-thread kernel at the head of each captured sub-step turns the prefetched CFL maximum into dt with
+ * compute_dt's REAL(4) operations and update_dt's 120 s cap (time_step.f90:313, :417) and keeps the clock the microphysics' own
+ * time step comes from (mp_driver.f90:708) -- so nothing of the host sits between two sub-steps; the model clock and dt_last come
+ * back after the launches.  Same bits as the eager loop, forced winds included (tests/test_gpu_step_rows.py).  Default: off --
+ * measured equal to the eager loop within noise on MI355X (profiles/r04_steps.md), because that loop already keeps the host off
+ * the critical path. */
+int icar_hip_graph_mode(icar_hip_ctx *ctx, int on);
+/* how many sub-steps this context has launched as graph replays so far (bench.py reports it; tests assert it) */
+int icar_hip_graph_replays(icar_hip_ctx *ctx, long long *n);
+
 /* Measurement only: 2 x pairs sub-steps with a fixed dt issued eagerly, then the same number as replays of one hipGraph of two
  * captured sub-steps (one image; the CFL prefetch off inside).  Wall-clock of each in ms.  The loops of this library stay eager:
  * profiles/r04_steps.md has what this measured.  No counterpart in the reference. */
