@@ -564,7 +564,7 @@ static int graph_steps(icar_hip_ctx *c, int count, double nominal_dt, double *dt
                         HIPCHK(hipMemcpyAsync(st.h_dtblk, st.dtblk, sizeof(IcarDtBlock), hipMemcpyDeviceToHost, c->stream));
                         HIPCHK(hipMemcpyAsync(st.h_dt_ring, st.dt_ring, sizeof(double) * i, hipMemcpyDeviceToHost, c->stream));
                         HIPCHK(hipStreamSynchronize(c->stream));
-                        st.model_time = st.h_dtblk->time; st.mp_last_model_time = st.h_dtblk->mp_last; *dt_last = st.h_dt_ring[i - 1];
+                        st.model_time = st.h_dtblk->time; if (g.microphysics != 0) st.mp_last_model_time = st.h_dtblk->mp_last; *dt_last = st.h_dt_ring[i - 1];
                         c->winds_valid = false;
                         *done += i;
                     }
@@ -582,7 +582,7 @@ static int graph_steps(icar_hip_ctx *c, int count, double nominal_dt, double *dt
         HIPCHK(hipMemcpyAsync(st.h_dt_ring, st.dt_ring, sizeof(double) * chunk, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->aux) HIPCHK(hipStreamSynchronize(c->aux));
-        st.model_time = st.h_dtblk->time; st.mp_last_model_time = st.h_dtblk->mp_last;
+        st.model_time = st.h_dtblk->time; if (g.microphysics != 0) st.mp_last_model_time = st.h_dtblk->mp_last;
         *dt_last = st.h_dt_ring[chunk - 1];
         c->winds_valid = false;                                                   // (the host's record of the Courant winds' dt is the nominal one)
         if (st.h_dtblk->err) { icar_set_error("ERROR time step too small"); return 1; }
