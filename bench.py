@@ -531,6 +531,10 @@ def main():
                                 "one message per neighbour through pinned host memory (icar_hip_comm_init_host)") + ", strips+pack on the second stream beside the interior mp" if world > 1
                                else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips+pack on the second stream beside the interior mp",
                        "ranks_seen": ranks_seen, "halo_check": halo_check, "graph_replays": graph_replays,
+                       # what the timed path computes: the microphysics, diagnostics, forcing and halos bit-identical to the CPU reference;
+                       # MPDATA either the fused kernel (every cell within 1e-5 of the local field scale per step, measured <= 3e-6) or,
+                       # with --mpdata-exact, the reference's operation order (bit-identical; tests/test_gpu_trajectory.py)
+                       "mpdata_arithmetic": ("reference operation order (bit-identical)" if args.mpdata_exact else "fused kernel (<= 1e-5 of the local scale per step)") if args.adv == "mpdata" else "n/a",
                        "dt_s": dt, "mp_active_column_fraction": active},
             "later_window": later,
             "roofline": {"bound": "hbm", "kernel": "advect (k_upwind_pass + k_mpx_velocities + k_mpx_limit_donor: icar_hip_mpdata_exact)" if (args.mpdata_exact and args.adv == "mpdata")
