@@ -651,11 +651,20 @@ int icar_hip_substep_graph_probe(icar_hip_ctx *c, double dt, int pairs, double *
     auto t1 = std::chrono::steady_clock::now();
     *ms_eager = std::chrono::duration<double, std::milli>(t1 - t0).count();
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    void *keep_field[ICAR_N_FIELDS]; float *keep_alt[ICAR_N_ADVECTABLE];
+    memcpy(keep_field, c->field, sizeof keep_field); memcpy(keep_alt, c->alt, sizeof keep_alt);
+    const double keep_time = c->step.model_time, keep_last = c->step.mp_last_model_time;
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
     const int rc = run2(2);
     const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
-    c->step.model_time -= 2 * dt;                                                 // (captured, not executed)
-    if (rc || ec != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) icar_set_error("substep_graph_probe: capture failed"); return 1; }
+    c->step.model_time = keep_time;                                               // (captured, not executed)
+    if (rc || ec != hipSuccess || !graph) {
+        // nothing of the two sub-steps ran: the host's view of the buffers and of the microphysics' clock goes back
+        memcpy(c->field, keep_field, sizeof keep_field); memcpy(c->alt, keep_alt, sizeof keep_alt); c->step.mp_last_model_time = keep_last;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!rc) icar_set_error("substep_graph_probe: capture failed");
+        return 1;
+    }
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); icar_set_error("substep_graph_probe: hipGraphInstantiate failed"); return 1; }
     if (hipGraphLaunch(exec, c->stream) != hipSuccess) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); icar_set_error("substep_graph_probe: hipGraphLaunch failed"); return 1; }
     HIPCHK(sync());                                                               // first launch (upload) untimed ...
