@@ -674,6 +674,7 @@ int icar_hip_substep_graph_probe(icar_hip_ctx *c, double dt, int pairs, double *
     t1 = std::chrono::steady_clock::now();
     *ms_graph = (pairs > 1) ? std::chrono::duration<double, std::milli>(t1 - t0).count() * pairs / (pairs - 1) : 0.0;      // ... scaled to `pairs` launches
     c->step.model_time += 2.0 * pairs * dt;
+    if (c->step.cfg.microphysics != 0) c->step.mp_last_model_time = c->step.model_time - dt;   // the last replayed sub-step's start
     (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
     return 0;
 }
