@@ -217,7 +217,14 @@ struct ThTiles { int n, i0[4], i1[4], j0[4], j1[4], tall[4], ib0[4], nbx[4], off
 // register budget of 3 waves per SIMD (168 VGPRs, no spills); at 128 VGPRs / 4 waves the kernel ran exactly as fast but spilled
 // 62 VGPRs -- 4 GB of scratch traffic per launch against 0.9 GB of algorithmic bytes.  1024-thread blocks need the 128.
 template <int MAXT>
-__global__ void __launch_bounds__(MAXT, MAXT > 512 ? 4 : 3)
+// Waves per SIMD of the 256-thread launch: until the DOUBLE PRECISION functions became glibc's (table look-ups from LDS: more
+// latency to hide, and no scalar registers held for polynomial coefficients any more) three waves at 168 VGPRs beat four at 128
+// (1.93 vs 1.98 ms); since then four win -- 1.77 against 1.86 ms alone, 3.10 against 3.15 ms per step at 512 x 512 x 40 (53 VGPRs
+// in scratch, no SGPR spills), equal on the small tiles (profiles/r04_steps.md).
+#ifndef TH_PACK_WAVES
+#define TH_PACK_WAVES 4
+#endif
+__global__ void __launch_bounds__(MAXT, MAXT > 512 ? 4 : TH_PACK_WAVES)
 k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, float *__restrict__ qc, float *__restrict__ qr,
                 float *__restrict__ qi, float *__restrict__ qs, float *__restrict__ qg, float *__restrict__ ni, float *__restrict__ nr,
                 float *__restrict__ th, const float *__restrict__ pii, const float *__restrict__ p, const float *__restrict__ dz,
