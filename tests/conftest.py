@@ -44,6 +44,13 @@ def host_libm_matches_device_math():
             bad = {l.split()[0]: int(l.split()[2]) for l in out.splitlines() if len(l.split()) >= 3}
             if any(bad.values()) or len(bad) < 5:
                 ok, why = False, f"the host libm differs from the glibc 2.35 FMA builds icar_amd/csrc/glibc_flt32.h restates: {bad}"
+            else:       # ... and the DOUBLE PRECISION exp / log / pow of the Thompson level code (glibc_dbl64.h), 2e5 arguments per class
+                exe2 = exe + "_d"
+                subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", os.path.join(ROOT, "tests", "glibc_dbl64_check.cpp"), "-o", exe2])
+                out = subprocess.check_output([exe2, "200000"], text=True, timeout=300)
+                bad = {l.split()[0]: int(l.split()[2]) for l in out.splitlines() if len(l.split()) >= 3 and not l.startswith(" ")}
+                if any(bad.values()) or len(bad) < 12:
+                    ok, why = False, f"the host libm differs from the glibc 2.35 FMA builds icar_amd/csrc/glibc_dbl64.h restates: {bad}"
     except Exception as e:  # no compiler, no libm ...: cannot tell -> do not hide the tests
         ok, why = True, f"(libm probe unavailable: {e})"
     _LIBM.update(ok=ok, why=why)
