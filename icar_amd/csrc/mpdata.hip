@@ -116,12 +116,36 @@ k_mpdata_coef(Dims d, const float *__restrict__ U, const float *__restrict__ V, 
         const float Wc = Wz[c], aW = fabsf(Wc), c0 = 0.0625f * Wc * rG;
         C[MPC_AW * n3 + c] = 0.5f * aW * (1.0f - 2.0f * aW * rG) * dzc; C[MPC_CWU * n3 + c] = xin ? c0 * evu * dzc : 0.0f; C[MPC_CWV * n3 + c] = c0 * evv * dzc;
     } else { C[MPC_AW * n3 + c] = 0.f; C[MPC_CWU * n3 + c] = 0.f; C[MPC_CWV * n3 + c] = 0.f; }
-    C[MPC_RDH * n3 + c] = frcp(g); C[MPC_RDV * n3 + c] = frcp(dzc * g);
+    // ring cells keep their value (adv_mpdata.f90:63-65): with a zero here the donor-cell pass and the final update of
+    // k_mpdata_fused return q there without a test
+    const bool ring = (i == 0) || (i == nx - 1) || (j == 0) || (j == ny - 1);
+    C[MPC_RDH * n3 + c] = ring ? 0.0f : frcp(g); C[MPC_RDV * n3 + c] = ring ? 0.0f : frcp(dzc * g);
 }
 
+// mode of one step of the march: generic (any plane, rolls by copying) or one half of a steady pair (its exchange-buffer parity)
+template <bool ST, int PAR> struct MpMode { static constexpr bool steady = ST; static constexpr int par = PAR; };
+
 // KB levels per thread (at most MP_NW waves per block), FCT: limiter on (advect_density lives in the coefficients),
-// PASS1: first corrective iteration (donor-cell pass inside); false: iord >= 3, where q2 == q (adv_mpdata.f90:393-402)
-template <int KB, bool FCT, bool PASS1>
+// PASS1: first corrective iteration (donor-cell pass inside); false: iord >= 3, where q2 == q (adv_mpdata.f90:393-402),
+// EXACT: the block's waves hold exactly the column (nz == waves x KB, one level range): the top of the column is slot KB of the
+// last wave, known at compile time, and every slot is stored -- no per-slot level tests at all.
+//
+// Round 5: the step is written for the ISSUE rate of a wave, not for the VALU pipe.  At two waves per SIMD one wave issues an
+// instruction only every 6.5-8 clocks whatever its kind (profiles/micro/issuebench.hip: s_add_i32 costs what v_add_f32 costs, a
+// not-taken branch pair 17 clocks, s_nop 7), and the round-4 steady step was 1103 VALU + 556 SALU + 150 other instructions in
+// ~100 basic blocks.  What changed:
+//   * boundary forms come out of the DATA: 1/(jaco rho) and 1/(jaco rho dz) are zero on the ring cells (k_mpdata_coef), so the
+//     donor-cell pass and the final update return q there without a select; lanes left / right of the domain are clamped copies
+//     of the ring column, so the limiter's first / last-cell extrema are the general three-cell form; the ring's zero in / out
+//     flow is a per-lane factor folded into the fma that adds the epsilon; the ground is a wave-uniform factor on two values;
+//     neighbour waves that do not exist are the wave itself (address selection, once).  The steady step has no branch left but
+//     the four spin waits and one store mask.
+//   * buffer offsets: one VGPR per level slot (loop-invariant) + one scalar per (array, plane): 17 s_add per step instead of 98.
+//   * the window does not roll: the steady loop runs PAIRS of steps with the two register sets of each rolling quantity
+//     swapped (q: planes N / NN; q2, extrema, stencils: planes P / N), and the next plane of the scalar is loaded straight into
+//     the set that has just been used up.  The donor-cell flux through a y face is carried to the next step (it was computed
+//     twice), which also makes the q window two planes deep and drops a plane of V loads.
+template <int KB, bool FCT, bool PASS1, bool EXACT>
 // 248 VGPRs, not the 256 two waves per SIMD could have (the attribute counts half of gfx90a+'s unified file: 124 -> 248).  The
 // 248 blocks of a launch hold their CUs for the whole kernel, so whatever the host issues on the second stream beside the
 // advection (whole-field forcing, the CFL reduction of the next update_dt) can only run in what these waves leave: with 2 x 248
@@ -141,38 +165,16 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     // first half of a step need that room to overlap: those 9 KB + 2 values per thread are parked in LDS in between
     // (thread-private float4 slots: no synchronisation, conflict-free b128 accesses).
     // The two z exchanges of a step are synchronised between NEIGHBOURING waves only: a wave needs the edge levels of the wave
-    // below and the wave above it, nothing else.  A wave posts its edges (data, then -- lgkmcnt(0) in between -- a step counter in
-    // s_flag), does the work that needs no neighbour, and spins on the two neighbouring counters.  With __syncthreads every step
-    // ran at the pace of the slowest of the block's 8 waves, twice; now a late wave delays its two neighbours only, and they
-    // catch up (1.30 -> 1.22 ms per advect() at 512 x 512 x 40, 9 scalars).  The double buffering by step parity stays sufficient: wave w overwrites a buffer at step
-    // t + 2 only after it has seen the counters of w-1 / w+1 at t + 1, which they post after their reads of step t.
-    __shared__ int s_flag[2][MP_NW];
-    int seqA = 0, seqB = 0;
-#define MP_POST(e, seq)                                                                                                   \
-    {                                                                                                                      \
-        ++seq;                                                                                                             \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                             \
-        if (lane == 0) __hip_atomic_store(&s_flag[e][wv], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);            \
-    }
-#define MP_WAIT1(e, seq, w)                                                                                                \
-    {                                                                                                                      \
-        int spin = 0;                                                                                                      \
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_flag[e][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < seq) { \
-            __builtin_amdgcn_s_sleep(1);                  /* 0, 1, 3: the same time */                                                                            \
-            if (++spin > (1 << 26)) __builtin_trap();              /* a lost neighbour must not hang the device */          \
-        }                                                                                                                  \
-    }
-#define MP_WAIT(e, seq)                                                                                                    \
-    {                                                                                                                      \
-        if (wv > 0) MP_WAIT1(e, seq, wv - 1)                                                                               \
-        if (wv < nw - 1) MP_WAIT1(e, seq, wv + 1)                                                                          \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                             \
-    }
-    constexpr bool PARK = true;
-    constexpr int NA4 = (H + 3) / 4, NB4 = 2 * KB;  // float4 slots: q2M[H] | mM nM v2S FyS bYinM bYoutM acc rdhM [KB each]
-    constexpr int NC4 = (2 * KB + 3) / 4;           // 1 / (jaco rho), 1 / (jaco rho dz) of plane N: loaded for the donor-cell pass, needed
-                                                    // again by the roll of the NEXT step (N has become P by then)
-    __shared__ float4 s_park[PARK ? NA4 + NB4 + NC4 : 1][PARK ? 64 * MP_NW : 1];
+    // below and the wave above it, nothing else.  A wave posts its edges (data, then a step counter; the LDS executes one
+    // wave's operations in order, so a reader that sees the counter sees the data), does the work that needs no neighbour, and
+    // spins on the two neighbouring counters.  The double buffering by step parity stays sufficient: wave w overwrites a buffer
+    // at step t + 2 only after it has seen the counters of w-1 / w+1 at t + 1, which they post after their reads of step t.
+    // Counters: s_sync[e * NW2 + 1 + wave]; the entries below wave 0 and above the last wave are INT_MAX (never waited for).
+    // Every lane stores (no EXEC change): lane 0 to the counter, the others to a dump area behind the counters.
+    constexpr int NW2 = MP_NW + 2;
+    __shared__ int s_sync[3 * NW2 + 64];
+    constexpr int NA4 = (H + 3) / 4, NB4 = 2 * KB;  // float4 slots: q2M[H] | per level {mM nM v2S FyS} {bYinM bYoutM acc rdhM}
+    __shared__ float4 s_park[NA4 + NB4][64 * MP_NW];
 
     const int lane = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y), nw = blockDim.y;
@@ -189,7 +191,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         const unsigned cap = (nitem + 7u) / 8u, xcd = id & 7u, slot = id >> 3;
         const unsigned it = xcd * cap + slot;
         if (slot >= cap || it >= nitem) return;
-        if (lane == 0) { s_flag[0][threadIdx.y] = 0; s_flag[1][threadIdx.y] = 0; }
+        for (int t = tid; t < 2 * NW2; t += 64 * nw) { const int j = t % NW2; s_sync[t] = (j == 0 || j > nw) ? 0x7fffffff : 0; }
         __syncthreads();
         const unsigned g = it / nv;
         m = (int)(it - g * nv);
@@ -207,134 +209,136 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                  cr = mkrsrc(Cg);                           // the eleven coefficient arrays, asz bytes each
 
     const int i = 1 - MP_HL + tile * MP_XOUT + lane;
-    const int ic = min(max(i, 0), nx - 1);
-    const bool xlo = (i == 0), xhi = (i == nx - 1), xin = (i > 0) && (i < nx - 1);
-    const bool xring = xlo || xhi;
-    const bool lane_out = (lane >= MP_HL) && (lane < 64 - MP_HL) && xin;
-    const int bx = 4 * ic;
+    const int ic = min(max(i, 0), nx - 1);                  // lanes outside the domain are copies of the ring column
+    const bool xin = (i > 0) && (i < nx - 1), xring = (i == 0) || (i == nx - 1);
+    const bool lane_store = ((lane >= MP_HL) && (lane < 64 - MP_HL) && xin) || xring;
+    float rm = xring ? 0.0f : 1.0f;                         // the limiter sees no flow into or out of a ring cell
     const int ja = 1 + chunk * clen, jb = min(ja + clen - 1, ny - 2);
     const int k0 = kbase + wv * KB;
-    // level of slot h (0..H-1) = k0-1+h, clamped for addressing; flags are wave-uniform
-    int kc[H];
+    // byte offset of (column, level of slot h) -- slot h (0..H-1) = level k0-1+h, clamped: the slot above the top level holds the
+    // top level's own values and the slot below level 0 those of level 0: upw(q(top), q(top+1), W) IS q(top) W
+    // (adv_mpdata.f90:96), and the z limiter's first-cell form (extrema without the cell below, no flux through the ground)
+    // falls out of the general one because max(q2(0), l(0)) is the cell's own extremum and the ground flux is +-0.
+    int vk[H];
 #pragma unroll
-    for (int h = 0; h < H; ++h) kc[h] = min(max(k0 - 1 + h, 0), nz - 1) * nx * 4;       // byte offset of the level
+    for (int h = 0; h < H; ++h) { vk[h] = 4 * ic + min(max(k0 - 1 + h, 0), nz - 1) * nx * 4; asm volatile("" : "+v"(vk[h])); }
+    asm volatile("" : "+v"(rm));
+    // nothing flows through the ground (slot 0 is a clamped load there): a wave-uniform factor
+    const float gmul = __int_as_float(__builtin_amdgcn_readfirstlane((k0 == 0) ? 0 : 0x3f800000));
+    // what is left of the level flags: the last-cell form of the z limiter at the top of the column and, unless EXACT, the
+    // store range.  EXACT: slot KB of the last wave, one wave-uniform flag.  Otherwise three scalars, kept opaque so that the
+    // comparisons are redone by the scalar unit inside the step instead of living in SGPR pairs across it.
+    const bool topwave = (k0 + KB == nz);
+    const int htop_u = __builtin_amdgcn_readfirstlane(nz - k0), kst0_u = __builtin_amdgcn_readfirstlane(ka - k0), kst1_u = __builtin_amdgcn_readfirstlane(kb - k0);
+    // neighbour waves: where the wave below / above does not exist the wave reads its own edge instead (for the pass-1 field
+    // that IS the clamped halo level; the betas read this way limit a face whose flux is zero)
+    const int wlo = max(wv - 1, 0), whi = min(wv + 1, nw - 1);
+    const int q2lo = (wv > 0) ? 1 : 0, q2hi = (wv < nw - 1) ? 0 : 1;          // which edge of that wave
+    const int bzlo = (wv > 0) ? 2 : 0, bzhi = (wv < nw - 1) ? 0 : 2;
+    int *const fpost = (lane == 0) ? &s_sync[1 + wv] : &s_sync[2 * NW2 + lane];
+    int seqA = 0, seqB = 0;
+#define MP_POST(e, seq)                                                                                                   \
+    {                                                                                                                      \
+        ++seq;                                                                                                             \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+        __hip_atomic_store(fpost + (e) * NW2, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                         \
+    }
+#define MP_WAIT(e, seq)                                                                                                    \
+    {                                                                                                                      \
+        int spin = 0;                                                                                                      \
+        for (;;) {                                                                                                         \
+            const int fa = __hip_atomic_load(&s_sync[(e) * NW2 + wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      \
+            const int fb = __hip_atomic_load(&s_sync[(e) * NW2 + wv + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  \
+            if (__builtin_amdgcn_readfirstlane(min(fa, fb)) >= seq) break;                                                 \
+            __builtin_amdgcn_s_sleep(1);                                                                                   \
+            if (++spin > (1 << 26)) __builtin_trap();              /* a lost neighbour must not hang the device */          \
+        }                                                                                                                  \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
+    }
 
-#define LDP(arr, h, plane) ldb(arr, bx, (plane) * sj4 + kc[h])
-#define LDC(a, h, plane) ldb(cr, bx, (a) * asz + (plane) * sj4 + kc[h])                 /* coefficient array a (MPC_*) */
+#define LDQ(h, po) ldb(q, vk[h], (po))
+#define LDC(a, h, po) ldb(cr, vk[h], (a) * asz + (po))                  /* coefficient array a (MPC_*) */
 #define CLAMPJ(p) min(max((p), 0), ny - 1)
 
     // ---- rolling state (planes relative to the step's in-plane index P; N = P+1, M = P-1) ----
-    float qP[KB], qN[H], qPh0 = 0.f, qPh1 = 0.f;            // q (= l of the limiter): plane P own levels (+ its halo levels), plane N
-    float q2P[H];                                           // field after pass 1, plane P
-    float mP[KB], nP[KB];                                   // max / min of (q2, l) per cell, plane P
-    float DxP[KB], SxP[KB], DzP[KB], SzP[KB];               // q2(i+1) -+ q2(i-1), q2(k+1) -+ q2(k-1) on plane P
-    // plane-M part (parked between steps): pkA = q2M[H] ; pkB = mM nM v2S FyS bYinM bYoutM acc rdhM, KB values each
-    //   mM, nM: extrema of plane M; v2S, FyS: pseudo-velocity / unlimited flux of the y face (P-1/2); bY*M: beta_y of
-    //   plane M; acc: q2 - x/z/south contributions of plane M; rdhM: 1 / (jaco rho) of plane M
-    float pkA[NA4 * 4], pkB[NB4 * 4];
+    struct QBuf { float v[H]; };                            // one plane of the scalar (= l of the limiter)
+    struct PSet {                                           // everything of a plane that a later step reads from registers
+        float q2[H];                                        // field after pass 1
+        float m[KB], n[KB];                                 // max / min of (q2, l) per cell
+        float Dx[KB], Sx[KB], Dz[KB], Sz[KB];               // q2(i+1) -+ q2(i-1), q2(k+1) -+ q2(k-1)
+        float Fyd[KB];                                      // donor-cell flux through the plane's NORTH face (pass 1)
+        float mh0, nh0, mh1, nh1;                           // extrema of the two halo levels (z limiter)
+    };
+    QBuf Q0, Q1;
+    PSet S0, S1;
 #pragma unroll
-    for (int t = 0; t < NA4 * 4; ++t) pkA[t] = 0.f;
+    for (int kk = 0; kk < KB; ++kk) { S0.m[kk] = S0.n[kk] = 0.f; S0.Dx[kk] = S0.Sx[kk] = S0.Dz[kk] = S0.Sz[kk] = 0.f; S0.Fyd[kk] = 0.f; }
 #pragma unroll
-    for (int t = 0; t < NB4 * 4; ++t) pkB[t] = 0.f;
-    if (PARK) {
+    for (int h = 0; h < H; ++h) S0.q2[h] = 0.f;
+    S0.mh0 = 0.f; S0.nh0 = 0.f; S0.mh1 = 0.f; S0.nh1 = 0.f;
+    S1 = S0;
 #pragma unroll
-        for (int t = 0; t < NA4 + NB4 + NC4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) { mP[kk] = nP[kk] = 0.f; DxP[kk] = SxP[kk] = DzP[kk] = SzP[kk] = 0.f; }
-#pragma unroll
-    for (int h = 0; h < H; ++h) q2P[h] = 0.f;
+    for (int t = 0; t < NA4 + NB4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int P0 = ja - 3;
+    // inputs of one step that are requested during the step before it
+    float WN[KB + 1], UN[KB], VNN[KB], rdhN[KB], rdvN[KB];
+// group A: what the donor-cell pass of step PP reads (plane PP+1; the north face's V on plane PP+2)
+#define ISSUE_LOADS_A(oN_, oNN_)                                                                                         \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = ldb(Wr, vk[h], (oN_));                                   \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = ldb(Ur, vk[kk + 1], (oN_)); VNN[kk] = ldb(Vr, vk[kk + 1], (oNN_)); } \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { rdhN[kk] = LDC(MPC_RDH, kk + 1, (oN_)); rdvN[kk] = LDC(MPC_RDV, kk + 1, (oN_)); } \
+    }
+    {
+        const int o0 = CLAMPJ(P0) * sj4, o1 = CLAMPJ(P0 + 1) * sj4, o2 = CLAMPJ(P0 + 2) * sj4;
+        float qP0[KB], V1[KB];
 #pragma unroll
-    for (int kk = 0; kk < KB; ++kk) qP[kk] = LDP(q, kk + 1, CLAMPJ(P0));
+        for (int kk = 0; kk < KB; ++kk) { qP0[kk] = LDQ(kk + 1, o0); V1[kk] = ldb(Vr, vk[kk + 1], o1); }
 #pragma unroll
-    for (int h = 0; h < H; ++h) qN[h] = LDP(q, h, CLAMPJ(P0 + 1));
-
-    // inputs of one step (plane indices relative to that step's P): see ISSUE_LOADS
-    float qNN[H], WN[KB + 1], UN[KB], VN[KB], VNN[KB], rdhN[KB], rdvN[KB];
-    float avN[KB], cvuN[KB], cvwN[KB], auP[KB], cuvP[KB], cuwP[KB], awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1];
-// group A: what the donor-cell pass (first half of a step) reads; group B: the x / y face coefficients (plane P / face P | N),
-// requested at the top of the step; group Z: the z face coefficients of plane P, requested after the donor-cell pass
-#define ISSUE_LOADS_A(PP)                                                                                                \
-    {                                                                                                                    \
-        const int lN = CLAMPJ((PP) + 1), lNN = CLAMPJ((PP) + 2);                                                         \
-        _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = LDP(Wr, h, lN);                                          \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = LDP(Ur, kk + 1, lN); VN[kk] = LDP(Vr, kk + 1, lN); VNN[kk] = LDP(Vr, kk + 1, lNN); } \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { rdhN[kk] = LDC(MPC_RDH, kk + 1, lN); rdvN[kk] = LDC(MPC_RDV, kk + 1, lN); } \
+        for (int h = 0; h < H; ++h) Q0.v[h] = LDQ(h, o1);
+#pragma unroll
+        for (int h = 0; h < H; ++h) Q1.v[h] = LDQ(h, o2);
+        ISSUE_LOADS_A(o1, o2)
+        if (PASS1) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) S0.Fyd[kk] = upw(qP0[kk], Q0.v[kk + 1], V1[kk]);     // the face between planes P0 and P0+1
+        }
     }
-#define ISSUE_LOADS_B(PP)                                                                                                \
-    {                                                                                                                    \
-        const int lP = CLAMPJ(PP), lN = CLAMPJ((PP) + 1);                                                                \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { avN[kk] = LDC(MPC_AV, kk + 1, lN); cvuN[kk] = LDC(MPC_CVU, kk + 1, lN); cvwN[kk] = LDC(MPC_CVW, kk + 1, lN); } \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { auP[kk] = LDC(MPC_AU, kk + 1, lP); cuvP[kk] = LDC(MPC_CUV, kk + 1, lP); cuwP[kk] = LDC(MPC_CUW, kk + 1, lP); } \
-    }
-#define ISSUE_LOADS_Z(PP)                                                                                                \
-    {                                                                                                                    \
-        const int lP = CLAMPJ(PP);                                                                                       \
-        _Pragma("unroll") for (int h = 0; h <= KB; ++h) { awP[h] = LDC(MPC_AW, h, lP); cwuP[h] = LDC(MPC_CWU, h, lP); cwvP[h] = LDC(MPC_CWV, h, lP); } \
-    }
-// the scalar itself: every plane of it comes from HBM exactly once, so its latency is the longest of all inputs
-#define ISSUE_LOADS_Q(DST, PLANE)                                                                                        \
-    {                                                                                                                    \
-        const int lq = CLAMPJ(PLANE);                                                                                    \
-        _Pragma("unroll") for (int h = 0; h < H; ++h) DST[h] = LDP(q, h, lq);                                            \
-    }
-    ISSUE_LOADS_Q(qNN, P0 + 2)
-    ISSUE_LOADS_A(P0)
-    // One step of the march.  STEADY = every stage is on and no plane of the window is a boundary row of the domain
-    // (the bulk of a chunk): the stage conditions and the first/last-row forms of the y limiter are compiled out, and
-    // with them the zero-initialisations and merge copies of ~70 values per step.  The generic form runs the warm-up
-    // steps of a chunk, its last steps and the chunks that touch row 0 / ny-1.
-    // Level flags.  "Is slot h the ground / the top of the column" is wave-uniform and loop-invariant; written as k-comparisons
-    // per slot the compiler keeps every one of them as a 64-bit select mask in SGPRs (~50 pairs, half of them spilled to
-    // VGPR lanes and read back with v_readlane every step).  Most of them are not needed at all:
-    //   * the halo slots are CLAMPED loads, so the slot above the top level holds the top level's own values and the slot
-    //     below level 0 those of level 0: upw(q(top), q(top+1), W) IS q(top) W (adv_mpdata.f90:96), and the z limiter's
-    //     first-cell form (extrema without the cell below, no flux through the ground) falls out of the general one because
-    //     max(q2(0), l(0)) is the cell's own extremum and the ground flux is +-0;
-    //   * what is left -- zero pseudo-velocity through the ground and the top face, no z cross terms in the lowest and highest
-    //     level, the last-cell form of the z limiter, the store range -- is decided from four scalars per step (ground, slot of the
-    //     top level, first / last stored slot), made opaque below so that the comparisons are redone by the scalar unit inside the
-    //     step instead of living in SGPR pairs across it.
-    const int htop_u = __builtin_amdgcn_readfirstlane(nz - k0), gnd_u = __builtin_amdgcn_readfirstlane((k0 == 0) ? 1 : 0),    // slot h = level k0-1+h
-              kst0_u = __builtin_amdgcn_readfirstlane(ka - k0), kst1_u = __builtin_amdgcn_readfirstlane(kb - k0);
-    auto step = [&](auto steady_tag, const int P) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        int htop = htop_u, gnd = gnd_u, kst0 = kst0_u, kst1 = kst1_u;
-        asm volatile("" : "+s"(htop), "+s"(gnd), "+s"(kst0), "+s"(kst1));
+    // One step of the march.  STEADY = every stage is on and no plane of the window is a boundary row of the domain (the bulk of
+    // a chunk): qN / qNN and sP / sN are the two register sets in this step's roles, nothing is copied, PAR is a constant.
+    // The generic form runs the warm-up steps of a chunk, its last steps and the chunks that touch row 0 / ny-1, always with
+    // the sets in the roles (Q0, Q1, S0, S1), and rolls them by copying.
+    auto step = [&](auto md, QBuf &qN, QBuf &qNN, PSet &sP, PSet &sN, const int P) {
+        constexpr bool STEADY = decltype(md)::steady;
+        const int par = STEADY ? decltype(md)::par : ((P - P0) & 1);
         const int N = P + 1;
-        const int pP = CLAMPJ(P), pN = CLAMPJ(N), pNN = CLAMPJ(N + 1);
-        const int par = (P - P0) & 1;
         const bool haveN = STEADY || ((N >= 0) && (N <= ny - 1));
-        // Group A of this step's global loads was issued during the previous step (after its x/z limiter), group B is
-        // issued here; each group back to back -- loads placed next to their use were waited for one by one: 59 exposed
-        // L2 round trips per step.
-        ISSUE_LOADS_B(P)                                           // land while the donor-cell pass runs
+        const int oP = (STEADY ? P : CLAMPJ(P)) * sj4, oN = (STEADY ? N : CLAMPJ(N)) * sj4;
+        int htop = htop_u, kst0 = kst0_u, kst1 = kst1_u;
+        if (!EXACT) asm volatile("" : "+s"(htop), "+s"(kst0), "+s"(kst1));
+        // Group A of this step's global loads was issued during the previous step (after its x/z limiter), group B -- the x / y
+        // face coefficients -- is issued here; each group back to back: loads placed next to their use were waited for one by one.
+        float avN[KB], cvuN[KB], cvwN[KB], auP[KB], cuvP[KB], cuwP[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) { avN[kk] = LDC(MPC_AV, kk + 1, oN); cvuN[kk] = LDC(MPC_CVU, kk + 1, oN); cvwN[kk] = LDC(MPC_CVW, kk + 1, oN); }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) { auP[kk] = LDC(MPC_AU, kk + 1, oP); cuvP[kk] = LDC(MPC_CUV, kk + 1, oP); cuwP[kk] = LDC(MPC_CUW, kk + 1, oP); }
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= S1: donor-cell pass on plane N, its extrema and x/z differences =================
-        float q2N[H], mN[KB], nN[KB], DxN[KB], SxN[KB], DzN[KB], SzN[KB];
-#pragma unroll
-        for (int h = 0; h < H; ++h) q2N[h] = qN[h];
+        float *const q2N = sN.q2;
         if (haveN) {
-            const bool ring = !STEADY && ((N == 0) || (N == ny - 1));
-            if (PASS1 && !ring) {
+            if (PASS1) {
                 float FzT[KB + 1];                                 // flux through the face ABOVE level k0-1+h
 #pragma unroll
-                for (int h = 0; h <= KB; ++h) {
-                    const float Wc = WN[h];
-                    float f = upw(qN[h], qN[h + 1], Wc);          // at the top of the column q(h+1) == q(h): q*W (adv_mpdata.f90:96)
-                    if (h == 0 && gnd) f = 0.f;                   // the ground
-                    FzT[h] = f;
-                }
+                for (int h = 0; h <= KB; ++h) FzT[h] = upw(qN.v[h], qN.v[h + 1], WN[h]);   // at the top of the column q(h+1) == q(h): q*W (adv_mpdata.f90:96)
+                FzT[0] *= gmul;                                    // the ground
                 auto donor = [&](const int kk) {
                     const int h = kk + 1;
-                    const float Uc = UN[kk], Vs = VN[kk], Vn = VNN[kk];
-                    const float rdh = rdhN[kk], rdv = rdvN[kk];
-                    const float FxL = upw(dpp_l(qN[h]), qN[h], Uc), FxR = dpp_r(FxL);
-                    const float Fs = upw(qP[kk], qN[h], Vs), Fn = upw(qN[h], qNN[h], Vn);
-                    const float v = qN[h] - ((FxR - FxL) + (Fn - Fs)) * rdh - (FzT[h] - FzT[h - 1]) * rdv;
-                    q2N[h] = xring ? qN[h] : v;
+                    const float FxL = upw(dpp_l(qN.v[h]), qN.v[h], UN[kk]), FxR = dpp_r(FxL);
+                    const float Fn = upw(qN.v[h], qNN.v[h], VNN[kk]);
+                    q2N[h] = qN.v[h] - ((FxR - FxL) + (Fn - sP.Fyd[kk])) * rdhN[kk] - (FzT[h] - FzT[h - 1]) * rdvN[kk];   // ring cells: rdh = rdv = 0
+                    sN.Fyd[kk] = Fn;
                 };
                 // the two levels the neighbouring waves wait for go first and are posted before the others are computed
                 donor(0);
@@ -344,55 +348,59 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
                 for (int kk = 1; kk < KB - 1; ++kk) donor(kk);
             } else {
-                // pass-1 field of the levels just below / above my own ones
-                s_q2[par][wv][0][lane] = q2N[1]; s_q2[par][wv][1][lane] = q2N[KB];
-                MP_POST(0, seqA)
+#pragma unroll
+                for (int h = 0; h < H; ++h) q2N[h] = qN.v[h];      // iord >= 3: q2 == q, halo levels included (no exchange)
             }
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) { mN[kk] = fmaxf(q2N[kk + 1], qN[kk + 1]); nN[kk] = fminf(q2N[kk + 1], qN[kk + 1]); }
+            for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = fmaxf(q2N[kk + 1], qN.v[kk + 1]); sN.n[kk] = fminf(q2N[kk + 1], qN.v[kk + 1]); }
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {                      // what needs no neighbour, before the wait
                 const int h = kk + 1;
                 const float l = dpp_l(q2N[h]), r = dpp_r(q2N[h]);
-                DxN[kk] = r - l; SxN[kk] = r + l;
-                if (kk > 0 && kk < KB - 1) { DzN[kk] = q2N[h + 1] - q2N[h - 1]; SzN[kk] = q2N[h + 1] + q2N[h - 1]; }
+                sN.Dx[kk] = r - l; sN.Sx[kk] = r + l;
+                if (kk > 0 && kk < KB - 1) { sN.Dz[kk] = q2N[h + 1] - q2N[h - 1]; sN.Sz[kk] = q2N[h + 1] + q2N[h - 1]; }
             }
-            MP_WAIT(0, seqA)
-            q2N[0] = (wv > 0) ? s_q2[par][wv - 1][1][lane] : q2N[1];
-            q2N[H - 1] = (wv < nw - 1) ? s_q2[par][wv + 1][0][lane] : q2N[KB];
-            DzN[0] = q2N[2] - q2N[0]; SzN[0] = q2N[2] + q2N[0];
-            if (KB > 1) { DzN[KB - 1] = q2N[KB + 1] - q2N[KB - 1]; SzN[KB - 1] = q2N[KB + 1] + q2N[KB - 1]; }
+            if (PASS1) {
+                MP_WAIT(0, seqA)
+                q2N[0] = s_q2[par][wlo][q2lo][lane];
+                q2N[H - 1] = s_q2[par][whi][q2hi][lane];
+            }
+            sN.Dz[0] = q2N[2] - q2N[0]; sN.Sz[0] = q2N[2] + q2N[0];
+            if (KB > 1) { sN.Dz[KB - 1] = q2N[KB + 1] - q2N[KB - 1]; sN.Sz[KB - 1] = q2N[KB + 1] + q2N[KB - 1]; }
+            sN.mh0 = fmaxf(q2N[0], qN.v[0]); sN.nh0 = fminf(q2N[0], qN.v[0]);
+            sN.mh1 = fmaxf(q2N[H - 1], qN.v[H - 1]); sN.nh1 = fminf(q2N[H - 1], qN.v[H - 1]);
         } else {
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) { mN[kk] = nN[kk] = 0.f; DxN[kk] = SxN[kk] = DzN[kk] = SzN[kk] = 0.f; }
+            for (int h = 0; h < H; ++h) q2N[h] = qN.v[h];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = sN.n[kk] = 0.f; sN.Dx[kk] = sN.Sx[kk] = sN.Dz[kk] = sN.Sz[kk] = 0.f; sN.Fyd[kk] = 0.f; }
+            sN.mh0 = 0.f; sN.nh0 = 0.f; sN.mh1 = 0.f; sN.nh1 = 0.f;
         }
 
-        // The q part of the window rolls here, and the next plane of the scalar is requested now: three quarters of a
-        // step cover its HBM latency instead of the one quarter left after the x/z limiter (1.41 -> 1.34 ms; a fourth
-        // plane of q in registers, requested a whole step ahead, costs more in register pressure than it hides: 1.41).
-        float qPh0n, qPh1n;
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) qP[kk] = qN[kk + 1];
-        qPh0n = qN[0]; qPh1n = qN[H - 1];
-#pragma unroll
-        for (int h = 0; h < H; ++h) qN[h] = qNN[h];
+        // Plane N of the scalar has been used up: the next plane is requested now, three quarters of a step ahead (it is the
+        // one input that ALWAYS comes from HBM) -- in the steady loop straight into the registers of plane N.
         __builtin_amdgcn_sched_barrier(0);
-        ISSUE_LOADS_Q(qNN, P + 3)
-        ISSUE_LOADS_Z(P)
-        __builtin_amdgcn_sched_barrier(0);
-        // 1 / (jaco rho), 1 / (jaco rho dz) of plane N: parked for the roll of the next step; those of plane P come back
-        float rdhL[KB], rdvL[KB];
         {
-            float pc[NC4 * 4];
+            const int o3 = (STEADY ? P + 3 : CLAMPJ(P + 3)) * sj4;
+            if (STEADY) {
 #pragma unroll
-            for (int t = 0; t < NC4; ++t) { const float4 v = s_park[NA4 + NB4 + t][tid]; pc[4 * t] = v.x; pc[4 * t + 1] = v.y; pc[4 * t + 2] = v.z; pc[4 * t + 3] = v.w; }
+                for (int h = 0; h < H; ++h) qN.v[h] = LDQ(h, o3);
+            } else {
+                qN = qNN;
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) { rdhL[kk] = pc[kk]; rdvL[kk] = pc[KB + kk]; pc[kk] = rdhN[kk]; pc[KB + kk] = rdvN[kk]; }
-#pragma unroll
-            for (int t = 0; t < NC4; ++t) s_park[NA4 + NB4 + t][tid] = make_float4(pc[4 * t], pc[4 * t + 1], pc[4 * t + 2], pc[4 * t + 3]);
+                for (int h = 0; h < H; ++h) qNN.v[h] = LDQ(h, o3);
+            }
         }
+        // group Z: the z face coefficients of plane P and its 1 / (jaco rho), 1 / (jaco rho dz)
+        float awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1], rdhP[KB], rdvP[KB];
+#pragma unroll
+        for (int h = 0; h <= KB; ++h) { awP[h] = LDC(MPC_AW, h, oP); cwuP[h] = LDC(MPC_CWU, h, oP); cwvP[h] = LDC(MPC_CWV, h, oP); }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) { rdhP[kk] = LDC(MPC_RDH, kk + 1, oP); rdvP[kk] = LDC(MPC_RDV, kk + 1, oP); }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ================= S2: y face between planes P and N =================
+        const float *const q2P = sP.q2;
         float v2N[KB], FyN[KB];
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; }
@@ -400,10 +408,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const int h = kk + 1;
-                const float av = avN[kk], cvu = cvuN[kk], cvw = cvwN[kk];          // k_mpdata_coef
-                const float t = av * (q2N[h] - q2P[h]) * frcp(q2N[h] + q2P[h] + EPSQ)
-                              - cvu * (DxN[kk] + DxP[kk]) * frcp(SxN[kk] + SxP[kk] + EPSQ)
-                              - cvw * (DzN[kk] + DzP[kk]) * frcp(SzN[kk] + SzP[kk] + EPSQ);
+                const float t = avN[kk] * (q2N[h] - q2P[h]) * frcp(q2N[h] + q2P[h] + EPSQ)
+                              - cvuN[kk] * (sN.Dx[kk] + sP.Dx[kk]) * frcp(sN.Sx[kk] + sP.Sx[kk] + EPSQ)
+                              - cvwN[kk] * (sN.Dz[kk] + sP.Dz[kk]) * frcp(sN.Sz[kk] + sP.Sz[kk] + EPSQ);
                 v2N[kk] = t; FyN[kk] = upw(q2P[h], q2N[h], t);
             }
         }
@@ -412,13 +419,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         float xdiv[KB], zdiv[KB];
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) { xdiv[kk] = zdiv[kk] = 0.f; }
-        float q2M[H];
-        if (PARK) {
+        float q2M[NA4 * 4];
 #pragma unroll
-            for (int t = 0; t < NA4; ++t) { const float4 v = s_park[t][tid]; pkA[4 * t] = v.x; pkA[4 * t + 1] = v.y; pkA[4 * t + 2] = v.z; pkA[4 * t + 3] = v.w; }
-        }
-#pragma unroll
-        for (int h = 0; h < H; ++h) q2M[h] = pkA[h];
+        for (int t = 0; t < NA4; ++t) { const float4 v = s_park[t][tid]; q2M[4 * t] = v.x; q2M[4 * t + 1] = v.y; q2M[4 * t + 2] = v.z; q2M[4 * t + 3] = v.w; }
         const bool planeP = STEADY || ((P >= ja) && (P <= jb));                // warm-up planes feed nothing but the y limiter
         if (planeP) {
             float Dy[H], Sy[H];
@@ -429,43 +432,40 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const int h = kk + 1;
-                const float au = auP[kk], cuv = cuvP[kk], cuw = cuwP[kk];
                 const float qL = dpp_l(q2P[h]);
-                const float t = au * (q2P[h] - qL) * frcp(q2P[h] + qL + EPSQ)
-                              - cuv * (Dy[h] + dpp_l(Dy[h])) * frcp(Sy[h] + dpp_l(Sy[h]) + EPSQ)
-                              - cuw * (DzP[kk] + dpp_l(DzP[kk])) * frcp(SzP[kk] + dpp_l(SzP[kk]) + EPSQ);
+                const float t = auP[kk] * (q2P[h] - qL) * frcp(q2P[h] + qL + EPSQ)
+                              - cuvP[kk] * (Dy[h] + dpp_l(Dy[h])) * frcp(Sy[h] + dpp_l(Sy[h]) + EPSQ)
+                              - cuwP[kk] * (sP.Dz[kk] + dpp_l(sP.Dz[kk])) * frcp(sP.Sz[kk] + dpp_l(sP.Sz[kk]) + EPSQ);
                 u2[kk] = t; Fx[kk] = upw(qL, q2P[h], t);
             }
             // ---- z faces above levels k0-1 .. k0+KB-1 (the lowest one is also computed by the wave below)
             float DxA[H], SxA[H];
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) { DxA[kk + 1] = DxP[kk]; SxA[kk + 1] = SxP[kk]; }
+            for (int kk = 0; kk < KB; ++kk) { DxA[kk + 1] = sP.Dx[kk]; SxA[kk + 1] = sP.Sx[kk]; }
             { const float l0 = dpp_l(q2P[0]), r0 = dpp_r(q2P[0]), l1 = dpp_l(q2P[H - 1]), r1 = dpp_r(q2P[H - 1]);
               DxA[0] = r0 - l0; SxA[0] = r0 + l0; DxA[H - 1] = r1 - l1; SxA[H - 1] = r1 + l1; }
             float Fz[KB + 1], w2[KB + 1];
 #pragma unroll
             for (int hf = 0; hf <= KB; ++hf) {
-                const float aw = awP[hf], cwu = cwuP[hf], cwv = cwvP[hf];         // already times dz (:383-385); zero for the top level (:214)
-                float t = aw * (q2P[hf + 1] - q2P[hf]) * frcp(q2P[hf + 1] + q2P[hf] + EPSQ)
-                        - cwu * (DxA[hf] + DxA[hf + 1]) * frcp(SxA[hf] + SxA[hf + 1] + EPSQ)
-                        - cwv * (Dy[hf] + Dy[hf + 1]) * frcp(Sy[hf] + Sy[hf + 1] + EPSQ);
-                if (hf == 0 && gnd) t = 0.0f;                     // no face below the ground (slot 0 is a clamped load there)
+                // coefficients already times dz (:383-385); zero for the top level (:214)
+                float t = awP[hf] * (q2P[hf + 1] - q2P[hf]) * frcp(q2P[hf + 1] + q2P[hf] + EPSQ)
+                        - cwuP[hf] * (DxA[hf] + DxA[hf + 1]) * frcp(SxA[hf] + SxA[hf + 1] + EPSQ)
+                        - cwvP[hf] * (Dy[hf] + Dy[hf + 1]) * frcp(Sy[hf] + Sy[hf + 1] + EPSQ);
+                if (hf == 0) t *= gmul;                           // no face below the ground
                 w2[hf] = t; Fz[hf] = upw(q2P[hf], q2P[hf + 1], t);
             }
-            // ---- limiter, x direction
+            // ---- limiter, x direction.  First / last cell of a line: the lanes beyond the ring are copies of the ring column
+            // (whose q2 == l), so max3 / min3 over (left, cell, right) ARE the reference's two-cell extrema there, and its
+            // "qmax(n) without l(n)" as well; the ring's fin = fout = 0 is the factor rm in the denominator.
             float FxLim[KB];
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 const int h = kk + 1;
                 if (FCT) {
                     const float qc = q2P[h], FxW = Fx[kk], FxE = dpp_r(Fx[kk]);
-                    const float mL = dpp_l(mP[kk]), mR = dpp_r(mP[kk]), nL = dpp_l(nP[kk]), nR = dpp_r(nP[kk]);
-                    float qmax = max3f(mL, mP[kk], mR), qmin = min3f(nL, nP[kk], nR);
-                    if (xlo) { qmax = fmaxf(mP[kk], mR); qmin = fminf(nP[kk], nR); }
-                    if (xhi) { qmax = fmaxf(mL, qc); qmin = fminf(nL, qc); }
-                    float fin = fmaxf(0.f, FxW) - fminf(0.f, FxE), fout = fmaxf(0.f, FxE) - fminf(0.f, FxW);
-                    if (xring) { fin = 0.f; fout = 0.f; }
-                    const float bin = (qmax - qc) * frcp(fin + EPSF), bout = (qc - qmin) * frcp(fout + EPSF);
+                    const float qmax = max3f(dpp_l(sP.m[kk]), sP.m[kk], dpp_r(sP.m[kk])), qmin = min3f(dpp_l(sP.n[kk]), sP.n[kk], dpp_r(sP.n[kk]));
+                    const float fin = fmaxf(0.f, FxW) - fminf(0.f, FxE), fout = fmaxf(0.f, FxE) - fminf(0.f, FxW);
+                    const float bin = (qmax - qc) * frcp(__builtin_fmaf(fin, rm, EPSF)), bout = (qc - qmin) * frcp(__builtin_fmaf(fout, rm, EPSF));
                     const float bLin = dpp_l(bin), bLout = dpp_l(bout);
                     const float s = fminf(1.0f, (u2[kk] > 0.0f) ? fminf(bin, bLout) : fminf(bLin, bout));
                     FxLim[kk] = s * Fx[kk];
@@ -478,13 +478,19 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 float bZin[H], bZout[H];
                 auto betaz = [&](const int kk) {
                     const int h = kk + 1;
-                    const float qc = q2P[h], FzB = Fz[h - 1], FzT = Fz[h];
-                    const float mlo = (kk > 0) ? mP[kk - 1] : fmaxf(q2P[0], qPh0), nlo = (kk > 0) ? nP[kk - 1] : fminf(q2P[0], qPh0);
-                    const float mhi = (kk < KB - 1) ? mP[kk + 1] : fmaxf(q2P[H - 1], qPh1), nhi = (kk < KB - 1) ? nP[kk + 1] : fminf(q2P[H - 1], qPh1);
-                    float qmax = max3f(mlo, mP[kk], mhi), qmin = min3f(nlo, nP[kk], nhi);
-                    float fin = fmaxf(0.f, FzB) - fminf(0.f, FzT), fout = fmaxf(0.f, FzT) - fminf(0.f, FzB);
+                    const float qc = q2P[h], FzB = Fz[h - 1];
+                    float FzT = Fz[h];
+                    const float mlo = (kk > 0) ? sP.m[kk - 1] : sP.mh0, nlo = (kk > 0) ? sP.n[kk - 1] : sP.nh0;
+                    float mhi = (kk < KB - 1) ? sP.m[kk + 1] : sP.mh1, nhi = (kk < KB - 1) ? sP.n[kk + 1] : sP.nh1;
+                    float mc = sP.m[kk], nc = sP.n[kk];
                     // (level 0: mlo / nlo are the cell's own extrema and FzB = +-0, which is the reference's first-cell form)
-                    if (h >= htop) { qmax = fmaxf(mlo, qc); qmin = fminf(nlo, qc); fin = fmaxf(0.f, FzB) - fminf(0.f, FzB); fout = fin; }
+                    // last cell of the column: extrema without l(n) and without a cell above, fin = fout = |FzB|
+                    if (EXACT ? (h == KB) : true) {
+                        const bool tp = EXACT ? topwave : (h >= htop);
+                        mc = tp ? qc : mc; nc = tp ? qc : nc; mhi = tp ? qc : mhi; nhi = tp ? qc : nhi; FzT = tp ? FzB : FzT;
+                    }
+                    const float qmax = max3f(mlo, mc, mhi), qmin = min3f(nlo, nc, nhi);
+                    const float fin = fmaxf(0.f, FzB) - fminf(0.f, FzT), fout = fmaxf(0.f, FzT) - fminf(0.f, FzB);
                     bZin[h] = (qmax - qc) * frcp(fin + EPSF); bZout[h] = (qc - qmin) * frcp(fout + EPSF);
                 };
                 betaz(0);                                          // the edge cells first: their betas are what the neighbouring waves wait for
@@ -499,10 +505,10 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                     FzLim[hf] = s * Fz[hf];
                 }
                 MP_WAIT(1, seqB)
-                bZin[0] = (wv > 0) ? s_bz[par][wv - 1][2][lane] : 0.f; bZout[0] = (wv > 0) ? s_bz[par][wv - 1][3][lane] : 0.f;
-                bZin[H - 1] = (wv < nw - 1) ? s_bz[par][wv + 1][0][lane] : 0.f; bZout[H - 1] = (wv < nw - 1) ? s_bz[par][wv + 1][1][lane] : 0.f;
+                bZin[0] = s_bz[par][wlo][bzlo][lane]; bZout[0] = s_bz[par][wlo][bzlo + 1][lane];
+                bZin[H - 1] = s_bz[par][whi][bzhi][lane]; bZout[H - 1] = s_bz[par][whi][bzhi + 1][lane];
 #pragma unroll
-                for (int hf = 0; hf <= KB; hf += KB) {             // the two faces shared with a neighbouring wave
+                for (int hf = 0; hf <= KB; hf += KB) {             // the two faces shared with a neighbouring wave (ground / column top: zero flux)
                     const float s = fminf(1.0f, (w2[hf] > 0.0f) ? fminf(bZin[hf + 1], bZout[hf]) : fminf(bZin[hf], bZout[hf + 1]));
                     FzLim[hf] = s * Fz[hf];
                 }
@@ -511,104 +517,94 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 for (int hf = 0; hf <= KB; ++hf) FzLim[hf] = Fz[hf];
             }
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                zdiv[kk] = FzLim[kk + 1] - FzLim[kk];
-
-            }
+            for (int kk = 0; kk < KB; ++kk) zdiv[kk] = FzLim[kk + 1] - FzLim[kk];
         }
 
-        // ---- the inputs of the NEXT step: in flight while this step finishes (y limiter, store, roll) ----
-        qPh0 = qPh0n; qPh1 = qPh1n;
+        // ---- the inputs of the NEXT step: in flight while this step finishes (y limiter, store, park) ----
         __builtin_amdgcn_sched_barrier(0);
-        ISSUE_LOADS_A(P + 1)
+        {
+            const int o2 = (STEADY ? P + 2 : CLAMPJ(P + 2)) * sj4, o3 = (STEADY ? P + 3 : CLAMPJ(P + 3)) * sj4;
+            ISSUE_LOADS_A(o2, o3)
+        }
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= S4: beta_y of plane P ; S5: limited y face (P-1/2) =================
-        float mM[KB], nM[KB], v2S[KB], FyS[KB], bYinM[KB], bYoutM[KB], acc[KB], rdhM[KB];
-        if (PARK) {
-#pragma unroll
-            for (int t = 0; t < NB4; ++t) { const float4 v = s_park[NA4 + t][tid]; pkB[4 * t] = v.x; pkB[4 * t + 1] = v.y; pkB[4 * t + 2] = v.z; pkB[4 * t + 3] = v.w; }
-        }
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            mM[kk] = pkB[kk]; nM[kk] = pkB[KB + kk]; v2S[kk] = pkB[2 * KB + kk]; FyS[kk] = pkB[3 * KB + kk];
-            bYinM[kk] = pkB[4 * KB + kk]; bYoutM[kk] = pkB[5 * KB + kk]; acc[kk] = pkB[6 * KB + kk]; rdhM[kk] = pkB[7 * KB + kk];
-        }
-        float bYin[KB], bYout[KB], FyLimS[KB];
+        // parked by the step before: per level {mM nM v2S FyS} {bYinM bYoutM acc rdhM} -- extrema of plane M; pseudo-velocity /
+        // unlimited flux of the y face (P-1/2); beta_y of plane M; q2 - x/z/south contributions of plane M; its 1 / (jaco rho)
+        float bYin[KB], bYout[KB], FyLimS[KB], outM[KB];
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int h = kk + 1;
+            const float4 pa = s_park[NA4 + 2 * kk][tid], pb = s_park[NA4 + 2 * kk + 1][tid];
+            const float mM = pa.x, nM = pa.y, v2S = pa.z, FyS = pa.w, bYinM = pb.x, bYoutM = pb.y, acc = pb.z, rdhM = pb.w;
             if (FCT) {
                 const float qc = q2P[h];
-                float qmax = max3f(mM[kk], mP[kk], mN[kk]), qmin = min3f(nM[kk], nP[kk], nN[kk]);
-                float fin = fmaxf(0.f, FyS[kk]) - fminf(0.f, FyN[kk]), fout = fmaxf(0.f, FyN[kk]) - fminf(0.f, FyS[kk]);
-                if (!STEADY && P <= 0) { qmax = fmaxf(mP[kk], mN[kk]); qmin = fminf(nP[kk], nN[kk]); fin = 0.f; fout = 0.f; }
-                if (!STEADY && P >= ny - 1) { qmax = fmaxf(mM[kk], qc); qmin = fminf(nM[kk], qc); fin = 0.f; fout = 0.f; }
+                float qmax = max3f(mM, sP.m[kk], sN.m[kk]), qmin = min3f(nM, sP.n[kk], sN.n[kk]);
+                float fin = fmaxf(0.f, FyS) - fminf(0.f, FyN[kk]), fout = fmaxf(0.f, FyN[kk]) - fminf(0.f, FyS);
+                if (!STEADY && P <= 0) { qmax = fmaxf(sP.m[kk], sN.m[kk]); qmin = fminf(sP.n[kk], sN.n[kk]); fin = 0.f; fout = 0.f; }
+                if (!STEADY && P >= ny - 1) { qmax = fmaxf(mM, qc); qmin = fminf(nM, qc); fin = 0.f; fout = 0.f; }
                 bYin[kk] = (qmax - qc) * frcp(fin + EPSF); bYout[kk] = (qc - qmin) * frcp(fout + EPSF);
-                const float s = fminf(1.0f, (v2S[kk] > 0.0f) ? fminf(bYin[kk], bYoutM[kk]) : fminf(bYinM[kk], bYout[kk]));
-                FyLimS[kk] = s * FyS[kk];
-            } else { bYin[kk] = bYout[kk] = 0.f; FyLimS[kk] = FyS[kk]; }
+                const float s = fminf(1.0f, (v2S > 0.0f) ? fminf(bYin[kk], bYoutM) : fminf(bYinM, bYout[kk]));
+                FyLimS[kk] = s * FyS;
+            } else { bYin[kk] = bYout[kk] = 0.f; FyLimS[kk] = FyS; }
+            outM[kk] = acc - FyLimS[kk] * rdhM;                    // plane M is complete (ring cells: rdh = 0, acc = q)
         }
 
-        // ================= S6: plane M is complete =================
+        // ================= S6: store plane M =================
         const int M = P - 1;
         if (STEADY || (M >= ja && M <= jb)) {
+            if (lane_store) {
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const float v = xring ? q2M[kk + 1] : acc[kk] - FyLimS[kk] * rdhM[kk];
-                if ((lane_out || (xring && lane < 64)) && (kk >= kst0 && kk <= kst1)) stb(out, bx, M * sj4 + kc[kk + 1], v);
+                for (int kk = 0; kk < KB; ++kk)
+                    if (EXACT || (kk >= kst0 && kk <= kst1)) stb(out, vk[kk + 1], M * sj4, outM[kk]);
             }
         }
         // the boundary rows of the new field are the old ones (adv_mpdata.f90:63-65)
         if (!STEADY && M == 0 && ja == 1) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out, bx, kc[kk + 1], q2M[kk + 1]);
+                if (lane_store && (EXACT || (kk >= kst0 && kk <= kst1))) stb(out, vk[kk + 1], 0, q2M[kk + 1]);
         }
         if (!STEADY && P == ny - 1 && jb == ny - 2) {
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk)
-                if ((lane_out || xring) && (kk >= kst0 && kk <= kst1)) stb(out, bx, (ny - 1) * sj4 + kc[kk + 1], q2P[kk + 1]);
+                if (lane_store && (EXACT || (kk >= kst0 && kk <= kst1))) stb(out, vk[kk + 1], (ny - 1) * sj4, q2P[kk + 1]);
         }
-        // ---- roll the window
+        // ---- park what the next step needs of plane P
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int h = kk + 1;
-            pkB[kk] = mP[kk]; pkB[KB + kk] = nP[kk]; pkB[2 * KB + kk] = v2N[kk]; pkB[3 * KB + kk] = FyN[kk];
-            pkB[4 * KB + kk] = bYin[kk]; pkB[5 * KB + kk] = bYout[kk];
-            pkB[6 * KB + kk] = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdhL[kk] - zdiv[kk] * rdvL[kk];
-            pkB[7 * KB + kk] = rdhL[kk];
-            mP[kk] = mN[kk]; nP[kk] = nN[kk];
-            DxP[kk] = DxN[kk]; SxP[kk] = SxN[kk]; DzP[kk] = DzN[kk]; SzP[kk] = SzN[kk];
+            const float accP = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdhP[kk] - zdiv[kk] * rdvP[kk];
+            s_park[NA4 + 2 * kk][tid] = make_float4(sP.m[kk], sP.n[kk], v2N[kk], FyN[kk]);
+            s_park[NA4 + 2 * kk + 1][tid] = make_float4(bYin[kk], bYout[kk], accP, rdhP[kk]);
         }
+        {
+            float pq[NA4 * 4];
 #pragma unroll
-        for (int h = 0; h < H; ++h) { pkA[h] = q2P[h]; q2P[h] = q2N[h]; }
-        if (PARK) {
+            for (int t = 0; t < NA4 * 4; ++t) pq[t] = (t < H) ? q2P[t < H ? t : 0] : 0.f;
 #pragma unroll
-            for (int t = 0; t < NA4; ++t) s_park[t][tid] = make_float4(pkA[4 * t], pkA[4 * t + 1], pkA[4 * t + 2], pkA[4 * t + 3]);
-#pragma unroll
-            for (int t = 0; t < NB4; ++t) s_park[NA4 + t][tid] = make_float4(pkB[4 * t], pkB[4 * t + 1], pkB[4 * t + 2], pkB[4 * t + 3]);
+            for (int t = 0; t < NA4; ++t) s_park[t][tid] = make_float4(pq[4 * t], pq[4 * t + 1], pq[4 * t + 2], pq[4 * t + 3]);
         }
-
+        if (!STEADY) sP = sN;                                      // the generic form rolls by copying
     };
+    using MdGeneric = MpMode<false, 0>; using MdEven = MpMode<true, 0>; using MdOdd = MpMode<true, 1>;
     {
-        const int s0 = ja + 1, s1 = max(min(jb, ny - 3), s0 - 1);  // steady steps: P in [s0, s1] (possibly empty)
+        // steady steps: P in [s0, s1] (possibly empty), taken in pairs; s0 - P0 = 4, so a pair starts on an even step parity.
+        // A steady step addresses planes P-1 .. P+3 without clamping: P + 3 <= ny - 1.
+        const int s0 = ja + 1, s1 = max(min(jb, ny - 4), s0 - 1);
+        const int npair = (s1 - s0 + 1) / 2, s1p = s0 + 2 * npair - 1;
         for (int ph = 0; ph < 2; ++ph) {                           // generic warm-up, steady bulk, generic tail
-            const int lo = ph ? s1 + 1 : P0, hi = ph ? jb + 1 : s0 - 1;
-            for (int P = lo; P <= hi; ++P) step(std::false_type{}, P);
+            const int lo = ph ? s1p + 1 : P0, hi = ph ? jb + 1 : s0 - 1;
+            for (int P = lo; P <= hi; ++P) step(MdGeneric{}, Q0, Q1, S0, S1, P);
             if (ph == 0)
-                for (int P = s0; P <= s1; ++P) step(std::true_type{}, P);
+                for (int P = s0; P < s1p; P += 2) { step(MdEven{}, Q0, Q1, S0, S1, P); step(MdOdd{}, Q1, Q0, S1, S0, P + 1); }
         }
     }
 #undef ISSUE_LOADS_A
-#undef ISSUE_LOADS_Q
-#undef ISSUE_LOADS_B
-#undef LDP
+#undef LDQ
 #undef LDC
-#undef ISSUE_LOADS_Z
 #undef MP_POST
 #undef MP_WAIT
-#undef MP_WAIT1
 #undef CLAMPJ
 }
 
@@ -616,13 +612,15 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 // host side
 // ------------------------------------------------------------------------------------------------
 template <int KB>
-static void launch_fused(icar_hip_ctx *c, bool fct, bool pass1, const CVarPtrs &in, const VarPtrs &out, int nv,
+static void launch_fused(icar_hip_ctx *c, bool fct, bool pass1, bool exact, const CVarPtrs &in, const VarPtrs &out, int nv,
                          int nw, int clen, int ntile, int nchunk, int nkr, int kstore)
 {
     const unsigned nitem = (unsigned)(ntile * nchunk * nkr * nv), cap = (nitem + 7u) / 8u;
     const dim3 g(8u * cap), b(64, nw);                      // block id = xcd + 8 * slot, slot < cap
-#define GO(F, P1) hipLaunchKernelGGL((k_mpdata_fused<KB, F, P1>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->mpc, (int)(c->n3 * sizeof(float)), clen, ntile, nchunk, nv, nkr, kstore)
-    if (fct) { if (pass1) GO(true, true); else GO(true, false); } else { if (pass1) GO(false, true); else GO(false, false); }
+#define GO(F, P1, E) hipLaunchKernelGGL((k_mpdata_fused<KB, F, P1, E>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->mpc, (int)(c->n3 * sizeof(float)), clen, ntile, nchunk, nv, nkr, kstore)
+#define GO2(F, P1) { if (exact) GO(F, P1, true); else GO(F, P1, false); }
+    if (fct) { if (pass1) GO2(true, true) else GO2(true, false) } else { if (pass1) GO2(false, true) else GO2(false, false) }
+#undef GO2
 #undef GO
 }
 
@@ -669,7 +667,8 @@ int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, co
     }
     const int clen = (rows + nchunk - 1) / nchunk;
     nchunk = (rows + clen - 1) / clen;
-#define KBCASE(K) case K: launch_fused<K>(c, fct, pass1, in, out, nv, nw, clen, ntile, nchunk, nkr, kstore); break;
+    const bool exact = (nkr == 1) && (kb * nw == nz);          // the waves hold exactly the column: no per-slot level tests
+#define KBCASE(K) case K: launch_fused<K>(c, fct, pass1, exact, in, out, nv, nw, clen, ntile, nchunk, nkr, kstore); break;
     switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) default: icar_set_error("mpdata: internal level-range error"); return 1; }
 #undef KBCASE
     HIPCHK(hipGetLastError());
