@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # finite data only: drop the NaN-canonicalisation v_max x,x,x in front of every fmin/fmax (no effect on finite results)
 PER_FILE_FLAGS = {"advect.hip": ["-fno-honor-nans"],
                   # the fused MPDATA kernel is held to the 1e-5 tolerance, not to bit equality: fma contraction allowed
-                  "mpdata.hip": ["-fno-honor-nans", "-ffp-contract=fast"]}
+                  "mpdata.hip": ["-fno-honor-nans", "-ffp-contract=fast", "-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",     # (a later -ffp-contract wins)
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -48,6 +48,7 @@
 #define MP_ZH 2                       // halo levels of a level range: a fake edge corrupts the outputs of the 2 levels next to it
 #define EPSQ 1e-10f
 #define EPSF 1e-15f
+#define HEPSQ 0.5e-10f                // every cross-term denominator is the sum of TWO stencil sums + EPSQ: each sum carries half of it
 
 // bound_ctrl:1 -- a lane without a source reads 0, so no `old` value has to be materialised and the shift can fold into
 // the consuming VALU instruction (v_sub_f32_dpp ...)
@@ -55,6 +56,13 @@ __device__ __forceinline__ float dpp_l(float x)   // value of lane-1 (0 in lane 
 { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x138, 0xf, 0xf, true)); }
 __device__ __forceinline__ float dpp_r(float x)   // value of lane+1 (0 in lane 63)
 { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130, 0xf, 0xf, true)); }
+// the same shifts with a dummy `old` operand: a DPP read folds into its consumer only when it has ONE consumer, and two reads of
+// one register written with dpp_l / dpp_r are merged into one v_mov_b32_dpp with two users.  (bound_ctrl:1: `old` is never read.)
+__device__ __forceinline__ float dpp_l2(float x, float o)
+{ return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(o), __float_as_int(x), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_r2(float x, float o)
+{ return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(o), __float_as_int(x), 0x130, 0xf, 0xf, true)); }
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }   // keeps max(max(a, b), c) two DPP-foldable v_max instead of v_max3 + two moves
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float upw(float l, float r, float U) { return U * (U > 0.0f ? l : r); }      // == flux1 (adv_mpdata.f90:40)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
@@ -327,6 +335,18 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 
         // ================= S1: donor-cell pass on plane N, its extrema and x/z differences =================
         float *const q2N = sN.q2;
+        const float *const q2P = sP.q2;
+        // S2, the y face between planes P and N, level by level
+        float v2N[KB], FyN[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; }
+        auto yface = [&](const int kk) {
+            const int h = kk + 1;
+            const float t = avN[kk] * (q2N[h] - q2P[h]) * frcp(q2N[h] + q2P[h] + EPSQ)
+                          - cvuN[kk] * (sN.Dx[kk] + sP.Dx[kk]) * frcp(sN.Sx[kk] + sP.Sx[kk])       // (the sums carry EPSQ / 2 each)
+                          - cvwN[kk] * (sN.Dz[kk] + sP.Dz[kk]) * frcp(sN.Sz[kk] + sP.Sz[kk]);
+            v2N[kk] = t; FyN[kk] = upw(q2P[h], q2N[h], t);
+        };
         if (haveN) {
             if (PASS1) {
                 float FzT[KB + 1];                                 // flux through the face ABOVE level k0-1+h
@@ -356,17 +376,17 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {                      // what needs no neighbour, before the wait
                 const int h = kk + 1;
-                const float l = dpp_l(q2N[h]), r = dpp_r(q2N[h]);
-                sN.Dx[kk] = r - l; sN.Sx[kk] = r + l;
-                if (kk > 0 && kk < KB - 1) { sN.Dz[kk] = q2N[h + 1] - q2N[h - 1]; sN.Sz[kk] = q2N[h + 1] + q2N[h - 1]; }
+                const float l = dpp_l(q2N[h]);
+                sN.Dx[kk] = dpp_r(q2N[h]) - l; sN.Sx[kk] = dpp_r2(q2N[h], l) + (l + HEPSQ);
+                if (kk > 0 && kk < KB - 1) { sN.Dz[kk] = q2N[h + 1] - q2N[h - 1]; sN.Sz[kk] = q2N[h + 1] + (q2N[h - 1] + HEPSQ); }
             }
             if (PASS1) {
                 MP_WAIT(0, seqA)
                 q2N[0] = s_q2[par][wlo][q2lo][lane];
                 q2N[H - 1] = s_q2[par][whi][q2hi][lane];
             }
-            sN.Dz[0] = q2N[2] - q2N[0]; sN.Sz[0] = q2N[2] + q2N[0];
-            if (KB > 1) { sN.Dz[KB - 1] = q2N[KB + 1] - q2N[KB - 1]; sN.Sz[KB - 1] = q2N[KB + 1] + q2N[KB - 1]; }
+            sN.Dz[0] = q2N[2] - q2N[0]; sN.Sz[0] = q2N[2] + (q2N[0] + HEPSQ);
+            if (KB > 1) { sN.Dz[KB - 1] = q2N[KB + 1] - q2N[KB - 1]; sN.Sz[KB - 1] = q2N[KB + 1] + (q2N[KB - 1] + HEPSQ); }
             sN.mh0 = fmaxf(q2N[0], qN.v[0]); sN.nh0 = fminf(q2N[0], qN.v[0]);
             sN.mh1 = fmaxf(q2N[H - 1], qN.v[H - 1]); sN.nh1 = fminf(q2N[H - 1], qN.v[H - 1]);
         } else {
@@ -380,6 +400,11 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         // Plane N of the scalar has been used up: the next plane is requested now, three quarters of a step ahead (it is the
         // one input that ALWAYS comes from HBM) -- in the steady loop straight into the registers of plane N.
         __builtin_amdgcn_sched_barrier(0);
+        // group Z: the z face coefficients of plane P -- requested BEFORE the scalar:
+        // vmcnt counts in order, so cache-resident loads issued behind an HBM load are waited for as long as that one
+        float awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1], rdhP[KB], rdvP[KB];
+#pragma unroll
+        for (int h = 0; h <= KB; ++h) { awP[h] = LDC(MPC_AW, h, oP); cwuP[h] = LDC(MPC_CWU, h, oP); cwvP[h] = LDC(MPC_CWV, h, oP); }
         {
             const int o3 = (STEADY ? P + 3 : CLAMPJ(P + 3)) * sj4;
             if (STEADY) {
@@ -391,30 +416,37 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 for (int h = 0; h < H; ++h) qNN.v[h] = LDQ(h, o3);
             }
         }
-        // group Z: the z face coefficients of plane P and its 1 / (jaco rho), 1 / (jaco rho dz)
-        float awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1], rdhP[KB], rdvP[KB];
-#pragma unroll
-        for (int h = 0; h <= KB; ++h) { awP[h] = LDC(MPC_AW, h, oP); cwuP[h] = LDC(MPC_CWU, h, oP); cwvP[h] = LDC(MPC_CWV, h, oP); }
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) { rdhP[kk] = LDC(MPC_RDH, kk + 1, oP); rdvP[kk] = LDC(MPC_RDV, kk + 1, oP); }
         __builtin_amdgcn_sched_barrier(0);
 
         // ================= S2: y face between planes P and N =================
-        const float *const q2P = sP.q2;
-        float v2N[KB], FyN[KB];
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; }
         if (STEADY || (P >= 0 && haveN)) {
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const int h = kk + 1;
-                const float t = avN[kk] * (q2N[h] - q2P[h]) * frcp(q2N[h] + q2P[h] + EPSQ)
-                              - cvuN[kk] * (sN.Dx[kk] + sP.Dx[kk]) * frcp(sN.Sx[kk] + sP.Sx[kk] + EPSQ)
-                              - cvwN[kk] * (sN.Dz[kk] + sP.Dz[kk]) * frcp(sN.Sz[kk] + sP.Sz[kk] + EPSQ);
-                v2N[kk] = t; FyN[kk] = upw(q2P[h], q2N[h], t);
-            }
+            for (int kk = 0; kk < KB; ++kk) yface(kk);
         }
 
+        // ================= S4: beta_y of plane P ; S5: limited y face (P-1/2) =================
+        // parked by the step before: per level {mM nM v2S FyS} {bYinM bYoutM acc rdhM} -- extrema of plane M; pseudo-velocity /
+        // unlimited flux of the y face (P-1/2); beta_y of plane M; q2 - x/z/south contributions of plane M; its 1 / (jaco rho).
+        float bYin[KB], bYout[KB], FyLimS[KB], outM[KB];
+        auto ylim = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const int h = kk + 1;
+            const float4 pa = s_park[NA4 + 2 * kk][tid], pb = s_park[NA4 + 2 * kk + 1][tid];
+            const float mM = pa.x, nM = pa.y, v2S = pa.z, FyS = pa.w, bYinM = pb.x, bYoutM = pb.y, acc = pb.z, rdhM = pb.w;
+            if (FCT) {
+                const float qc = q2P[h];
+                float qmax = max3f(mM, sP.m[kk], sN.m[kk]), qmin = min3f(nM, sP.n[kk], sN.n[kk]);
+                float fin = fmaxf(0.f, FyS) - fminf(0.f, FyN[kk]), fout = fmaxf(0.f, FyN[kk]) - fminf(0.f, FyS);
+                if (!STEADY && P <= 0) { qmax = fmaxf(sP.m[kk], sN.m[kk]); qmin = fminf(sP.n[kk], sN.n[kk]); fin = 0.f; fout = 0.f; }
+                if (!STEADY && P >= ny - 1) { qmax = fmaxf(mM, qc); qmin = fminf(nM, qc); fin = 0.f; fout = 0.f; }
+                bYin[kk] = (qmax - qc) * frcp(fin + EPSF); bYout[kk] = (qc - qmin) * frcp(fout + EPSF);
+                const float s = fminf(1.0f, (v2S > 0.0f) ? fminf(bYin[kk], bYoutM) : fminf(bYinM, bYout[kk]));
+                FyLimS[kk] = s * FyS;
+            } else { bYin[kk] = bYout[kk] = 0.f; FyLimS[kk] = FyS; }
+            outM[kk] = acc - FyLimS[kk] * rdhM;                    // plane M is complete (ring cells: rdh = 0, acc = q)
+        }
+        };
         // ================= S3: x and z faces of plane P, their limiter, divergence =================
         float xdiv[KB], zdiv[KB];
 #pragma unroll
@@ -426,7 +458,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         if (planeP) {
             float Dy[H], Sy[H];
 #pragma unroll
-            for (int h = 0; h < H; ++h) { Dy[h] = q2N[h] - q2M[h]; Sy[h] = q2N[h] + q2M[h]; }
+            for (int h = 0; h < H; ++h) { Dy[h] = q2N[h] - q2M[h]; Sy[h] = q2N[h] + (q2M[h] + HEPSQ); }
             // ---- x faces (i-1/2) of my own levels
             float Fx[KB], u2[KB];
 #pragma unroll
@@ -434,23 +466,24 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 const int h = kk + 1;
                 const float qL = dpp_l(q2P[h]);
                 const float t = auP[kk] * (q2P[h] - qL) * frcp(q2P[h] + qL + EPSQ)
-                              - cuvP[kk] * (Dy[h] + dpp_l(Dy[h])) * frcp(Sy[h] + dpp_l(Sy[h]) + EPSQ)
-                              - cuwP[kk] * (sP.Dz[kk] + dpp_l(sP.Dz[kk])) * frcp(sP.Sz[kk] + dpp_l(sP.Sz[kk]) + EPSQ);
+                              - cuvP[kk] * (Dy[h] + dpp_l(Dy[h])) * frcp(Sy[h] + dpp_l(Sy[h]))
+                              - cuwP[kk] * (sP.Dz[kk] + dpp_l(sP.Dz[kk])) * frcp(sP.Sz[kk] + dpp_l(sP.Sz[kk]));
                 u2[kk] = t; Fx[kk] = upw(qL, q2P[h], t);
             }
             // ---- z faces above levels k0-1 .. k0+KB-1 (the lowest one is also computed by the wave below)
             float DxA[H], SxA[H];
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) { DxA[kk + 1] = sP.Dx[kk]; SxA[kk + 1] = sP.Sx[kk]; }
-            { const float l0 = dpp_l(q2P[0]), r0 = dpp_r(q2P[0]), l1 = dpp_l(q2P[H - 1]), r1 = dpp_r(q2P[H - 1]);
-              DxA[0] = r0 - l0; SxA[0] = r0 + l0; DxA[H - 1] = r1 - l1; SxA[H - 1] = r1 + l1; }
+            { const float l0 = dpp_l(q2P[0]), l1 = dpp_l(q2P[H - 1]);
+              DxA[0] = dpp_r(q2P[0]) - l0; SxA[0] = dpp_r2(q2P[0], l0) + (l0 + HEPSQ);
+              DxA[H - 1] = dpp_r(q2P[H - 1]) - l1; SxA[H - 1] = dpp_r2(q2P[H - 1], l1) + (l1 + HEPSQ); }
             float Fz[KB + 1], w2[KB + 1];
 #pragma unroll
             for (int hf = 0; hf <= KB; ++hf) {
                 // coefficients already times dz (:383-385); zero for the top level (:214)
                 float t = awP[hf] * (q2P[hf + 1] - q2P[hf]) * frcp(q2P[hf + 1] + q2P[hf] + EPSQ)
-                        - cwuP[hf] * (DxA[hf] + DxA[hf + 1]) * frcp(SxA[hf] + SxA[hf + 1] + EPSQ)
-                        - cwvP[hf] * (Dy[hf] + Dy[hf + 1]) * frcp(Sy[hf] + Sy[hf + 1] + EPSQ);
+                        - cwuP[hf] * (DxA[hf] + DxA[hf + 1]) * frcp(SxA[hf] + SxA[hf + 1])
+                        - cwvP[hf] * (Dy[hf] + Dy[hf + 1]) * frcp(Sy[hf] + Sy[hf + 1]);
                 if (hf == 0) t *= gmul;                           // no face below the ground
                 w2[hf] = t; Fz[hf] = upw(q2P[hf], q2P[hf + 1], t);
             }
@@ -462,9 +495,11 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             for (int kk = 0; kk < KB; ++kk) {
                 const int h = kk + 1;
                 if (FCT) {
-                    const float qc = q2P[h], FxW = Fx[kk], FxE = dpp_r(Fx[kk]);
-                    const float qmax = max3f(dpp_l(sP.m[kk]), sP.m[kk], dpp_r(sP.m[kk])), qmin = min3f(dpp_l(sP.n[kk]), sP.n[kk], dpp_r(sP.n[kk]));
-                    const float fin = fmaxf(0.f, FxW) - fminf(0.f, FxE), fout = fmaxf(0.f, FxE) - fminf(0.f, FxW);
+                    // in / out flow from the positive and negative part of the one face a lane owns: max(0, F_W) - min(0, F_E), max(0, F_E) - min(0, F_W)
+                    const float qc = q2P[h], Fp = fmaxf(0.f, Fx[kk]), Fm = fminf(0.f, Fx[kk]);
+                    const float fin = Fp - dpp_r(Fm), fout = dpp_r(Fp) - Fm;
+                    const float qmax = fmaxf(dpp_r(sP.m[kk]), opaque(fmaxf(dpp_l(sP.m[kk]), sP.m[kk])));
+                    const float qmin = fminf(dpp_r(sP.n[kk]), opaque(fminf(dpp_l(sP.n[kk]), sP.n[kk])));
                     const float bin = (qmax - qc) * frcp(__builtin_fmaf(fin, rm, EPSF)), bout = (qc - qmin) * frcp(__builtin_fmaf(fout, rm, EPSF));
                     const float bLin = dpp_l(bin), bLout = dpp_l(bout);
                     const float s = fminf(1.0f, (u2[kk] > 0.0f) ? fminf(bin, bLout) : fminf(bLin, bout));
@@ -475,11 +510,13 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             // ---- limiter, z direction
             float FzLim[KB + 1];
             if (FCT) {
-                float bZin[H], bZout[H];
+                float bZin[H], bZout[H], Fzp[KB + 1], Fzm[KB + 1];
+#pragma unroll
+                for (int hf = 0; hf <= KB; ++hf) { Fzp[hf] = fmaxf(0.f, Fz[hf]); Fzm[hf] = fminf(0.f, Fz[hf]); }
                 auto betaz = [&](const int kk) {
                     const int h = kk + 1;
-                    const float qc = q2P[h], FzB = Fz[h - 1];
-                    float FzT = Fz[h];
+                    const float qc = q2P[h];
+                    float FzTp = Fzp[h], FzTm = Fzm[h];
                     const float mlo = (kk > 0) ? sP.m[kk - 1] : sP.mh0, nlo = (kk > 0) ? sP.n[kk - 1] : sP.nh0;
                     float mhi = (kk < KB - 1) ? sP.m[kk + 1] : sP.mh1, nhi = (kk < KB - 1) ? sP.n[kk + 1] : sP.nh1;
                     float mc = sP.m[kk], nc = sP.n[kk];
@@ -487,10 +524,10 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                     // last cell of the column: extrema without l(n) and without a cell above, fin = fout = |FzB|
                     if (EXACT ? (h == KB) : true) {
                         const bool tp = EXACT ? topwave : (h >= htop);
-                        mc = tp ? qc : mc; nc = tp ? qc : nc; mhi = tp ? qc : mhi; nhi = tp ? qc : nhi; FzT = tp ? FzB : FzT;
+                        mc = tp ? qc : mc; nc = tp ? qc : nc; mhi = tp ? qc : mhi; nhi = tp ? qc : nhi; FzTp = tp ? Fzp[h - 1] : FzTp; FzTm = tp ? Fzm[h - 1] : FzTm;
                     }
                     const float qmax = max3f(mlo, mc, mhi), qmin = min3f(nlo, nc, nhi);
-                    const float fin = fmaxf(0.f, FzB) - fminf(0.f, FzT), fout = fmaxf(0.f, FzT) - fminf(0.f, FzB);
+                    const float fin = Fzp[h - 1] - FzTm, fout = FzTp - Fzm[h - 1];
                     bZin[h] = (qmax - qc) * frcp(fin + EPSF); bZout[h] = (qc - qmin) * frcp(fout + EPSF);
                 };
                 betaz(0);                                          // the edge cells first: their betas are what the neighbouring waves wait for
@@ -525,30 +562,14 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         {
             const int o2 = (STEADY ? P + 2 : CLAMPJ(P + 2)) * sj4, o3 = (STEADY ? P + 3 : CLAMPJ(P + 3)) * sj4;
             ISSUE_LOADS_A(o2, o3)
+            // 1 / (jaco rho), 1 / (jaco rho dz) of plane P for the update at the end of this step: requested here, not with the
+            // z coefficients -- ten registers less across the x / z limiter
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) { rdhP[kk] = LDC(MPC_RDH, kk + 1, oP); rdvP[kk] = LDC(MPC_RDV, kk + 1, oP); }
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        // ================= S4: beta_y of plane P ; S5: limited y face (P-1/2) =================
-        // parked by the step before: per level {mM nM v2S FyS} {bYinM bYoutM acc rdhM} -- extrema of plane M; pseudo-velocity /
-        // unlimited flux of the y face (P-1/2); beta_y of plane M; q2 - x/z/south contributions of plane M; its 1 / (jaco rho)
-        float bYin[KB], bYout[KB], FyLimS[KB], outM[KB];
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            const int h = kk + 1;
-            const float4 pa = s_park[NA4 + 2 * kk][tid], pb = s_park[NA4 + 2 * kk + 1][tid];
-            const float mM = pa.x, nM = pa.y, v2S = pa.z, FyS = pa.w, bYinM = pb.x, bYoutM = pb.y, acc = pb.z, rdhM = pb.w;
-            if (FCT) {
-                const float qc = q2P[h];
-                float qmax = max3f(mM, sP.m[kk], sN.m[kk]), qmin = min3f(nM, sP.n[kk], sN.n[kk]);
-                float fin = fmaxf(0.f, FyS) - fminf(0.f, FyN[kk]), fout = fmaxf(0.f, FyN[kk]) - fminf(0.f, FyS);
-                if (!STEADY && P <= 0) { qmax = fmaxf(sP.m[kk], sN.m[kk]); qmin = fminf(sP.n[kk], sN.n[kk]); fin = 0.f; fout = 0.f; }
-                if (!STEADY && P >= ny - 1) { qmax = fmaxf(mM, qc); qmin = fminf(nM, qc); fin = 0.f; fout = 0.f; }
-                bYin[kk] = (qmax - qc) * frcp(fin + EPSF); bYout[kk] = (qc - qmin) * frcp(fout + EPSF);
-                const float s = fminf(1.0f, (v2S > 0.0f) ? fminf(bYin[kk], bYoutM) : fminf(bYinM, bYout[kk]));
-                FyLimS[kk] = s * FyS;
-            } else { bYin[kk] = bYout[kk] = 0.f; FyLimS[kk] = FyS; }
-            outM[kk] = acc - FyLimS[kk] * rdhM;                    // plane M is complete (ring cells: rdh = 0, acc = q)
-        }
+        ylim();
 
         // ================= S6: store plane M =================
         const int M = P - 1;
@@ -669,7 +690,12 @@ int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, co
     nchunk = (rows + clen - 1) / clen;
     const bool exact = (nkr == 1) && (kb * nw == nz);          // the waves hold exactly the column: no per-slot level tests
 #define KBCASE(K) case K: launch_fused<K>(c, fct, pass1, exact, in, out, nv, nw, clen, ntile, nchunk, nkr, kstore); break;
-    switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) default: icar_set_error("mpdata: internal level-range error"); return 1; }
+#ifdef MPX_DEV_KB5
+    switch (kb) { KBCASE(5) default:
+#else
+    switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) default:
+#endif
+        icar_set_error("mpdata: internal level-range error"); return 1; }
 #undef KBCASE
     HIPCHK(hipGetLastError());
     return 0;
