@@ -82,7 +82,7 @@ def build_tile(args, rank, world, device):
 ADVECT_KERNELS = {"mpdata": "k_mpdata_fused", "upwind": "k_upwind_pass"}
 SETUP_KERNELS = ("k_setup_winds", "k_mpdata_coef")      # launched once per step for the advect() call (timer group "winds")
 # bumped whenever the advection kernels change what they read or write: profiles/advect_traffic.json (PMC passes) belongs to one
-KERNEL_GENERATION = "r03: scalar-independent MPDATA coefficients precomputed (k_mpdata_coef)"
+KERNEL_GENERATION = "r05: branch-free paired steady steps, ring cells through zero coefficients (k_mpdata_fused + k_mpdata_coef)"
 
 FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
 
@@ -99,77 +99,20 @@ def run_steps(d, opt, n):
     return step_n(d, n, opt, forced=FORCED)
 
 
-def cpu_reference(args, domain, nscalars):
-    """The UNMODIFIED reference kernels (oracle/_ref: adv_mpdata.f90 + mp_thompson.f90 / mp_simple.f90 compiled by
-    oracle/build_ref.sh, no OpenMP -> one core) timed on one step of the same tile size as the GPU line.  Informational, next
-    to cpu_baseline (the OpenMP port that is bit-identical to them).  Thompson's tables are read from the .dat caches
-    the device tables were written to (byte-identical to the reference's own, tests/test_gpu_thompson.py), which skips
-    the reference's 56 s single-core table build.  Runs in a child process: the Fortran runtime writes to stdout."""
+def cpu_reference(args, nscalars):
+    """The UNMODIFIED reference kernels (adv_mpdata.f90 + mp_thompson.f90 compiled by oracle/build_ref.sh, flang -O2, one core)
+    on one step of this workload -- RECORDED, not run here: the compiled reference can only be rebuilt where /root/reference
+    exists, so it is timed in the build container (profiles/measure_cpu_reference.py -> profiles/cpu_reference.json, with the CPU it
+    ran on) and attached when the record is of this configuration.  Informational, next to cpu_baseline, which IS timed live on
+    this box's host cores (the OpenMP restatement that is bit-identical to those kernels)."""
     try:
-        from oracle import ref
-        if not ref.available():
+        rec = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference.json")))
+        want = {"nx": args.nx, "ny": args.ny, "nz": args.nz, "adv": args.adv, "mp": args.mp, "nscalars": nscalars}
+        if rec.get("config") != want:
             return None
-        import subprocess, tempfile
-        tmp = tempfile.mkdtemp(prefix="icar_ref_tables_")
-        if args.mp == "thompson":
-            from icar_amd.thompson_cache import write_caches
-            write_caches(domain, tmp)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--ref-child", tmp, "--adv", args.adv, "--mp", args.mp,
-                            "--nx", str(args.nx), "--ny", str(args.ny), "--nz", str(args.nz), "--hill", str(args.hill), "--ref-nscal", str(nscalars)],
-                           capture_output=True, text=True, timeout=600, preexec_fn=_unlimited_stack)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
-    except Exception as e:  # pragma: no cover
-        return {"value": None, "unit": "grid-cell updates/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
-
-
-def _unlimited_stack():
-    # adv_mpdata.f90:365-368 keeps four full-grid temporaries on the stack (42 MB at 256x256x40): the reference needs
-    # `ulimit -s unlimited` like any ICAR run
-    import resource
-    hard = resource.getrlimit(resource.RLIMIT_STACK)[1]
-    resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
-
-
-def ref_child(args):
-    from oracle import ref
-    from icar_amd import ideal
-    nscalars = args.ref_nscal
-    nx, ny, nz = args.nx, args.ny, args.nz             # the SAME tile size as the GPU line
-    c = ideal.make_case(nx, ny, nz, hill_height=args.hill, noise=0.01, n_hydro=1)
-    c["water_vapor"] = (c["water_vapor"] * np.float32(1.4)).astype(np.float32)
-    dt = min(ideal.cfl_dt(c), 120.0)
-    names = ["water_vapor", "cloud_water", "rain", "snow", "potential_temperature", "cloud_ice", "graupel",
-             "ice_number", "rain_number"][:nscalars]
-    q = np.stack([c[n] for n in names]).copy()
-    z2 = lambda: np.zeros((ny, nx), np.float32)
-    if args.mp == "thompson":
-        ref.thompson_init(workdir=args.ref_child)
-    if args.mp == "wsm3":
-        ref.wsm3_init()
-    if args.mp == "wsm6":
-        ref.wsm6_init()
-    acc = [z2() for _ in range(5)]
-    t0 = time.perf_counter()
-    if args.mp == "thompson":
-        ref.thompson(c["water_vapor"], c["cloud_water"], c["rain"], c["cloud_ice"], c["snow"], c["graupel"], c["ice_number"],
-                     c["rain_number"], c["potential_temperature"], c["exner"], c["pressure"], c["dz_mass"], dt, *acc,
-                     1, nx, 1, ny, 1, nz, 2, nx - 1, 2, ny - 1, 1, nz)
-    elif args.mp == "simple":
-        ref.mp_simple(c["pressure"], c["potential_temperature"], c["exner"], c["density"], c["water_vapor"], c["cloud_water"],
-                      c["rain"], c["snow"], acc[0], acc[1], dt, c["dz_mass"], 2, nx - 1, 2, ny - 1, 1, nz)
-    elif args.mp == "wsm3":
-        ref.wsm3(c["potential_temperature"], c["water_vapor"], c["cloud_water"], c["rain"], c["w"], c["density"], c["exner"], c["pressure"],
-                 c["dz_mass"], dt, *acc, 2, nx - 1, 2, ny - 1, 1, nz)
-    elif args.mp == "wsm6":
-        ref.wsm6(c["potential_temperature"], c["water_vapor"], c["cloud_water"], c["rain"], c["cloud_ice"], c["snow"], c["graupel"], c["density"],
-                 c["exner"], c["pressure"], c["dz_mass"], dt, *acc, 2, nx - 1, 2, ny - 1, 1, nz)
-    ref.advect(1 if args.adv == "upwind" else 2, q, c["u"], c["v"], c["w"], c["density"], c["jacobian"], c["jacobian_u"],
-               c["jacobian_v"], c["jacobian_w"], c["advection_dz"], c["dz_levels"], float(c["dx"]), dt)
-    el = time.perf_counter() - t0
-    print("\n" + json.dumps({"value": (nx - 2) * (ny - 2) * nz / el, "unit": "grid-cell updates/s", "cores": 1, "kind": "reference",
-                             "sample": f"1 step of {nx}x{ny}x{nz}, the reference's own {args.adv} + {args.mp} kernels compiled unmodified "
-                                       f"(flang -O2, no OpenMP), {el:.1f} s"}), flush=True)
+        return {k: rec[k] for k in ("value", "unit", "cores", "kind", "where", "sample", "recorded")}
+    except Exception:
+        return None
 
 
 def usable_cpus():
@@ -335,15 +278,9 @@ def main():
     ap.add_argument("--no-later-window", action="store_true", help="skip the second (untimed-region) window 100 steps later")
     ap.add_argument("--no-traffic-probe", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--no-kernel-timers", action="store_true", help="profiling: leave the library's per-group HIP-event timers off (roofline.avg_ms is then 0)")
-    ap.add_argument("--thompson-layout", type=int, default=0, choices=[0, 1, 2, 3],
-                    help="profiling: thread layout of the Thompson interior launch (icar_hip_thompson_layout; 0 = the library's default)")
     ap.add_argument("--mpdata-exact", action="store_true",
                     help="advect with icar_hip_mpdata_exact(ctx, 1): MPDATA in the reference's operation order, bit-identical to the CPU reference")
-    ap.add_argument("--ref-child", default=None, help=argparse.SUPPRESS)      # internal: cpu_reference()'s child process
-    ap.add_argument("--ref-nscal", type=int, default=9, help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.ref_child is not None:
-        return ref_child(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
@@ -379,10 +316,6 @@ def main():
     lib = capi.lib()
     if args.mpdata_exact:
         capi.check(lib.icar_hip_mpdata_exact(d.ctx, 1), "icar_hip_mpdata_exact")
-    if os.environ.get("ICAR_BENCH_GRAPH") == "1":       # profiling A/B (profiles/micro/graph_ab.sh): sub-steps as hipGraph replays with dt in device memory
-        capi.check(lib.icar_hip_graph_mode(d.ctx, 1), "icar_hip_graph_mode")
-    if args.thompson_layout:
-        capi.check(lib.icar_hip_thompson_layout(d.ctx, args.thompson_layout), "icar_hip_thompson_layout")
     kind = int(lib.icar_hip_comm_kind(d.ctx))
     nscal = sum(1 for v in opt.vars_to_advect.values() if v > 0)
 
@@ -437,9 +370,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    nrep = ctypes.c_longlong(0)
-    lib.icar_hip_graph_replays(d.ctx, ctypes.byref(nrep))
-    graph_replays = int(nrep.value)           # sub-steps this rank launched as hipGraph replays so far (warm-up + timed + diagnostic window)
     own_cells = (g.ite - g.its + 1) * (g.jte - g.jts + 1) * args.nz
     cells_t = torch.tensor([float(own_cells)], dtype=torch.float64, device=red_device)
     if world > 1:
@@ -530,7 +460,7 @@ def main():
                        "halo": ("one ncclSend/ncclRecv group per step issued by the library (icar_hip_halo_send)" if kind == capi.COMM_RCCL else
                                 "one message per neighbour through pinned host memory (icar_hip_comm_init_host)") + ", strips+pack on the second stream beside the interior mp" if world > 1
                                else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips+pack on the second stream beside the interior mp",
-                       "ranks_seen": ranks_seen, "halo_check": halo_check, "graph_replays": graph_replays,
+                       "ranks_seen": ranks_seen, "halo_check": halo_check,
                        # what the timed path computes: the microphysics, diagnostics, forcing and halos bit-identical to the CPU reference;
                        # MPDATA either the fused kernel (every cell within 1e-5 of the local field scale per step, measured <= 3e-6) or,
                        # with --mpdata-exact, the reference's operation order (bit-identical; tests/test_gpu_trajectory.py)
@@ -571,7 +501,7 @@ def main():
                                                           "3-step child runs of this configuration, mean per dispatch of " + ADVECT_KERNELS[args.adv]})
         if not args.no_cpu_baseline and world == 1:          # the CPU legs are timed at N=1 only (the other ranks would idle at the barrier)
             out["cpu_baseline"] = cpu_baseline(args, nscal)
-            r = cpu_reference(args, d, nscal)
+            r = cpu_reference(args, nscal)
             if r is not None:
                 out["cpu_reference"] = r
         print(json.dumps(out), flush=True)

@@ -14,12 +14,17 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicar_hip.so")
 SOURCES = ["capi.hip", "advect.hip", "mpdata.hip", "mpdata_exact.hip", "mp_simple.hip", "mp_thompson.hip", "thompson_tables.hip", "step.hip", "linear_winds.hip", "iterative_winds.hip", "mp_wsm3.hip", "mp_wsm6.hip", "comm.hip", "timestep.hip"]
-NO_SCRATCH = {"mp_thompson.hip": ["k_thompson_march"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # finite data only: drop the NaN-canonicalisation v_max x,x,x in front of every fmin/fmax (no effect on finite results)
 PER_FILE_FLAGS = {"advect.hip": ["-fno-honor-nans"],
                   # the fused MPDATA kernel is held to the 1e-5 tolerance, not to bit equality: fma contraction allowed
-                  "mpdata.hip": ["-fno-honor-nans", "-ffp-contract=fast", "-fno-slp-vectorize"]}
+                  # ... and no SLP packing: the vectoriser's v_pk_add / mul / fma_f32 pairs are assembled with more v_mov than they
+                  # save (profiles/r05_steps.md)
+                  "mpdata.hip": ["-fno-honor-nans", "-ffp-contract=fast", "-fno-slp-vectorize"],
+                  # k_thompson_pack runs at 4 waves per SIMD with ~50 VGPRs in scratch.  The one miscompile seen in this code (round 4,
+                  # a since-removed kernel) needed SGPRs spilled into VGPR lanes on top of VGPR spills: SGPR spills, should a compiler
+                  # ever produce them here, go to memory instead
+                  "mp_thompson.hip": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=false"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",     # (a later -ffp-contract wins)
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -43,16 +48,13 @@ def build(force=False, verbose=False):
             cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            if s in NO_SCRATCH:
-                # kernels that must not spill (see the comment at k_thompson_march): read the compiler's own resource report
-                rep = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], check=True, capture_output=True, text=True).stderr
-                for kern in NO_SCRATCH[s]:
-                    blocks = [b for b in rep.split("Function Name: ")[1:] if kern in b.split("\n")[0] and "remark" in b]
-                    if not blocks or any("ScratchSize [bytes/lane]: 0" not in b for b in blocks):
-                        os.remove(obj)                    # (a later build() must not take the object for up to date)
-                        raise RuntimeError(f"{s}: {kern} must compile without scratch")
-            else:
-                subprocess.check_call(cmd)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.stderr.strip():
+                sys.stderr.write(r.stderr)                # warnings of every file, and the diagnostics of a failed compile
+            if r.returncode != 0:
+                if os.path.exists(obj):
+                    os.remove(obj)                        # (a later build() must not take the object for up to date)
+                raise RuntimeError(f"{s}: hipcc failed with status {r.returncode} (diagnostics above)")
         objs.append(obj)
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrocfft", "-ldl", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]

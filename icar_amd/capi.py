@@ -18,7 +18,7 @@ SYMBOLS = [
     "icar_hip_aux_fork", "icar_hip_aux_begin", "icar_hip_aux_end", "icar_hip_aux_join", "icar_hip_max_courant_device",
     "icar_hip_field_upload", "icar_hip_field_download", "icar_hip_field_fill", "icar_hip_field_device_ptr",
     "icar_hip_field_count", "icar_hip_field_elem_size", "icar_hip_setup_winds", "icar_hip_advect",
-    "icar_hip_mpdata_exact", "icar_hip_substep_graph_probe", "icar_hip_graph_mode", "icar_hip_graph_replays", "icar_hip_mp_simple", "icar_hip_mp_simple_tiles", "icar_hip_thompson_init", "icar_hip_thompson", "icar_hip_thompson_tiles", "icar_hip_thompson_layout", "icar_hip_thompson_table", "icar_hip_thompson_dec_index", "icar_hip_thompson_math_probe", "icar_hip_mp_tiles",
+    "icar_hip_mpdata_exact", "icar_hip_mp_simple", "icar_hip_mp_simple_tiles", "icar_hip_thompson_init", "icar_hip_thompson", "icar_hip_thompson_tiles", "icar_hip_thompson_table", "icar_hip_mp_tiles",
     "icar_hip_wsm3_init", "icar_hip_wsm3", "icar_hip_wsm6_init", "icar_hip_wsm6", "icar_hip_wsm6_tiles", "icar_hip_winds_valid", "icar_hip_max_courant", "icar_hip_max_courant_prefetch", "icar_hip_max_abs_winds", "icar_hip_balance_uvw", "icar_hip_balance_uvw_update", "icar_hip_make_winds_grid_relative", "icar_hip_mass_conservative_acceleration", "icar_hip_update_winds", "icar_hip_exchange_uv", "icar_hip_iterative_winds_correct_w", "icar_hip_iterative_winds_sweep", "icar_hip_box_pack", "icar_hip_box_unpack", "icar_hip_dqdt_download", "icar_hip_diagnostic_update", "icar_hip_diagnostic_update_parts", "icar_hip_dqdt_upload",
     "icar_hip_apply_forcing", "icar_hip_enforce_limits", "icar_hip_halo_count", "icar_hip_halo_pack",
     "icar_hip_halo_unpack", "icar_hip_halo_pack_dirs", "icar_hip_halo_unpack_dirs", "icar_hip_timing_enable", "icar_hip_timing_groups", "icar_hip_timing_read", "icar_hip_timing_reset",
@@ -87,7 +87,6 @@ def lib():
         L.icar_hip_substep.argtypes = [vp, cd, ci]
         L.icar_hip_step.argtypes = [vp, cd, ctypes.POINTER(ci)]
         L.icar_hip_step_n.argtypes = [vp, ci, ctypes.POINTER(cd)]
-        L.icar_hip_substep_graph_probe.argtypes = [vp, cd, ci, ctypes.POINTER(cd), ctypes.POINTER(cd)]
         L.icar_hip_update_dt.argtypes = [vp, ctypes.POINTER(cd)]
         L.icar_hip_compute_dt.argtypes = [vp, ctypes.POINTER(cd)]
         L.icar_hip_co_min.argtypes = [vp, ctypes.POINTER(cd)]

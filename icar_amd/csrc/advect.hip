@@ -51,9 +51,8 @@ __global__ void __launch_bounds__(BX * BY)
 k_setup_winds(Dims d, const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
               const float *__restrict__ rho, const float *__restrict__ ju, const float *__restrict__ jv,
               const float *__restrict__ jw, const float *__restrict__ dz, float dt, float dx,
-              float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float *__restrict__ Wdz, const IcarDtBlock *__restrict__ blk)
+              float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float *__restrict__ Wdz)
 {
-    if (blk) dt = blk->dt_f;                        // graph replay: this step's dt lives in device memory (timestep.hip)
     const TileId tb = xcd_tile(4);
     const int i = tb.x * BX + threadIdx.x;
     const int k = tb.y * BY + threadIdx.y;
@@ -171,7 +170,7 @@ int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int
     if (!u || !v || !w || !ju || !jv || !jw || !dz || (advect_density && !rho)) return 1;
     ScopedTimer t(c, "winds");
     dim3 g = grid3(c->d), b(BX, BY);
-#define LAUNCH(S, R) hipLaunchKernelGGL((k_setup_winds<S, R>), g, b, 0, c->stream, c->d, u, v, w, rho, ju, jv, jw, dz, dt, dx, c->U, c->V, c->W, c->Wdz, c->dt_dev)
+#define LAUNCH(S, R) hipLaunchKernelGGL((k_setup_winds<S, R>), g, b, 0, c->stream, c->d, u, v, w, rho, ju, jv, jw, dz, dt, dx, c->U, c->V, c->W, c->Wdz)
     if (scheme == 1) { if (advect_density) LAUNCH(1, true); else LAUNCH(1, false); }
     else             { if (advect_density) LAUNCH(2, true); else LAUNCH(2, false); }
 #undef LAUNCH

@@ -303,7 +303,7 @@ bool icar_cfl_prefetched_global(icar_hip_ctx *c, float dx, const float *dz_level
     c->cfl_pre.valid = false;
     // (a failed wait is an error of this image alone; falling back to a fresh reduction here would issue an all-reduce the other
     // images do not pair -- the value is handed out as NaN and compute_dt reports it)
-    if (hipEventSynchronize(c->cfl_ev) != hipSuccess) { *value = __builtin_nanf(""); return true; }
+    if (hipEventSynchronize(c->cfl_ev) != hipSuccess) { *value = __builtin_nanf(""); c->cfl_wait_failed = true; return true; }
     *value = *c->h_cfl_pre;
     return true;
 }
@@ -317,10 +317,8 @@ int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_lev
     if (!c->h_cfl_pre) { HIPCHK(hipHostMalloc((void **)&c->h_cfl_pre, sizeof(float), hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&c->cfl_ev, hipEventDisableTiming)); }
     if (icar_max_courant_run(c, dx, dz_levels, nullptr, c->d_red + 8)) return 1;             // on the current stream, nothing waits
     if (allreduce && icar_comm_max_device(c, c->d_red + 8) != 0) return 1;
-    if (!c->dt_dev) {               // (inside a captured sub-step the device reads the maximum itself; the host's copy follows the last replay)
-        HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
-    }
+    HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
     c->cfl_pre.reduced = allreduce;
     c->cfl_pre.valid = true; c->cfl_pre.ver = c->wind_version; c->cfl_pre.dx = dx; c->cfl_pre.dzl.assign(dz_levels, dz_levels + c->d.nz);
     return 0;
@@ -457,7 +455,6 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     if (c->h_cfl_pre) hipHostFree(c->h_cfl_pre);
     if (c->cfl_ev) hipEventDestroy(c->cfl_ev);
     if (c->iw_adj) hipFree(c->iw_adj);
-    if (c->th_ws) hipFree(c->th_ws);
     if (c->wgr_tmp) hipFree(c->wgr_tmp);
     icar_wsm3_free(c);
     icar_wsm6_free(c);
@@ -465,11 +462,6 @@ int icar_hip_ctx_destroy(icar_hip_ctx *c)
     icar_linwinds_free(c);
     icar_comm_free(c);
     if (c->step.h_val) hipHostFree(c->step.h_val);
-    icar_graph_invalidate(c);
-    if (c->step.dtblk) hipFree(c->step.dtblk);
-    if (c->step.dt_ring) hipFree(c->step.dt_ring);
-    if (c->step.h_dtblk) hipHostFree(c->step.h_dtblk);
-    if (c->step.h_dt_ring) hipHostFree(c->step.h_dt_ring);
     if (c->on_aux) c->stream = c->main_saved;
     if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -576,21 +568,6 @@ int icar_hip_mpdata_exact(icar_hip_ctx *c, int on)
     return 0;
 }
 
-int icar_hip_graph_mode(icar_hip_ctx *c, int on)
-{
-    if (!c || (on != 0 && on != 1)) { icar_set_error("graph_mode: ctx and on = 0 / 1"); return 1; }
-    c->graph_mode = on;
-    if (!on) icar_graph_invalidate(c);
-    return 0;
-}
-
-int icar_hip_graph_replays(icar_hip_ctx *c, long long *n)
-{
-    if (!c || !n) { icar_set_error("graph_replays: null argument"); return 1; }
-    *n = c->graph_launches;
-    return 0;
-}
-
 int icar_hip_mp_simple(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err_count)
 {
     if (!c) { icar_set_error("null ctx"); return 1; }
@@ -626,27 +603,6 @@ int icar_hip_thompson_tiles(icar_hip_ctx *c, float dt, int ntiles, const int til
     if (!c || !tiles) { icar_set_error("thompson_tiles: null argument"); return 1; }
     HIPCHK(hipSetDevice(c->device));
     return icar_thompson_run_tiles(c, dt, ntiles, tiles, kts, kte, ids, ide, jds, jde, kds, kde);
-}
-
-int icar_hip_thompson_layout(icar_hip_ctx *c, int layout)
-{
-    if (!c || layout < 0 || layout > 3) { icar_set_error("thompson_layout: ctx and layout in 0..3"); return 1; }
-    c->th_layout = layout;
-    return 0;
-}
-
-int icar_hip_thompson_dec_index(icar_hip_ctx *c, const float *r4, const double *r8, int n, int n2, int which, int *out)
-{
-    if (!c || !out || (!r4 && !r8) || (r4 && r8)) { icar_set_error("thompson_dec_index: exactly one of r4 / r8, and out"); return 1; }
-    HIPCHK(hipSetDevice(c->device));
-    return icar_thompson_dec_index_run(c, r4, r8, n, n2, which ? 1 : 0, out);
-}
-
-int icar_hip_thompson_math_probe(icar_hip_ctx *c, int op, int n, const double *x, const double *y, double *out)
-{
-    if (!c || !x || !out) { icar_set_error("thompson_math_probe: ctx, x and out are required"); return 1; }
-    HIPCHK(hipSetDevice(c->device));
-    return icar_thompson_math_probe_run(c, op, n, x, y, out);
 }
 
 int icar_hip_thompson_table(icar_hip_ctx *c, const char *name, double *out, size_t capacity, size_t *count)

@@ -29,10 +29,6 @@ struct IcarComm;         // comm.hip
 
 // state of the step driver (timestep.hip): the options / grid members the sub-step loop reads, the model clock, and what
 // mp_driver.f90 keeps in SAVE variables (last_model_time)
-// dt in device memory (graph replays of the sub-step, timestep.hip): written by k_dt_update at the head of a captured sub-step,
-// read by the three kernels that take dt (k_setup_winds, the Thompson launch, k_apply_forcing) when their `blk` argument is set
-struct IcarDtBlock { double time, mp_last, dt_d; float dt_f, mp_dt; int err, n; };
-struct IcarGraphSlot { hipGraphExec_t exec = nullptr; const void *key = nullptr; };
 
 struct IcarStepState {
     bool configured = false;
@@ -43,11 +39,6 @@ struct IcarStepState {
     int winds_scheme = 0, winds_dens = 0; float winds_dt = 0.f;   // what the Courant winds on the device were set up for
     float *h_val = nullptr;                  // pinned: the reduced CFL maximum
     bool early_open = false, early_wreal = false, early_face = false;   // a sub-step whose dt-independent opening is already in flight
-    // hipGraph replay of the sub-step inside icar_hip_step_n (one image; timestep.hip)
-    IcarDtBlock *dtblk = nullptr, *h_dtblk = nullptr;      // device block, pinned host copy
-    double *dt_ring = nullptr, *h_dt_ring = nullptr;       // dt of every replayed sub-step (device, pinned host)
-    IcarGraphSlot graph[2];                                // one executable per parity of the advected scalars' ping-pong buffers
-    std::vector<unsigned char> graph_stamp;                // the configuration the executables were captured for
     bool winds_first = true;                 // wind.f90:297 `.not. allocated(domain%sintheta)`: update_winds has not run yet
 };
 
@@ -62,10 +53,6 @@ struct icar_hip_ctx {
     hipStream_t aux = nullptr, main_saved = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool on_aux = false;
-    const IcarDtBlock *dt_dev = nullptr;  // non-null while a sub-step is being captured: kernels that take dt read it from here
-    bool dt_bad = false;                 // a launch that cannot read dt from device memory happened during the capture
-    int graph_mode = 0;                  // icar_hip_graph_mode (off by default: measured equal to the eager loop, profiles/r04_steps.md)
-    long long graph_launches = 0;        // sub-steps launched as graph replays so far (icar_hip_graph_replays)
     void *field[ICAR_N_FIELDS] = {nullptr};
     float *dqdt[ICAR_N_FIELDS] = {nullptr};    // variable_t%dqdt_3d mirrors (apply_forcing)
     // advection scratch (A1-A5)
@@ -83,6 +70,7 @@ struct icar_hip_ctx {
     bool wind_ptr_escaped = false;
     struct { bool valid = false, reduced = false; unsigned long long ver = 0; float dx = 0.f; std::vector<float> dzl; } cfl_pre;
     float *h_cfl_pre = nullptr;          // pinned host copy of the prefetched maximum (d_red[8] on the device)
+    bool cfl_wait_failed = false;        // the wait for that copy failed (compute_dt reports it; a NaN maximum otherwise means NaN winds)
     hipEvent_t cfl_ev = nullptr;
     float *iw_adj = nullptr;             // iterative_winds ADJ scratch (iterative_winds.hip)
     float *wgr_tmp = nullptr;            // make_winds_grid_relative: rotated mass-grid u | v (2 x n3)
@@ -91,8 +79,6 @@ struct icar_hip_ctx {
     std::vector<float> dzl_host;         // dz_levels last uploaded behind d_red (compute_dt re-sends them only when they change)
     int *d_flag = nullptr;
     ThompsonTables *thompson = nullptr;
-    float *th_ws = nullptr; size_t th_ws_floats = 0;   // k_thompson_march: ThHand of every cell between its two sweeps (mp_thompson.hip)
-    int th_layout = 0;                   // 0 / 1 = one level per thread, 2 = one column per lane (icar_hip_thompson_layout)
     LinWinds *linwinds = nullptr;
     Wsm3State *wsm3 = nullptr;
     Wsm6State *wsm6 = nullptr;
@@ -141,11 +127,8 @@ int icar_make_winds_grid_relative(icar_hip_ctx *c, int update);
 int icar_box_copy(icar_hip_ctx *c, int field, int which, int i0, int ni, int j0, int nj, float *buf, bool unpack);
 enum { ICAR_DIAG_CELL = 4, ICAR_DIAG_FACE = 8 };     // finer parts of icar_diagnostic_update_run (step.hip), internal
 int icar_diagnostic_update_run(icar_hip_ctx *c, int parts);
-int icar_thompson_math_probe_run(icar_hip_ctx *c, int op, int n, const double *x, const double *y, double *out);
-int icar_thompson_dec_index_run(icar_hip_ctx *c, const float *rf, const double *rd, int n, int n2, int which, int *out);
 int icar_max_courant_prefetch_run(icar_hip_ctx *c, float dx, const float *dz_levels, bool allreduce);
 bool icar_cfl_prefetched_global(icar_hip_ctx *c, float dx, const float *dz_levels, float *value);
-void icar_graph_invalidate(icar_hip_ctx *c);                           // timestep.hip: drop the captured sub-steps
 bool icar_cfl_prefetch_waiting(icar_hip_ctx *c);      // a prefetched CFL maximum of the current winds is waiting for update_dt
 inline void icar_winds_changed(icar_hip_ctx *c) { c->winds_valid = false; ++c->wind_version; }   // u, v, w (or density / jacobians) rewritten
 int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const int *fb, int n, int w, int e, int s, int nn);

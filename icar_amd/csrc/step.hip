@@ -146,9 +146,8 @@ k_diag_columns(Dims d, ColumnArgs a)
 struct ForceArgs { float *x[16]; const float *dq[16]; int stag[16]; int fb[16]; };
 
 __global__ void __launch_bounds__(256)
-k_apply_forcing(Dims d, ForceArgs a, double dt, int west, int east, int south, int north, const IcarDtBlock *__restrict__ blk)
+k_apply_forcing(Dims d, ForceArgs a, double dt, int west, int east, int south, int north)
 {
-    if (blk) dt = blk->dt_d;                        // graph replay: this step's dt lives in device memory (timestep.hip)
     const int m = blockIdx.z;
     const int nxm = d.nx + (a.stag[m] == 1), nym = d.ny + (a.stag[m] == 2);
     float *__restrict__ x = a.x[m];
@@ -265,7 +264,7 @@ int icar_apply_forcing_run(icar_hip_ctx *c, double dt, const int *fields, const 
     }
     ScopedTimer t(c, "forcing");
     dim3 g(2048, 1, n), b(256);
-    hipLaunchKernelGGL(k_apply_forcing, g, b, 0, c->stream, c->d, a, dt, w, e, s, nn, c->dt_dev);
+    hipLaunchKernelGGL(k_apply_forcing, g, b, 0, c->stream, c->d, a, dt, w, e, s, nn);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -48,7 +48,6 @@ int icar_mp_run(icar_hip_ctx *c, double dt_in, int halo, int subset)
 {
     const icar_hip_step_config &g = c->step.cfg;
     if (g.microphysics == 0) return 0;
-    if (c->dt_dev && g.microphysics != kMP_THOMPSON) c->dt_bad = true;          // (only the Thompson launch reads dt from device memory)
     IcarStepState &st = c->step;
     // the reference passes real(dt%seconds()) -- a REAL(4) -- into this arithmetic (time_step.f90:512, mp_driver.f90:673)
     const double dt4 = (double)(float)dt_in;
@@ -146,7 +145,11 @@ static int compute_dt(icar_hip_ctx *c, float *dt_out, bool *on_device)
             maxwind3d = fmaxf(maxwind1d, maxwind3d);
         } else if (strict == 4) maxwind3d = maxwind3d * sqrt3;                                                  // :302-305
     }
-    if (!(maxwind3d == maxwind3d)) { icar_set_error("compute_dt: the prefetched CFL maximum could not be read (HIP event wait failed)"); return 1; }
+    if (!(maxwind3d == maxwind3d)) {
+        if (c->cfl_wait_failed) { c->cfl_wait_failed = false; icar_set_error("compute_dt: the prefetched CFL maximum could not be read (HIP event wait failed)"); }
+        else icar_set_error("compute_dt: the CFL maximum is NaN (the winds contain NaN)");
+        return 1;
+    }
     const float dt = g.cfl_reduction_factor / maxwind3d;                                                       // :313
     if (dt < 1e-1f) { icar_set_error("ERROR time step too small"); return 1; }                                 // :322-328 `stop`
     *dt_out = dt;
@@ -225,6 +228,15 @@ int icar_substep_open_early(icar_hip_ctx *c)
     if (substep_open(c, 0.0, false, wl, fl)) return 1;
     c->step.early_open = true; c->step.early_wreal = wl; c->step.early_face = fl;
     return 0;
+}
+
+// update_dt failed after the opening of the sub-step was issued (time step too small, a transport timeout): join the second
+// stream and forget the opening, so that the next call on this context does not continue a half-issued sub-step
+static int update_dt_opened(icar_hip_ctx *c, double *dt)
+{
+    if (icar_update_dt(c, dt) == 0) return 0;
+    if (c->step.early_open) { (void)icar_hip_aux_join(c); c->step.early_open = false; }
+    return 1;
 }
 
 int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
@@ -460,139 +472,6 @@ int icar_hip_substep(icar_hip_ctx *c, double dt_seconds, int enforce_limits)
     return icar_substep(c, dt_seconds, enforce_limits != 0);
 }
 
-// ---- hipGraph replay of the sub-step (one image) ------------------------------------------------------------------------
-// A captured graph fixes every by-value kernel argument, and the loop's dt changes from step to step.  So dt moves to device
-// memory: k_dt_update, the first node of a captured sub-step, turns the CFL maximum the previous sub-step left reducing beside its
-// advection into dt -- compute_dt's REAL(4) operations and update_dt's cap, on the device -- and keeps the model clock the
-// microphysics' own time step comes from (mp_driver.f90:708); the three kernels that take dt read it from there.  Two executables
-// (the advected scalars ping-pong between two buffers: kernel arguments repeat with period 2) then serve any sequence of dt, and
-// icar_hip_step_n launches them back to back with nothing of the host in between; the dt of every sub-step comes back afterwards
-// for the model clock.  Measured before it was built (icar_hip_substep_graph_probe): 3.6 % (512 x 512 x 40) to 5.6 % (258 x 130 x
-// 40) per sub-step against the eager launches.  Not with neighbouring images (the transports are not captured), not with the
-// group timers on, cfl_strictness 3 / 4 only (the prefetched reduction), Thompson or no microphysics.
-__global__ void k_dt_update(IcarDtBlock *b, const float *__restrict__ cflmax, float factor, float sqrt3, int strict4, double *__restrict__ ring)
-{
-    float m = *cflmax;
-    if (strict4) m = m * sqrt3;                                                   // time_step.f90:302-305
-    const float dt = factor / m;                                                  // :313
-    if (!(m == m) || !(dt >= 1e-1f)) b->err = 1;                                  // :322-328 (the host reports it after the launches)
-    double s = (double)dt;
-    s = s < 120.0 ? s : 120.0;                                                    // :417
-    b->mp_dt = (float)(b->time - b->mp_last);                                     // mp_driver.f90:708 ...
-    b->mp_last = b->time;                                                         // ... :711-713
-    b->dt_d = s; b->dt_f = (float)s;
-    ring[b->n] = s; b->n = b->n + 1;
-    b->time = b->time + s;                                                        // time_step.f90:547, for the NEXT sub-step's microphysics
-}
-
-#define ICAR_GRAPH_RING 4096
-static void graph_drop(icar_hip_ctx *c)
-{
-    for (auto &sl : c->step.graph) { if (sl.exec) (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; sl.key = nullptr; }
-}
-extern "C++" void icar_graph_invalidate(icar_hip_ctx *c) { graph_drop(c); c->step.graph_stamp.clear(); }
-
-static bool graph_eligible(icar_hip_ctx *c)
-{
-    const icar_hip_step_config &g = c->step.cfg;
-    return c->graph_mode && !c->timing && !c->on_aux && !icar_comm_has_peers(c) && (g.cfl_strictness == 3 || g.cfl_strictness == 4) && g.prefetch_dt
-        && g.mp_update_interval == 0.0f && g.halo_size == 1 && (g.advection == ICAR_ADV_UPWIND || g.advection == ICAR_ADV_MPDATA) && g.n_advect > 0
-        && (g.microphysics == 0 || g.microphysics == kMP_THOMPSON) && (g.microphysics == 0 || c->step.mp_last_model_time != -999.0)
-        && !c->step.early_open && icar_cfl_prefetch_waiting(c);
-}
-
-// up to `count` sub-steps (whole pairs) as graph launches; *done += the number issued, *dt_last = the last one's dt.  Returns 1 on
-// error; a configuration that cannot be captured issues nothing and switches the context to the eager loop
-static int graph_steps(icar_hip_ctx *c, int count, double nominal_dt, double *dt_last, int *done)
-{
-    IcarStepState &st = c->step;
-    const icar_hip_step_config &g = st.cfg;
-    if (!st.dtblk) {
-        HIPCHK(hipMalloc(&st.dtblk, sizeof(IcarDtBlock))); HIPCHK(hipHostMalloc((void **)&st.h_dtblk, sizeof(IcarDtBlock), hipHostMallocDefault));
-        HIPCHK(hipMalloc(&st.dt_ring, sizeof(double) * ICAR_GRAPH_RING)); HIPCHK(hipHostMalloc((void **)&st.h_dt_ring, sizeof(double) * ICAR_GRAPH_RING, hipHostMallocDefault));
-    }
-    // the executables belong to one configuration (and to the switches that select kernels)
-    std::vector<unsigned char> stamp(sizeof(g) + 3 * sizeof(int));
-    memcpy(stamp.data(), &g, sizeof(g));
-    const int sw[3] = {c->mpdata_exact, c->th_layout, (int)st.dz_levels.size()};
-    memcpy(stamp.data() + sizeof(g), sw, sizeof(sw));
-    if (stamp != st.graph_stamp) { graph_drop(c); st.graph_stamp = stamp; }
-    const int f0 = g.advect_fields[0];
-    const float sqrt3 = sqrtf(3.0f) * 1.001f;                                     // :229
-    count -= count % 2;                                                           // whole pairs; the caller issues an odd last one eagerly
-    while (count > 0) {
-        const int chunk = count < ICAR_GRAPH_RING ? count : ICAR_GRAPH_RING;
-        *st.h_dtblk = IcarDtBlock{st.model_time, st.mp_last_model_time, 0.0, 0.f, 0.f, 0, 0};
-        HIPCHK(hipMemcpyAsync(st.dtblk, st.h_dtblk, sizeof(IcarDtBlock), hipMemcpyHostToDevice, c->stream));
-        for (int i = 0; i < chunk; i += 2) {
-            IcarGraphSlot *slot = nullptr;
-            for (auto &sl : st.graph) if (sl.exec && sl.key == c->field[f0]) slot = &sl;
-            if (!slot) {
-                // capture a PAIR of sub-steps (after two the ping-pong buffers of the advected scalars are back where they were, so
-                // one executable serves every pair that starts from this buffer state).  The host-side effects of the two
-                // sub-steps (clock of the microphysics, wind bookkeeping) happen here, once.
-                for (auto &sl : st.graph) if (!sl.exec) slot = &sl;
-                if (!slot) { graph_drop(c); slot = &st.graph[0]; }
-                void *keep_field[ICAR_N_FIELDS]; float *keep_alt[ICAR_N_ADVECTABLE];
-                memcpy(keep_field, c->field, sizeof keep_field); memcpy(keep_alt, c->alt, sizeof keep_alt);
-                const double keep_last = st.mp_last_model_time; const bool keep_valid = c->winds_valid;
-                const void *key = c->field[f0];
-                hipGraph_t graph = nullptr;
-                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-                int rc = 0;
-                c->dt_bad = false;
-                for (int h = 0; h < 2 && !rc; ++h) {
-                    c->winds_valid = false;                                       // the wind setup must be IN the graph: its dt is the device's
-                    hipLaunchKernelGGL(k_dt_update, dim3(1), dim3(1), 0, c->stream, st.dtblk, c->d_red + 8, g.cfl_reduction_factor, sqrt3, g.cfl_strictness == 4 ? 1 : 0, st.dt_ring);
-                    c->dt_dev = st.dtblk;
-                    rc = icar_substep(c, nominal_dt, false);
-                    c->dt_dev = nullptr;
-                }
-                const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
-                hipGraphExec_t exec = nullptr;
-                const bool ok = !rc && !c->dt_bad && ec == hipSuccess && graph && c->field[f0] == key && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-                if (graph) (void)hipGraphDestroy(graph);
-                if (!ok) {
-                    // nothing of the captured sub-steps was executed: put the host's view back
-                    memcpy(c->field, keep_field, sizeof keep_field); memcpy(c->alt, keep_alt, sizeof keep_alt);
-                    st.mp_last_model_time = keep_last; c->winds_valid = keep_valid; st.early_open = false;
-                    (void)hipGetLastError();
-                    c->graph_mode = 0;                                            // this context stays eager
-                    if (i > 0) {                                                  // sub-steps already launched in this chunk: account for them
-                        HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-                        HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
-                        HIPCHK(hipMemcpyAsync(st.h_dtblk, st.dtblk, sizeof(IcarDtBlock), hipMemcpyDeviceToHost, c->stream));
-                        HIPCHK(hipMemcpyAsync(st.h_dt_ring, st.dt_ring, sizeof(double) * i, hipMemcpyDeviceToHost, c->stream));
-                        HIPCHK(hipStreamSynchronize(c->stream));
-                        st.model_time = st.h_dtblk->time; if (g.microphysics != 0) st.mp_last_model_time = st.h_dtblk->mp_last; *dt_last = st.h_dt_ring[i - 1];
-                        c->winds_valid = false;
-                        *done += i;
-                    }
-                    return rc ? 1 : 0;
-                }
-                slot->exec = exec; slot->key = key;
-            }
-            if (hipGraphLaunch(slot->exec, c->stream) != hipSuccess) { icar_set_error("step_n: hipGraphLaunch failed"); return 1; }
-            c->graph_launches += 2;
-        }
-        // the CFL maximum the last replay left behind is the next update_dt's: the host's copy and a real event behind it
-        HIPCHK(hipMemcpyAsync(c->h_cfl_pre, c->d_red + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipEventRecord(c->cfl_ev, c->stream));
-        HIPCHK(hipMemcpyAsync(st.h_dtblk, st.dtblk, sizeof(IcarDtBlock), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(st.h_dt_ring, st.dt_ring, sizeof(double) * chunk, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->aux) HIPCHK(hipStreamSynchronize(c->aux));
-        st.model_time = st.h_dtblk->time; if (g.microphysics != 0) st.mp_last_model_time = st.h_dtblk->mp_last;
-        *dt_last = st.h_dt_ring[chunk - 1];
-        c->winds_valid = false;                                                   // (the host's record of the Courant winds' dt is the nominal one)
-        if (st.h_dtblk->err) { icar_set_error("ERROR time step too small"); return 1; }
-        if (st.h_dtblk->n != chunk) { icar_set_error("step_n: graph replay lost a sub-step"); return 1; }
-        *done += chunk;
-        count -= chunk;
-    }
-    return 0;
-}
-
 // nsteps sub-steps of the loop without an end time (a benchmark's "K passes of the hot path", a host that counts steps):
 // update_dt -> substep -> clock += dt, nothing of the host in between.  dt_last receives the last step's dt.
 int icar_hip_step_n(icar_hip_ctx *c, int nsteps, double *dt_last)
@@ -603,79 +482,12 @@ int icar_hip_step_n(icar_hip_ctx *c, int nsteps, double *dt_last)
     HIPCHK(hipSetDevice(c->device));
     double dt = 0.0;
     for (int n = 0; n < nsteps; ++n) {
-        // every sub-step after the first of a run (the microphysics' clock and a prefetched CFL maximum exist from then on) is a
-        // graph launch where the configuration allows it (graph_eligible)
-        const double nominal = n > 0 ? dt : (double)c->step.winds_dt;             // (only the host's branch decisions see it: dt > 1e-3)
-        // (an executable belongs to one state of the ping-pong buffers; where only the other state's exists, one eager sub-step
-        // brings the buffers there instead of a second capture + instantiation, a few ms)
-        bool match = false, any = false;
-        for (const auto &sl : c->step.graph) if (sl.exec) { any = true; if (sl.key == c->field[c->step.cfg.advect_fields[0]]) match = true; }
-        if (nsteps - n >= 2 && nominal > 1e-3 && (match || !any || nsteps - n < 3) && graph_eligible(c)) {
-            int done = 0;
-            if (graph_steps(c, nsteps - n, nominal, &dt, &done)) return 1;
-            n += done;
-        }
-        if (n >= nsteps) break;
         if (icar_substep_can_open_early(c) && icar_substep_open_early(c)) return 1;
-        if (icar_update_dt(c, &dt)) return 1;
+        if (update_dt_opened(c, &dt)) return 1;
         if (icar_substep(c, dt, false)) return 1;
         c->step.model_time += dt;
     }
     if (dt_last) *dt_last = dt;
-    return 0;
-}
-
-// Measurement only ("no captured step exists"): the same 2 x pairs sub-steps with a FIXED dt issued eagerly and as
-// replays of ONE hipGraph of two consecutive sub-steps (two: the advected scalars ping-pong between two buffers, so the kernel
-// arguments repeat with period 2), both streams and their fork / join events captured.  Wall-clock of each in ms; the device state
-// afterwards is that of 2 + 4 x pairs sub-steps (tests/test_gpu_step_rows.py compares it with the eager sequence bit for bit).  The CFL
-// prefetch is off inside (its host-side event wait has no place in a graph); the product loops stay eager -- profiles/r04_steps.md has
-// the numbers this produced.
-int icar_hip_substep_graph_probe(icar_hip_ctx *c, double dt, int pairs, double *ms_eager, double *ms_graph)
-{
-    if (!c || pairs < 1 || !ms_eager || !ms_graph) { icar_set_error("substep_graph_probe: ctx, pairs >= 1, two outputs"); return 1; }
-    if (!cfg_ok(c, "substep_graph_probe")) return 1;
-    if (c->on_aux || c->timing) { icar_set_error("substep_graph_probe: not between aux_begin / aux_end, timers off"); return 1; }
-    if (icar_comm_has_peers(c)) { icar_set_error("substep_graph_probe: one image only (the transports are not captured)"); return 1; }
-    HIPCHK(hipSetDevice(c->device));
-    const int keep_prefetch = c->step.cfg.prefetch_dt;
-    c->step.cfg.prefetch_dt = 0;
-    struct Restore { icar_hip_ctx *c; int v; ~Restore() { c->step.cfg.prefetch_dt = v; } } restore{c, keep_prefetch};
-    auto run2 = [&](int n) { for (int i = 0; i < n; ++i) { if (icar_substep(c, dt, false)) return 1; c->step.model_time += dt; } return 0; };
-    auto sync = [&]() { if (c->aux) (void)hipStreamSynchronize(c->aux); return hipStreamSynchronize(c->stream); };
-    if (run2(2)) return 1;                                                        // every lazy allocation, the steady mp_dt
-    HIPCHK(sync());
-    auto t0 = std::chrono::steady_clock::now();
-    if (run2(2 * pairs)) return 1;
-    HIPCHK(sync());
-    auto t1 = std::chrono::steady_clock::now();
-    *ms_eager = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-    void *keep_field[ICAR_N_FIELDS]; float *keep_alt[ICAR_N_ADVECTABLE];
-    memcpy(keep_field, c->field, sizeof keep_field); memcpy(keep_alt, c->alt, sizeof keep_alt);
-    const double keep_time = c->step.model_time, keep_last = c->step.mp_last_model_time;
-    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-    const int rc = run2(2);
-    const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
-    c->step.model_time = keep_time;                                               // (captured, not executed)
-    if (rc || ec != hipSuccess || !graph) {
-        // nothing of the two sub-steps ran: the host's view of the buffers and of the microphysics' clock goes back
-        memcpy(c->field, keep_field, sizeof keep_field); memcpy(c->alt, keep_alt, sizeof keep_alt); c->step.mp_last_model_time = keep_last;
-        if (graph) (void)hipGraphDestroy(graph);
-        if (!rc) icar_set_error("substep_graph_probe: capture failed");
-        return 1;
-    }
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); icar_set_error("substep_graph_probe: hipGraphInstantiate failed"); return 1; }
-    if (hipGraphLaunch(exec, c->stream) != hipSuccess) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); icar_set_error("substep_graph_probe: hipGraphLaunch failed"); return 1; }
-    HIPCHK(sync());                                                               // first launch (upload) untimed ...
-    t0 = std::chrono::steady_clock::now();
-    for (int i = 1; i < pairs; ++i) if (hipGraphLaunch(exec, c->stream) != hipSuccess) { icar_set_error("substep_graph_probe: hipGraphLaunch failed"); return 1; }
-    HIPCHK(sync());
-    t1 = std::chrono::steady_clock::now();
-    *ms_graph = (pairs > 1) ? std::chrono::duration<double, std::milli>(t1 - t0).count() * pairs / (pairs - 1) : 0.0;      // ... scaled to `pairs` launches
-    c->step.model_time += 2.0 * pairs * dt;
-    if (c->step.cfg.microphysics != 0) c->step.mp_last_model_time = c->step.model_time - dt;   // the last replayed sub-step's start
-    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
     return 0;
 }
 
@@ -690,7 +502,7 @@ int icar_hip_step(icar_hip_ctx *c, double end_time_seconds, int *nsteps)
         double dt;
         // (update_dt caps dt at 120 s, :417: farther than that from the end no clamp can shorten this step)
         if (end_time_seconds - c->step.model_time > 120.0 && icar_substep_can_open_early(c) && icar_substep_open_early(c)) return 1;
-        if (icar_update_dt(c, &dt)) return 1;                                    // :465
+        if (update_dt_opened(c, &dt)) return 1;                                  // :465
         if (c->step.model_time + dt > end_time_seconds) dt = end_time_seconds - c->step.model_time;       // :469-471
         if (icar_substep(c, dt, (end_time_seconds - c->step.model_time) < dt * 2)) return 1;               // :474-539
         c->step.model_time += dt;                                                // :547

@@ -19,7 +19,7 @@ module icar_hip
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative, &
             hip_step_config_t, hip_step_configure, hip_update_dt, hip_compute_dt, hip_substep, hip_step, hip_step_n, hip_mp, hip_advect_step, hip_mp_reset, &
             hip_model_time, hip_set_model_time, hip_comm_unique_id, hip_comm_init, hip_comm_init_local, hip_comm_init_host, hip_comm_destroy, &
-            hip_halo_send, hip_halo_retrieve, hip_co_min, hip_comm_ranks, hip_halo_selfcheck, hip_update_winds, hip_exchange_uv, hip_mpdata_exact, hip_graph_mode, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
+            hip_halo_send, hip_halo_retrieve, hip_co_min, hip_comm_ranks, hip_halo_selfcheck, hip_update_winds, hip_exchange_uv, hip_mpdata_exact, ICAR_NEIGHBOR_NONE, ICAR_NEIGHBOR_SELF, ICAR_N_ADVECTABLE
   public :: ICAR_F_WATER_VAPOR, ICAR_F_CLOUD_WATER, ICAR_F_RAIN, ICAR_F_SNOW, ICAR_F_POTENTIAL_TEMPERATURE, &
             ICAR_F_CLOUD_ICE, ICAR_F_GRAUPEL, ICAR_F_ICE_NUMBER, ICAR_F_RAIN_NUMBER, ICAR_F_U, ICAR_F_V, ICAR_F_W, &
             ICAR_F_PRESSURE, ICAR_F_EXNER, ICAR_F_DENSITY, ICAR_F_DZ_MASS, ICAR_F_JACOBIAN, ICAR_F_JACOBIAN_U, &
@@ -246,9 +246,6 @@ module icar_hip
      integer(c_int) function icar_hip_comm_ranks(ctx, nranks) bind(C, name="icar_hip_comm_ranks")
        import; type(c_ptr), value :: ctx; integer(c_int), intent(out) :: nranks
      end function
-     integer(c_int) function icar_hip_graph_mode(ctx, on) bind(C, name="icar_hip_graph_mode")
-       import; type(c_ptr), value :: ctx; integer(c_int), value :: on
-     end function
      integer(c_int) function icar_hip_mpdata_exact(ctx, on) bind(C, name="icar_hip_mpdata_exact")
        import; type(c_ptr), value :: ctx; integer(c_int), value :: on
      end function
@@ -449,14 +446,6 @@ contains
     call check(icar_hip_halo_selfcheck(ctx%p, int(halo,c_int), nb), "halo_selfcheck")
     n_bad = int(nb)
   end function
-
-  !> hip_step_n's sub-steps as replays of a captured hipGraph with dt computed on the device (one image; same results bit for bit,
-  !! measured equal in speed to the default eager loop); .false. = eager (default)
-  subroutine hip_graph_mode(ctx, on)
-    type(hip_ctx_t), intent(in) :: ctx
-    logical, intent(in) :: on
-    call check(icar_hip_graph_mode(ctx%p, merge(1_c_int, 0_c_int, on)), "graph_mode")
-  end subroutine
 
   !> MPDATA's corrective iterations in the operation order of adv_mpdata.f90 (bit-identical to the CPU reference, ~4x the
   !! advection time of the fused kernel); .false. = the fused kernel (default)

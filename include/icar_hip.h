@@ -172,33 +172,10 @@ int icar_hip_thompson(icar_hip_ctx *ctx, float dt,
  * {its,ite,jts,jte} (as icar_hip_mp_tiles returns them) in ONE launch.  Tiles must not overlap. */
 int icar_hip_thompson_tiles(icar_hip_ctx *ctx, float dt, int ntiles, const int tiles[][4], int kts, int kte,
                             int ids, int ide, int jds, int jde, int kds, int kde);
-/* Thread layout of the Thompson column physics (mp_thompson.f90:1057-2844 is a 1-D column routine; how its levels map to
- * lanes is the device's business).  0 / 1 (default): one level per thread, whole columns packed into 256-thread blocks.
- * 2: one column per LANE marching down its levels in two sweeps (point physics, then sedimentation + update); 3: 64 columns
- * x 4 levels per block, slabs marched top-down (a wave = 64 neighbouring columns of one level, one level per thread).  Both
- * for single tiles, both the same bits; on MI355X 2 is slower and 3 on a par with the default
- * (profiles/r04_thompson_layout.md) -- kept for profiling and as the starting point of north_star's layout. */
-int icar_hip_thompson_layout(icar_hip_ctx *ctx, int layout);
-
-
 /* Download one Thompson lookup table by its reference name (tcg_racg ... t_Efsw, Fortran order) for
  * cross-checks against ICAR's own qr_acr_qg_mpt.dat / qr_acr_qs_mpt.dat / freezeH2O_mpt.dat caches
  * (src/physics/mp_thompson.f90:2870-2887).  out may be NULL to query the element count. */
 int icar_hip_thompson_table(icar_hip_ctx *ctx, const char *name, double *out, size_t capacity, size_t *count);
-
-/* The decade index of the lookup tables (src/physics/mp_thompson.f90:1562-1574 for a REAL argument, :1620-1627 for a DOUBLE
- * PRECISION one) for n values of r (exactly one of r4 / r8 given; n2 = the table's first decade), computed on the device by
- * which = 0: the level code's form (decade from the hardware log2 + the same 10.**n and IEEE division, the reference's loop
- * only near a power of ten), which = 1: the reference's loop alone.  A cross-check for tests: the two must agree everywhere. */
-int icar_hip_thompson_dec_index(icar_hip_ctx *ctx, const float *r4, const double *r8, int n, int n2, int which, int *out);
-
-/* The device's evaluation of the scheme's transcendentals, for tests.  REAL(4) exp / log / log10 / x**y / atan are the C
- * library's expf / logf / log10f / powf / atanf restated bit for bit (icar_amd/csrc/glibc_flt32.h: what the compiled reference
- * calls); DOUBLE PRECISION log / exp / x**y are evaluated in FP64.  out[i] = op 0: log(x[i]), 1: exp(x[i]), 2: x[i]**y[i] in FP64;
- * on REAL(x[i]), REAL(y[i]) with the REAL(4) result widened: 3: powf, 4: expf, 5: logf, 6: log10f, 7: atanf, 8: powf through the
- * shared-base form the level code uses for several powers of one base, 9: 10.**x.  Host arrays of n doubles; y may be NULL
- * unless op is 2, 3 or 8. */
-int icar_hip_thompson_math_probe(icar_hip_ctx *ctx, int op, int n, const double *x, const double *y, double *out);
 
 /* ---- M0: tile bookkeeping of mp()/process_halo (src/physics/mp_driver.f90:609-772) -----------
  * Fills tiles[n][4] = {its,ite,jts,jte} for halo>0 (W,E,S,N strips; corners once) or for the
@@ -457,24 +434,6 @@ int icar_hip_step(icar_hip_ctx *ctx, double end_time_seconds, int *nsteps);
 /* the same loop for a given NUMBER of sub-steps (update_dt -> substep -> clock += dt each), no end-of-interval clamp and no
  * enforce_limits: what a benchmark times as "K passes of the hot path".  dt_last (may be NULL) receives the last dt. */
 int icar_hip_step_n(icar_hip_ctx *ctx, int nsteps, double *dt_last);
-
-/* on = 1: icar_hip_step_n launches its sub-steps, in pairs, as replays of ONE captured hipGraph (two sub-steps: the advected
- * scalars' ping-pong buffers are then back where they were) where it can: one image (no neighbouring images), group timers off,
- * cfl_strictness 3 or 4 with prefetch_dt, mp_update_interval 0, halo_size 1, Thompson or no microphysics.  dt then lives in
- * device memory -- a one-thread kernel at the head of each captured sub-step turns the prefetched CFL maximum into dt with
- * compute_dt's REAL(4) operations and update_dt's 120 s cap (time_step.f90:313, :417) and keeps the clock the microphysics' own
- * time step comes from (mp_driver.f90:708) -- so nothing of the host sits between two sub-steps; the model clock and dt_last come
- * back after the launches.  Same bits as the eager loop, forced winds included (tests/test_gpu_step_rows.py).  Default: off --
- * measured equal to the eager loop within noise on MI355X (profiles/r04_steps.md), because that loop already keeps the host off
- * the critical path. */
-int icar_hip_graph_mode(icar_hip_ctx *ctx, int on);
-/* how many sub-steps this context has launched as graph replays so far (bench.py reports it; tests assert it) */
-int icar_hip_graph_replays(icar_hip_ctx *ctx, long long *n);
-
-/* Measurement only: 2 x pairs sub-steps with a fixed dt issued eagerly, then the same number as replays of one hipGraph of two
- * captured sub-steps (one image; the CFL prefetch off inside).  Wall-clock of each in ms.  The loops of this library stay eager:
- * profiles/r04_steps.md has what this measured.  No counterpart in the reference. */
-int icar_hip_substep_graph_probe(icar_hip_ctx *ctx, double dt_seconds, int pairs, double *ms_eager, double *ms_graph);
 
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Average duration (ms) of the launches of a named kernel group since the last reset, measured

@@ -14,9 +14,6 @@ c=ideal.make_case(nx,ny,nz,hill_height=1000.,noise=0.01,n_hydro=1)
 c["water_vapor"]=(c["water_vapor"]*np.float32(1.4)).astype(np.float32)
 opt=options_t(); opt.physics.microphysics=kMP_THOMPSON; opt.physics.advection=kADV_MPDATA; mp_var_request(opt)
 d=domain_t(grid_t().set_grid_dimensions(nx,ny,nz,1,1)); d.load_case(c); mp_init(opt,d)
-from icar_amd.capi import lib, check
-layout=int(os.environ.get("TH_LAYOUT","0"))      # profiling only: 0 = by tile size, 1 = level per thread, 2 = column per lane
-check(lib().icar_hip_thompson_layout(d.ctx, layout), "layout")
 dt=60.0
 for it in range(6):
     mp(d,opt,dt); d.model_time_seconds+=dt
@@ -24,4 +21,4 @@ for it in range(6):
 d.synchronize(); t=time.time()
 for it in range(4):
     mp(d,opt,dt); d.model_time_seconds+=dt
-d.synchronize(); print("thompson layout", layout, "nx", nx, "ms/call", (time.time()-t)/4*1e3)
+d.synchronize(); print("thompson nx", nx, "ms/call", (time.time()-t)/4*1e3)

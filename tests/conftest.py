@@ -57,6 +57,9 @@ def host_libm_matches_device_math():
     return ok, why
 
 
+_ORACLE_TESTS = set()        # node ids of the collected GPU tests that compare the device with the oracle (they take its fixture)
+
+
 def pytest_collection_modifyitems(config, items):
     if not _has_gpu():
         skip = pytest.mark.skip(reason="no GPU in this container")
@@ -64,13 +67,18 @@ def pytest_collection_modifyitems(config, items):
             if "gpu" in item.keywords:
                 item.add_marker(skip)
         return
+    for item in items:
+        if "gpu" in item.keywords and ({"oracle", "th_oracle"} & set(getattr(item, "fixturenames", ()))):
+            _ORACLE_TESTS.add(item.nodeid)
     ok, why = host_libm_matches_device_math()
     if ok:
         return
-    # LOUD: every device-vs-oracle test (they take the `oracle` / `th_oracle` fixture) is skipped with the reason, and said once more at the end
+    # Every device-vs-oracle test is skipped with the reason -- and the session does NOT pass: tests/test_gpu_host_libm.py::
+    # test_host_libm_is_the_restated_glibc fails on such a host (a green `-m gpu` run always means the parity tests ran), unless
+    # ICAR_ALLOW_LIBM_MISMATCH=1 says the host is known to be different.
     skip = pytest.mark.skip(reason="HOST LIBM MISMATCH, device-vs-oracle parity not checkable here: " + why)
     for item in items:
-        if "gpu" in item.keywords and ({"oracle", "th_oracle"} & set(getattr(item, "fixturenames", ()))):
+        if item.nodeid in _ORACLE_TESTS:
             item.add_marker(skip)
 
 
@@ -78,6 +86,33 @@ def pytest_terminal_summary(terminalreporter):
     if _LIBM and not _LIBM["ok"]:
         terminalreporter.section("HOST LIBM MISMATCH")
         terminalreporter.write_line("device-vs-oracle GPU parity tests were SKIPPED on this host: " + _LIBM["why"])
+    if not _has_gpu():
+        return
+    # what a green run means: how many device-vs-oracle tests actually ran, and how many fields they compared how
+    passed = [r for r in terminalreporter.stats.get("passed", []) if getattr(r, "when", "") == "call"]
+    n_oracle = sum(1 for r in passed if r.nodeid in _ORACLE_TESTS)
+    try:
+        import util
+        counts = dict(util.COUNTS)
+    except Exception:
+        counts = {}
+    line = (f"device-vs-oracle tests run: {n_oracle} of {len(_ORACLE_TESTS)} collected, fields compared bit for bit: {counts.get('bit_exact_fields', 0)}, "
+            f"fields compared within a tolerance: {counts.get('tolerance_fields', 0)}")
+    terminalreporter.section("PARITY")
+    terminalreporter.write_line(line)
+    try:
+        out = os.path.join(ROOT, "gpurun_out", "parity"); os.makedirs(out, exist_ok=True)
+        open(os.path.join(out, "session_summary.txt"), "w").write(line + "\n")
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="session")
+def probe():
+    """tests/support/libicar_probe.so: the level code's device math functions on arrays of arguments (test infrastructure)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
+    import build_probe
+    return build_probe.lib()
 
 
 @pytest.fixture(scope="session")

@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 # MPDATA + mp_simple, three steps WITHOUT re-synchronising the oracle (mp_simple is bit-identical on equal inputs; MPDATA's 1-ulp
 # reciprocals leave ~2e-7 per step, which the saturation adjustment amplifies, tests/test_oracle_trajectory_sensitivity.py):
 # (fraction of cells beyond 1e-5 of the field maximum, max |d| / max, relative difference of the precipitation sum); measured on
-# MI355X: 7.8e-4 / 7.3e-3 / 1.9e-4 (profiles/r03_parity.json, fortran_host); bounds = 2x (round 2 allowed 5e-2 / 0.1 / 5e-2)
-FH_BOUND = (1.6e-3, 1.5e-2, 4e-4)
+# MI355X: 1.7e-3 / 7.3e-3 / 1.9e-4 with the round-5 kernel (39 of the 23 040 cells sit on the other side of a threshold after three
+# steps; the round-3/4 kernel's rounding put 18 there: 7.8e-4) -- which cells flip is a property of the last bit, the per-step
+# error is test_gpu_advect.py's (<= 2e-6 measured against 1e-5); bounds = 2x measured (round 2 allowed 5e-2 / 0.1 / 5e-2)
+FH_BOUND = (3.4e-3, 1.5e-2, 4e-4)
 
 
 @pytest.mark.parametrize("scheme", [1, 2, 3])

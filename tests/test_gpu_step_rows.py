@@ -371,118 +371,3 @@ def test_substep_equals_the_plain_sequence(mpname):
             x, y = a.get(n), b.get(n)
             assert np.array_equal(x, y), f"{mpname} step {it} {n}: {(x != y).sum()} cells differ"
     a.close(); b.close()
-
-
-def test_graph_replay_of_the_substep_equals_the_eager_launches():
-    """icar_hip_substep_graph_probe: two consecutive sub-steps (diagnostic_update -> Thompson strips + interior -> periodic halo ->
-    MPDATA -> forcing, both streams and their fork / join events) captured into ONE hipGraph and replayed; the state afterwards
-    must be the state of the same number of sub-steps issued eagerly, bit for bit -- i.e. the capture holds every launch of a
-    sub-step and its dependencies.  (Measurement entry; the loops of the library stay eager)"""
-    import ctypes
-    from icar_amd.capi import lib, check
-    from icar_amd.time_step import update_dt
-    from icar_amd.microphysics import mp_init, mp_var_request
-    from icar_amd.advection import adv_init, adv_var_request
-    from icar_amd.constants import kADV_MPDATA, kMP_THOMPSON, ADVECTION_ORDER
-    from icar_amd.grid import grid_t
-    from icar_amd.domain import domain_t
-    from icar_amd.halo import HaloComm
-    nx, ny, nz, pairs = 70, 44, 16, 3
-    c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.02, n_hydro=1)
-    c["water_vapor"] = (c["water_vapor"] * np.float32(1.6)).astype(np.float32)
-    rng = np.random.default_rng(3)
-    c["dzdx"] = (0.05 * rng.standard_normal(c["u"].shape)).astype(np.float32)
-    c["dzdy"] = (0.05 * rng.standard_normal(c["v"].shape)).astype(np.float32)
-    dq = {k: (s * rng.standard_normal(c[k].shape)).astype(np.float32) for k, s in {"water_vapor": 1e-8, "potential_temperature": 1e-4, "pressure": 1e-3}.items()}
-    forced = [("water_vapor", True), ("potential_temperature", True), ("pressure", False)]
-    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON
-    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"]); opt.parameters.ideal = True
-    mp_var_request(opt); adv_var_request(opt)
-
-    def fresh():
-        g = grid_t().set_grid_dimensions(nx, ny, nz, 1, 1)
-        d = domain_t(g, device=0, dx=float(c["dx"]), image=1, comm=HaloComm(g, 1, loopback=True))
-        d.load_case(c)
-        d.exchange_vars = [n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0]
-        mp_init(opt, d); adv_init(d, opt)
-        for k, a in dq.items():
-            d.set_dqdt(k, a)
-        d.configure(opt, forced=forced, diagnostics=True, prefetch_dt=False)
-        return d
-    a, b = fresh(), fresh()
-    dt = update_dt(a, opt)
-    a.configure(opt, forced=forced, diagnostics=True, prefetch_dt=False)
-    me, mg = ctypes.c_double(), ctypes.c_double()
-    check(lib().icar_hip_substep_graph_probe(a.ctx, dt, pairs, ctypes.byref(me), ctypes.byref(mg)), "substep_graph_probe")
-    for _ in range(2 + 4 * pairs):
-        check(lib().icar_hip_substep(b.ctx, dt, 0), "substep"); b.model_time_seconds += dt
-    assert a.model_time_seconds == pytest.approx(b.model_time_seconds, rel=1e-12) and me.value > 0 and mg.value > 0
-    for n in ("water_vapor", "cloud_water_mass", "rain_mass", "snow_mass", "potential_temperature", "cloud_ice_mass", "graupel_mass", "cloud_ice_number",
-              "rain_number", "pressure", "w_real", "density", "exner"):
-        x, y = a.get(n), b.get(n)
-        assert bits_equal(x, y), f"{n}: {nbitdiff(x, y)} cells differ between the graph replays and the eager sub-steps"
-    assert float(a.get("cloud_water_mass").max()) > 1e-6
-    assert np.array_equal(a.get("accumulated_precipitation"), b.get("accumulated_precipitation"))
-    a.close(); b.close()
-
-
-@pytest.mark.parametrize("mpname,forced_winds", [("thompson", True), ("thompson", False), ("none", True)])
-def test_step_n_graph_replays_equal_the_eager_loop(mpname, forced_winds):
-    """icar_hip_step_n launches every sub-step after the first as a replay of a captured graph with dt in device memory
-    (icar_hip_graph_mode, default on).  Against the same context kept eager (icar_hip_graph_mode(ctx, 0)): the dt of the last
-    sub-step, the model clock and every field bit for bit -- with forced winds (every sub-step its own dt: the device's
-    k_dt_update must reproduce compute_dt / update_dt), with standing winds, without a microphysics scheme, over two calls (the
-    second one starts with replays) and an odd number of sub-steps (the ping-pong buffers end on the other parity)."""
-    from icar_amd.capi import lib, check
-    from icar_amd.time_step import step_n
-    from icar_amd.microphysics import mp_init, mp_var_request
-    from icar_amd.advection import adv_init, adv_var_request
-    from icar_amd.constants import kADV_MPDATA, kMP_THOMPSON, ADVECTION_ORDER
-    from icar_amd.grid import grid_t
-    from icar_amd.domain import domain_t
-    from icar_amd.halo import HaloComm
-    nx, ny, nz = 70, 44, 16
-    c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.02, n_hydro=1)
-    c["water_vapor"] = (c["water_vapor"] * np.float32(1.5)).astype(np.float32)
-    rng = np.random.default_rng(4)
-    c["dzdx"] = (0.05 * rng.standard_normal(c["u"].shape)).astype(np.float32)
-    c["dzdy"] = (0.05 * rng.standard_normal(c["v"].shape)).astype(np.float32)
-    scale = {"water_vapor": 1e-8, "potential_temperature": 1e-4, "pressure": 1e-3}
-    forced = [("water_vapor", True), ("potential_temperature", True), ("pressure", False)]
-    if forced_winds:
-        scale.update({"u": 5e-4, "v": -5e-4, "w": 2e-6}); forced += [("u", False), ("v", False), ("w", False)]
-    dq = {k: (s * rng.standard_normal(c[k].shape)).astype(np.float32) for k, s in scale.items()}
-    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.physics.microphysics = kMP_THOMPSON if mpname == "thompson" else 0
-    opt.parameters.dz_levels = c["dz_levels"]; opt.parameters.dx = float(c["dx"]); opt.parameters.ideal = True
-    mp_var_request(opt); adv_var_request(opt)
-    if mpname == "none":
-        opt.advect_vars(["water_vapor", "potential_temperature", "cloud_water"])
-
-    def fresh(graph):
-        g = grid_t().set_grid_dimensions(nx, ny, nz, 1, 1)
-        d = domain_t(g, device=0, dx=float(c["dx"]), image=1, comm=HaloComm(g, 1, loopback=True))
-        d.load_case(c)
-        d.exchange_vars = [n for n in ADVECTION_ORDER if opt.vars_to_advect.get(n, 0) > 0]
-        mp_init(opt, d); adv_init(d, opt)
-        for k, a in dq.items():
-            d.set_dqdt(k, a)
-        check(lib().icar_hip_graph_mode(d.ctx, 1 if graph else 0), "graph_mode")
-        return d
-    a, b = fresh(True), fresh(False)
-    names = [n for n in ("water_vapor", "cloud_water_mass", "rain_mass", "snow_mass", "potential_temperature", "cloud_ice_mass", "graupel_mass",
-                         "cloud_ice_number", "rain_number") if mpname == "thompson" or n in ("water_vapor", "potential_temperature", "cloud_water_mass")]
-    names += ["u", "v", "w", "pressure", "w_real", "density", "exner"]
-    for nsteps in (6, 5):
-        dta = step_n(a, nsteps, opt, forced=forced)
-        dtb = step_n(b, nsteps, opt, forced=forced)
-        assert dta == dtb and a.model_time_seconds == b.model_time_seconds, (dta, dtb, a.model_time_seconds, b.model_time_seconds)
-        for n in names:
-            x, y = a.get(n), b.get(n)
-            assert bits_equal(x, y), f"{mpname} forced_winds={forced_winds} after {nsteps} more sub-steps, {n}: {nbitdiff(x, y)} cells differ"
-        if mpname == "thompson":
-            assert np.array_equal(a.get("accumulated_precipitation"), b.get("accumulated_precipitation"))
-    import ctypes
-    na, nb = ctypes.c_longlong(), ctypes.c_longlong()
-    check(lib().icar_hip_graph_replays(a.ctx, ctypes.byref(na)), "graph_replays"); check(lib().icar_hip_graph_replays(b.ctx, ctypes.byref(nb)), "graph_replays")
-    assert na.value == 8 and nb.value == 0, (na.value, nb.value)         # whole pairs: 4 of the first call's 6 sub-steps, 4 of the second's 5
-    a.close(); b.close()

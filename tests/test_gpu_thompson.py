@@ -5,7 +5,7 @@
   summation order without FMA contraction.
 * column physics: compared with the oracle in math-mode 0 -- the host's libm, i.e. what the compiled reference calls and what
   the device restates bit for bit (icar_amd/csrc/glibc_flt32.h) -- every field of every case, incl. every column of
-  512 x 512 x 40: BIT-IDENTICAL (asserted: 0 differing cells).  Both thread layouts (one level per thread; one column per lane).
+  512 x 512 x 40: BIT-IDENTICAL (asserted: 0 differing cells).  
   The measured values are recorded by every run (gpurun_out/parity -> profiles/r0*_parity.json)."""
 import ctypes
 import numpy as np
@@ -15,7 +15,7 @@ from icar_amd.capi import lib, check
 from icar_amd.options import options_t
 from icar_amd.microphysics import mp, mp_init
 from icar_amd.constants import kMP_THOMPSON
-from util import single_image_domain, parity_record, field_stats
+from util import single_image_domain, parity_record, field_stats, bits_equal
 
 pytestmark = pytest.mark.gpu
 TABLES = ["tcg_racg", "tmr_racg", "tcr_gacr", "tmg_gacr", "tnr_racg", "tnr_gacr", "tcs_racs1", "tmr_racs1", "tcs_racs2",
@@ -47,7 +47,7 @@ def test_lookup_tables_bit_identical(th_oracle):
     d.close()
 
 
-def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, mp_options=None, layout=0):
+def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, mp_options=None):
     c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, uniform_dz=uniform_dz)
     c["water_vapor"] = (c["water_vapor"] * np.float32(moist)).astype(np.float32)
     s = {k: c[k].copy() for k in list(FIELDS) + ["exner", "pressure", "dz_mass"]}
@@ -57,7 +57,6 @@ def run_case(oracle, nx, ny, nz, steps, cool, moist, dt, mode, uniform_dz=None, 
     if mp_options is not None:
         opt.mp_options = mp_options
     mp_init(opt, d)
-    check(lib().icar_hip_thompson_layout(d.ctx, layout), "thompson_layout")
     oracle.set_math_mode(mode)
     try:
         for _ in range(steps):
@@ -88,7 +87,9 @@ def check_close(out, ref, rtol, frac_allowed, label, abs_allowed=None):
         report.append(f"{k}: bitdiff {st['bitdiff_frac']:.2e}, beyond-rtol {st['beyond_rtol_frac']:.2e}, max|d|/max {st['max_abs_over_max']:.2e}")
     parity_record("thompson", label, stats)
     print(f"[{label}]\n  " + "\n  ".join(report))
+    import util
     for k, st in stats.items():
+        util.COUNTS["bit_exact_fields" if (frac_allowed == 0.0 and abs_allowed == 0.0) else "tolerance_fields"] += 1
         assert st["beyond_rtol_frac"] <= frac_allowed, f"[{label}] {k}: {st}"
         if abs_allowed is not None:
             assert st["max_abs_over_max"] <= abs_allowed, f"[{label}] {k}: {st}"
@@ -115,50 +116,33 @@ def test_thompson_bit_exact_vs_reference_math(th_oracle, case):
     check_close(out, ref, rtol=1e-5, label=case + "/mode0", **EXACT)
 
 
-@pytest.mark.parametrize("layout", [2, 3])
-@pytest.mark.parametrize("case", list(CASES))
-def test_thompson_column_per_lane_bit_exact(th_oracle, case, layout):
-    """Lanes along i (a wave = 64 neighbouring columns of one level) forced on the small cases: layout 2 = k_thompson_march (one
-    column per lane, levels marched top-down), layout 3 = k_thompson_slab (64 columns x 4 levels per block, slabs marched
-    top-down); ThHand parked in the HBM workspace between the sweeps, sedimentation flux history in LDS.  The same bits as the
-    oracle in the reference's math."""
-    out, ref = run_case(th_oracle, mode=0, layout=layout, **CASES[case])
-    assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
-    check_close(out, ref, rtol=1e-5, label=f"{case}/layout{layout}/mode0", **EXACT)
-
-
-@pytest.mark.parametrize("layout", [2, 3])
-def test_thompson_column_per_lane_chunked_substeps(th_oracle, layout):
-    """A time step long enough that a wave's sub-step counts (2 nstep_rain + 2 nstep_ice + nstep_snow + nstep_graupel) exceed
-    its 64 LDS rows: the sedimentation then runs in chunks of sub-steps, one sweep over the workspace per chunk."""
-    out, ref = run_case(th_oracle, mode=0, layout=layout, nx=70, ny=9, nz=40, steps=6, cool=3.0, moist=2.5, dt=400.0)
-    assert ref["rain"].max() > 1e-5 and ref["acc_rain"].max() > 0
-    check_close(out, ref, rtol=1e-5, label=f"chunked/layout{layout}/mode0", **EXACT)
-
-
-def test_thompson_layouts_agree_with_quiet_columns():
-    """Columns with nothing to do (:1363) beside active ones, both layouts, bit for bit (the dry half of the domain keeps
+def test_thompson_quiet_columns_beside_active_ones(th_oracle):
+    """Columns with nothing to do (:1363) beside active ones, bit for bit against the oracle (the dry half of the domain keeps
     its inputs except for what the column routine does before it returns)."""
     nx, ny, nz = 140, 11, 40
     c = ideal.make_case(nx, ny, nz, hill_height=800.0, noise=0.01)
     qv = c["water_vapor"].copy(); qv[:, :, : nx // 2] *= np.float32(0.05); qv[:, :, nx // 2:] *= np.float32(2.0)
     c["water_vapor"] = qv.astype(np.float32)
     c["cloud_water"][:, 3, 5:9] = np.float32(5e-13)          # below R1: zeroed even where the column returns early
-    outs = []
-    for layout in (1, 2, 3):
-        d = single_image_domain(c)
-        opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
-        mp_init(opt, d)
-        check(lib().icar_hip_thompson_layout(d.ctx, layout), "thompson_layout")
-        for _ in range(4):
-            mp(d, opt, 60.0); d.model_time_seconds += 60.0
-            d.set("potential_temperature", d.get("potential_temperature") - np.float32(1.5))
-        outs.append({k: d.get(m) for k, m in FIELDS.items()} | {"acc": d.get("accumulated_precipitation")})
-        d.close()
-    dry = outs[0]["cloud_water"].max(axis=1) == 0.0                      # (ny, nx): columns without any cloud water
-    assert dry.any() and (~dry).any() and outs[0]["cloud_water"][1:-1, 3, 5:9].max() == 0.0
-    for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k]) and np.array_equal(outs[0][k], outs[2][k]), k
+    s = {k: c[k].copy() for k in list(FIELDS) + ["exner", "pressure", "dz_mass"]}
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    mp_init(opt, d)
+    th_oracle.set_math_mode(0)
+    for _ in range(4):
+        r = np.zeros((ny, nx), np.float32); rv = r.copy(); sn = r.copy(); gr = r.copy(); sr = r.copy()
+        th_oracle.thompson(s["water_vapor"], s["cloud_water"], s["rain"], s["cloud_ice"], s["snow"], s["graupel"], s["ice_number"],
+                           s["rain_number"], s["potential_temperature"], s["exner"], s["pressure"], s["dz_mass"], 60.0, r, rv, sn, gr, sr,
+                           1, nx, 1, ny, 1, nz, 2, nx - 1, 2, ny - 1, 1, nz)
+        s["potential_temperature"] -= np.float32(1.5)
+        mp(d, opt, 60.0); d.model_time_seconds += 60.0
+        d.set("potential_temperature", d.get("potential_temperature") - np.float32(1.5))
+    out = {k: d.get(m) for k, m in FIELDS.items()}
+    d.close()
+    dry = out["cloud_water"].max(axis=1) == 0.0                      # (ny, nx): columns without any cloud water
+    assert dry.any() and (~dry).any() and out["cloud_water"][1:-1, 3, 5:9].max() == 0.0
+    for k in out:
+        assert bits_equal(out[k], s[k]), k
 
 
 def test_thompson_excludes_last_global_row_and_column(th_oracle):
@@ -216,14 +200,12 @@ def test_halo_strips_in_one_launch_equal_four_launches():
     assert inner.max() == 0.0, "only the halo ring is processed"
 
 
-@pytest.mark.parametrize("layout", [0, 2, 3])
-def test_thompson_full_size_every_column_bit_exact(th_oracle, layout):
+def test_thompson_full_size_every_column_bit_exact(th_oracle):
     """The BASELINE tile (512 x 512 x 40): EVERY column of two microphysics calls, device vs the CPU oracle in the reference's own
-    math, bit for bit (the column subset above only samples 3000 of the 260 100) -- the product layout and the two lanes-along-i
-    layouts."""
-    out, ref = run_case(th_oracle, mode=0, nx=512, ny=512, nz=40, steps=2, cool=1.5, moist=1.8, dt=60.0, layout=layout)
+    math, bit for bit (the column subset above only samples 3000 of the 260 100)."""
+    out, ref = run_case(th_oracle, mode=0, nx=512, ny=512, nz=40, steps=2, cool=1.5, moist=1.8, dt=60.0)
     assert ref["rain"].max() > 1e-5 and ref["cloud_water"].max() > 1e-5 and ref["acc_rain"].max() > 0
-    check_close(out, ref, rtol=1e-5, label=f"full_size_every_column/layout{layout}/mode0", **EXACT)
+    check_close(out, ref, rtol=1e-5, label="full_size_every_column/mode0", **EXACT)
 
 
 @pytest.mark.parametrize("mode", [0])
@@ -337,7 +319,7 @@ def test_non_default_mp_options(oracle):
         oracle.thompson_init(po, fo)
 
 
-def test_decade_index_fast_form_equals_reference_loop():
+def test_decade_index_fast_form_equals_reference_loop(probe):
     """The table indices (mp_thompson.f90:1562-1627) are integer-exact rows: the level code takes the decade from the hardware log2
     and one division by the tabulated 10.**n, and runs the reference's loop (nint(log10 r), 10.**n by repeated squaring, the
     [1, 10) test) only near a power of ten.  Both forms, value by value: log-uniform random arguments over every decade the scheme
@@ -367,14 +349,14 @@ def test_decade_index_fast_form_equals_reference_loop():
             fast = np.zeros(arr.size, np.int32); slow = np.zeros(arr.size, np.int32)
             p4 = arr.ctypes.data_as(ctypes.c_void_p) if is4 else None
             p8 = None if is4 else arr.ctypes.data_as(ctypes.c_void_p)
-            check(lib().icar_hip_thompson_dec_index(d.ctx, p4, p8, arr.size, n2, 0, fast.ctypes.data_as(ctypes.c_void_p)), "dec_index")
-            check(lib().icar_hip_thompson_dec_index(d.ctx, p4, p8, arr.size, n2, 1, slow.ctypes.data_as(ctypes.c_void_p)), "dec_index")
+            assert probe.icar_probe_dec_index(p4, p8, arr.size, n2, 0, fast.ctypes.data_as(ctypes.c_void_p)) == 0
+            assert probe.icar_probe_dec_index(p4, p8, arr.size, n2, 1, slow.ctypes.data_as(ctypes.c_void_p)) == 0
             bad = np.flatnonzero(fast != slow)
             assert bad.size == 0, (is4, n2, bad.size, arr[bad[:5]], fast[bad[:5]], slow[bad[:5]])
     d.close()
 
 
-def test_fp64_transcendentals_of_the_level_code(oracle):
+def test_fp64_transcendentals_of_the_level_code(oracle, probe):
     """The DOUBLE PRECISION log / exp / x**y of the level code are the C library's log / exp / pow restated (icar_amd/csrc/glibc_dbl64.h:
     glibc 2.35's FMA builds, operation by operation): on the device, bit for bit against the host libm on millions of arguments
     per function -- the scheme's ranges, every binade, arguments next to 1, arbitrary bit patterns, the special values.  (Until
@@ -387,11 +369,10 @@ def test_fp64_transcendentals_of_the_level_code(oracle):
     d = single_image_domain(c)
     rng = np.random.default_rng(11)
 
-    def probe(op, x, y=None):
+    def run(op, x, y=None):
         x = np.ascontiguousarray(x, np.float64); out = np.zeros(x.size, np.float64)
         yp = None if y is None else np.ascontiguousarray(y, np.float64).ctypes.data_as(ctypes.c_void_p)
-        check(lib().icar_hip_thompson_math_probe(d.ctx, op, x.size, x.ctypes.data_as(ctypes.c_void_p), yp,
-                                                 out.ctypes.data_as(ctypes.c_void_p)), "math_probe")
+        assert probe.icar_probe_math(op, x.size, x.ctypes.data_as(ctypes.c_void_p), yp, out.ctypes.data_as(ctypes.c_void_p)) == 0, "math_probe"
         return out
 
     def differ(a, b):
@@ -410,7 +391,7 @@ def test_fp64_transcendentals_of_the_level_code(oracle):
         xe = np.concatenate([rng.uniform(-87.3, 88.7, n).astype(np.float32).astype(np.float64), rng.uniform(-750.0, 715.0, n),
                              rng.uniform(-1.0, 1.0, n // 2) * 2.0 ** -rng.integers(0, 70, n // 2), anybits(n // 10), special])
         for op, name, x in ((0, "log", xl), (1, "exp", xe)):
-            got, want = probe(op, x), oracle.libm_d(op, x)
+            got, want = run(op, x), oracle.libm_d(op, x)
             bad = differ(got, want)
             stats[name] = {"n": int(x.size), "differ": int(bad.sum())}
             assert not bad.any(), f"{name}: {bad.sum()} of {x.size} differ from libm, first x = {x[bad][0]!r}: {got[bad][0]!r} vs {want[bad][0]!r}"
@@ -423,7 +404,7 @@ def test_fp64_transcendentals_of_the_level_code(oracle):
         yb[2 * n + n // 2: 3 * n] *= 1075.0 / np.maximum(1.0, np.abs(np.log2(xb[2 * n + n // 2: 3 * n])))
         sx, sy = np.meshgrid(special, special)
         xb = np.concatenate([xb, sx.ravel()]); yb = np.concatenate([yb, sy.ravel()])
-        got, want = probe(2, xb, yb), oracle.libm_d(2, xb, yb)
+        got, want = run(2, xb, yb), oracle.libm_d(2, xb, yb)
         bad = differ(got, want)
         stats["pow"] = {"n": int(xb.size), "differ": int(bad.sum())}
         assert not bad.any(), f"pow: {bad.sum()} of {xb.size} differ from libm, first ({xb[bad][0]!r}, {yb[bad][0]!r}): {got[bad][0]!r} vs {want[bad][0]!r}"

@@ -14,7 +14,13 @@ KVAR = {"water_vapor": "water_vapor", "cloud_water": "cloud_water", "rain": "rai
         "ice_number": "ice_number_concentration", "rain_number": "rain_number_concentration"}
 
 
+# what the session's comparisons were (tests/conftest.py prints the totals at the end of a `-m gpu` run): fields compared bit for
+# bit (bits_equal: the int32 views, so signs of zero and NaN payloads count) and fields compared within a tolerance
+COUNTS = {"bit_exact_fields": 0, "tolerance_fields": 0}
+
+
 def bits_equal(a, b):
+    COUNTS["bit_exact_fields"] += 1
     return np.array_equal(np.ascontiguousarray(a).view(np.int32), np.ascontiguousarray(b).view(np.int32))
 
 
@@ -46,6 +52,7 @@ MPDATA_BEYOND_FRAC = 1e-5
 def assert_fields_close(got, ref, name="", rtol=MPDATA_RTOL, record=None):
     """every cell within rtol of the local field scale; record = (test, label): also write the measured local-scale error and
     the POINTWISE statistics (field_stats) to the parity record"""
+    COUNTS["tolerance_fields"] += 1
     err, where = local_rel_err(got, ref)
     st = field_stats(got, ref, rtol); st["max_over_local_scale"] = err
     if record is not None:
