@@ -43,7 +43,7 @@
 
 #define MP_HL 3                       // halo lanes per side
 #define MP_XOUT (64 - 2 * MP_HL)      // outputs per 64-lane tile
-#define MP_NW 8                       // waves per block at most: two per SIMD, ~250 VGPRs each
+#define MP_NW 8                       // waves per block at most: two per SIMD, ~250 VGPRs each (12 x 3 levels at three per SIMD: no faster, profiles/r05_steps.md)
 #define MP_KB 5                       // levels per thread at most
 #define MP_ZH 2                       // halo levels of a level range: a fake edge corrupts the outputs of the 2 levels next to it
 #define EPSQ 1e-10f
@@ -690,12 +690,7 @@ int icar_mpdata_fused_run(icar_hip_ctx *c, bool rho_on, bool fct, bool pass1, co
     nchunk = (rows + clen - 1) / clen;
     const bool exact = (nkr == 1) && (kb * nw == nz);          // the waves hold exactly the column: no per-slot level tests
 #define KBCASE(K) case K: launch_fused<K>(c, fct, pass1, exact, in, out, nv, nw, clen, ntile, nchunk, nkr, kstore); break;
-#ifdef MPX_DEV_KB5
-    switch (kb) { KBCASE(5) default:
-#else
-    switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) default:
-#endif
-        icar_set_error("mpdata: internal level-range error"); return 1; }
+    switch (kb) { KBCASE(1) KBCASE(2) KBCASE(3) KBCASE(4) KBCASE(5) default: icar_set_error("mpdata: internal level-range error"); return 1; }
 #undef KBCASE
     HIPCHK(hipGetLastError());
     return 0;
