@@ -611,8 +611,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     using MdGeneric = MpMode<false, 0>; using MdEven = MpMode<true, 0>; using MdOdd = MpMode<true, 1>;
     {
         // steady steps: P in [s0, s1] (possibly empty), taken in pairs; s0 - P0 = 4, so a pair starts on an even step parity.
-        // A steady step addresses planes P-1 .. P+3 without clamping: P + 3 <= ny - 1.
-        const int s0 = ja + 1, s1 = max(min(jb, ny - 4), s0 - 1);
+        // A steady step addresses planes P-1 .. P+3 without clamping: P + 3 <= ny - 1.  The last step of a chunk, P = jb + 1 (it
+        // completes and stores plane jb), is a steady one too wherever those planes exist: what it computes for plane jb + 1 is not stored.
+        const int s0 = ja + 1, s1 = max(min(jb + 1, ny - 4), s0 - 1);
         const int npair = (s1 - s0 + 1) / 2, s1p = s0 + 2 * npair - 1;
         for (int ph = 0; ph < 2; ++ph) {                           // generic warm-up, steady bulk, generic tail
             const int lo = ph ? s1p + 1 : P0, hi = ph ? jb + 1 : s0 - 1;
