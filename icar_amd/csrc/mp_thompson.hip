@@ -123,7 +123,6 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
                 float dt, ThTiles tl, int k0, int nk, int cpb)
 {
     extern __shared__ double lds_pack[];
-    th_lds_init(threadIdx.x, blockDim.x);
     // several (its..ite, jts..jte) tiles in one launch (process_halo's four strips): block -> tile by prefix offsets
     // XCD-aware order: workgroups go to the 8 XCDs round-robin; neighbouring column groups share 64-B lines (a group is
     // 24 B wide at nz = 40), so each XCD takes runs of XCD_RUN consecutive groups and the shared lines hit in its L2.
@@ -141,6 +140,8 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     const bool tall = tl.tall[t] != 0;
     const int first = tall ? tl.j0[t] + local * cpb : (tl.ib0[t] + local % tl.nbx[t]) * cpb;
     BlockComm x(lds_pack, threadIdx.x, blockDim.x, cpb, nk, tall ? 0 : i0 - first, tall ? tl.j1[t] - first : i1 - first);
+    x.th_init((double)TH_gonv_max);                       // the exchange areas that are combined with min / atomics
+    th_lds_init(threadIdx.x, blockDim.x);                 // (ends with the block barrier that also publishes th_init's stores)
     const int j = tall ? (x.active ? first + x.col : first) : tl.j0[t] + local / tl.nbx[t];
     const int i = tall ? i0 : (x.active ? first + x.col : max(i0, min(i1, first)));
     const int c = d.idx(i, k0 + x.k, j);
