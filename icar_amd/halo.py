@@ -85,7 +85,8 @@ class HaloComm:
         if dist.get_backend(self.group) == "nccl":
             # RCCL.  Every image must end up with the SAME transport, so the outcome of the initialisation is agreed on over the
             # launcher's own process group; if any image could not open its communicator (no librccl, a refused device ...) all of
-            # them fall back to the host-staged transport and say so (bench.py prints it: a degraded run, not a silent one).
+            # them raise -- or, with ICAR_ALLOW_HOST_STAGED=1, all of them fall back to the host-staged transport with a warning
+            # (bench.py refuses to time such a run either way).
             uid = ctypes.create_string_buffer(128)
             err = None
             try:
@@ -107,7 +108,15 @@ class HaloComm:
             if int(ok.item()) == 1:
                 return
             lib().icar_hip_comm_destroy(domain.ctx)
-            self.transport_note = "RCCL communicator not available on every image (%s): host-staged transport" % (err or "another image failed")
+            import os, sys
+            why = err or "another image failed"
+            # every image takes this branch together (the all_reduce above): they all raise, or they all degrade
+            if os.environ.get("ICAR_ALLOW_HOST_STAGED") != "1":
+                raise RuntimeError("HaloComm: the RCCL communicator is not available on every image (%s).  The host-staged "
+                                   "transport (POSIX shared memory, ~100x slower, one node only) is a functional path, not a "
+                                   "substitute: set ICAR_ALLOW_HOST_STAGED=1 to run on it anyway" % why)
+            self.transport_note = "RCCL communicator not available on every image (%s): host-staged transport (ICAR_ALLOW_HOST_STAGED=1)" % why
+            sys.stderr.write("icar_amd WARNING [image %d]: %s\n" % (rank + 1, self.transport_note))
         import os
         name = [f"icar_hip_{os.getpid()}_{id(self) & 0xffffff:x}" if rank == 0 else None]
         dist.broadcast_object_list(name, 0, group=self.group)

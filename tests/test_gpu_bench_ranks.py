@@ -106,3 +106,21 @@ def test_bench_refuses_a_degraded_transport_when_a_gpu_per_rank_is_there():
     out = _line(r)
     assert out["error"] == "transport self-check failed" and out["degraded_to_host_staged"] is True and "value" not in out
     assert out["halo_check"] == "ok" and out["ranks_seen"] == 1          # the host-staged transport itself works; it is refused for what it is
+
+
+def test_a_failed_rccl_init_is_an_error_unless_the_host_transport_is_asked_for():
+    """a library user whose RCCL communicator cannot be opened gets an error on every image, not a silent run on
+    the ~100x slower host-staged transport; ICAR_ALLOW_HOST_STAGED=1 (previous test) is the explicit opt-in."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ICAR_ALLOW_HOST_STAGED"):
+        env.pop(k, None)
+    env["ICAR_TEST_STRICT_TRANSPORT"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_rccl_fallback_child.py"), "--gpus", "1"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "ICAR_ALLOW_HOST_STAGED=1" in r.stderr and "RCCL communicator is not available on every image" in r.stderr
+    assert '"value"' not in r.stdout
