@@ -15,13 +15,13 @@ from icar_amd import build as B
 
 # (name of the section that ENDS at the anchor, anchor substring, occurrence (1-based), file)
 ANCHORS = [
-    ("launch: lds tables", "int bid = (int)blockIdx.x;", 1, "hip"),
+    ("launch: tile index, exchange areas cleared, lds tables", "    const int j = tall ? (x.active ?", 1, "hip"),
     ("index + loads issued", "th_column_lane(T, x, nk, dt, dz1d", 2, "hip"),
     ("-> start of level code", "dtsave = dt; odt = 1.f / dt; odts", 1, "inc"),
     ("working variables (first use of the loads; lami, lamr)", "/* no_micro needs the ice saturation", 1, "inc"),
-    ("ice saturation", "if (!x.any(active && !no_micro)) return false;", 1, "inc"),
-    ("x.any barrier", "GRAUPEL_CHAIN((temp < 270.65f", 1, "inc"),
-    ("graupel chain 0 (N0_exp, suffix-min, 2 pow)", "/* ---- per-level phase A", 1, "inc"),
+    ("ice saturation", "    /* :1363 (nothing to do in the whole column group", 1, "inc"),
+    ("chain 0: N0_exp, any + suffix-min exchange", "        GRAUPEL_SLOPE(vmin_)", 1, "inc"),
+    ("chain 0: slope (2 pow)", "/* ---- per-level phase A", 1, "inc"),
     ("A: saturation, diffu, visco", "            if (L_qs) {", 1, "inc"),
     ("A: snow moments", "/* rain slope, mean volume diameter, intercept", 1, "inc"),
     ("A: rain slope, N0_r, warm rain", "        vts_boost = 1.5f;", 1, "inc"),
@@ -37,13 +37,13 @@ ANCHORS = [
     ("B: snow moments", "/* input of the second graupel chain", 1, "inc"),
     ("B: xslw, N0_r", "if ((ssatw > eps) || (ssatw < -eps && L_qc))", 1, "inc"),
     ("B: condensation (Newton)", "if ((ssatw < -eps) && L_qr && (!(prw_vcd > 0.)))", 1, "inc"),
-    ("B: rain evaporation", "GRAUPEL_CHAIN(xslw_arr, 1)", 1, "inc"),
-    ("graupel chain 1", "/* ---- :2515-2650 terminal fall speeds", 1, "inc"),
-    ("fall speeds: rain, ice", "x.carry_down2x2(a_r, b_r, has_r", 1, "inc"),
-    ("carry-down exchange 1", "{   /* snow and graupel: both read", 1, "inc"),
-    ("fall speeds: snow, graupel", "x.carry_down2x2(a_s, b_s, has_s", 1, "inc"),
-    ("carry-down exchange 2", "h.vtrk = vtrk; h.vtnrk", 1, "inc"),
-    ("hand-off", "x.sed_plan4(h.c4", 1, "inc"),
+    ("B: rain evaporation", "    /* ---- :2379-2391 second graupel chain and", 1, "inc"),
+    ("chain 1 N0_exp + fall speeds of rain, ice, snow", "            const float pv_[5]", 1, "inc"),
+    ("exchange 1 (post, barrier)", "        const int k_ = x.k;", 1, "inc"),
+    ("gathers: rain, ice, snow", "        GRAUPEL_SLOPE(x.min_fall1())", 1, "inc"),
+    ("chain 1 minimum, slope, graupel speed", "        x.post_fall2(a_g);", 1, "inc"),
+    ("exchange 2 (post, barrier)", "            const int kg = x.above(3, k_)", 1, "inc"),
+    ("gather graupel, sub-step counts, hand-off", "x.plan4(h.c4", 1, "inc"),
     ("sedimentation plan exchange", "odzq = 1.f / dzq; orho = 1.f / rho;", 1, "inc"),
     ("sedimentation loop", "    h.rr = rr; h.nr = nr; h.ri = ri; h.ni = ni; h.rs = rs; h.rg = rg;\n    h.qrten = qrten; h.nrten = nrten; h.qiten = qiten; h.niten = niten; h.qsten = qsten; h.qgten = qgten;\n}", 1, "inc"),
     ("-> finish", "th_level_finish(T, dt, h, qv1d", 1, "inc"),
@@ -114,7 +114,7 @@ def main():
     hip = src["hip"]
     hip = hip.replace('#include "thompson_lane.inc"', STAMP + '#include "thompson_lane_prof.inc"', 1)
     # first stamp of a block: reset, before the table copy; last: flush (before the early return of idle threads)
-    hip = insert(hip, "    extern __shared__ double lds_pack[];\n    th_lds_init(threadIdx.x, blockDim.x);", 1, "    TH_STAMP(-1) __syncthreads();\n")
+    hip = insert(hip, "    // several (its..ite, jts..jte) tiles in one launch", 1, "    TH_STAMP(-1) __syncthreads();\n")
     hip = insert(hip, "    if (!x.active) return;\n    if (x.k == 0) {", 1, "    TH_STAMP(64)\n")
     hip = insert(hip, "        HIPCHK(hipGetLastError());\n        return 0;\n    }\n    if (nk > 64)", 1, DUMP)
     hip = hip.replace("#include <cstring>", "#include <cstring>\n#include <cstdio>", 1)
