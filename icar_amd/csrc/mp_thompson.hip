@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstddef>
 
 const ThState *icar_thompson_device_state(icar_hip_ctx *c);
 const ThState *icar_thompson_host_state(icar_hip_ctx *c);
@@ -105,6 +106,18 @@ k_thompson_lane(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
 }
 
 struct ThTiles { int n, i0[4], i1[4], j0[4], j1[4], tall[4], ib0[4], nbx[4], off[5], xcd_run; };
+// The leading arguments of k_thompson_pack as they lie in its kernel-argument segment (by-value parameters in order, each at its
+// natural alignment = this struct's layout).  The kernel reads the field pointers a second time from that segment behind the level
+// code, for the stores, instead of keeping them (or nine 64-bit store addresses) in registers through the level code.  The
+// parameters themselves stay separate `__restrict__` pointers: as members of one struct argument they lose `noalias`, and the ~180
+// scalar loads of scheme parameters through T become vector loads (measured).
+struct ThPackArgs {
+    Dims d; const ThState *T;
+    float *qv, *qc, *qr, *qi, *qs, *qg, *ni, *nr, *th; const float *pii, *p, *dz;
+    double *rain_acc, *snow_acc, *graupel_acc;
+};
+static_assert(offsetof(ThPackArgs, T) == ((sizeof(Dims) + 7) & ~(size_t)7) && offsetof(ThPackArgs, qv) == offsetof(ThPackArgs, T) + 8
+              && offsetof(ThPackArgs, graupel_acc) == offsetof(ThPackArgs, qv) + 14 * 8, "ThPackArgs mirrors the kernel's argument list");
 
 // cpb whole columns per block (aligned to multiples of cpb in i), thread = level*cpb + column (thompson_lane.inc: BlockComm)
 // MAXT = largest block this instantiation is launched with.  Blocks of up to 512 threads (columns of up to 512 levels) get the
@@ -145,24 +158,40 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     const int j = tall ? (x.active ? first + x.col : first) : tl.j0[t] + local / tl.nbx[t];
     const int i = tall ? i0 : (x.active ? first + x.col : max(i0, min(i1, first)));
     const int c = d.idx(i, k0 + x.k, j);
-    const float pi_ = pii[c];
-    float t1d = th[c] * pi_, p1d = p[c], dz1d = dz[c], qv1d = qv[c], qc1d = qc[c], qi1d = qi[c], qr1d = qr[c], qs1d = qs[c],
-          qg1d = qg[c], ni1d = ni[c], nr1d = nr[c];
+    // One 32-bit byte offset for all twelve fields (base pointers stay in SGPRs: global_load v, v_off, s[base]); with `field[c]` the
+    // compiler keeps a 64-bit address pair per field alive from the loads to the stores -- 24 VGPRs through the whole level code,
+    // which is what it then spills (round 5).  (A field is < 4 GiB: the host checks the tile.)
+    const unsigned boff = ((unsigned)c & 0x3fffffffu) * 4u;
+#define TH_LD(p) (*(const float *)((const char *)(p) + boff))
+#define TH_ST(p, v) (*(float *)((char *)(p) + boff) = (v))
+    const float pi_ = TH_LD(pii);
+    float t1d = TH_LD(th) * pi_, p1d = TH_LD(p), dz1d = TH_LD(dz), qv1d = TH_LD(qv), qc1d = TH_LD(qc), qi1d = TH_LD(qi), qr1d = TH_LD(qr),
+          qs1d = TH_LD(qs), qg1d = TH_LD(qg), ni1d = TH_LD(ni), nr1d = TH_LD(nr);
     float pptrain = 0.f, pptsnow = 0.f, pptgraul = 0.f, pptice = 0.f;
     th_column_lane(T, x, nk, dt, dz1d, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, t1d, p1d, pptrain, pptsnow, pptgraul, pptice);
     if (!x.active) return;
+    // the argument segment again, through a pointer the compiler cannot connect with the reads at the top
+    const ThPackArgs *ka = (const ThPackArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
     if (x.k == 0) {
-        const int c2 = i + d.nx * j;
+        const int c2 = i + ka->d.nx * j;
         const float rainnc = 0.f + pptrain + pptsnow + pptgraul + pptice;
         const float snownc = 0.f + pptsnow + pptice;
         const float graupelnc = 0.f + pptgraul;
-        rain_acc[c2] = rain_acc[c2] + rainnc;
-        snow_acc[c2] = snow_acc[c2] + snownc;
-        graupel_acc[c2] = graupel_acc[c2] + graupelnc;
+        double *ra = ka->rain_acc, *sa = ka->snow_acc, *ga = ka->graupel_acc;
+        ra[c2] = ra[c2] + rainnc;
+        sa[c2] = sa[c2] + snownc;
+        ga[c2] = ga[c2] + graupelnc;
     }
-    qv[c] = (qv1d < 1.E-7f) ? 1.E-7f : qv1d;              // :997-1010
-    qc[c] = qc1d; qi[c] = qi1d; qr[c] = qr1d; qs[c] = qs1d; qg[c] = qg1d; ni[c] = ni1d; nr[c] = nr1d;
-    th[c] = t1d / pi_;
+    unsigned boff2 = boff;
+    asm volatile("" : "+v"(boff2));
+#undef TH_ST
+#define TH_ST(p, v) (*(float *)((char *)(ka->p) + boff2) = (v))
+    TH_ST(qv, (qv1d < 1.E-7f) ? 1.E-7f : qv1d);              // :997-1010
+    TH_ST(qc, qc1d); TH_ST(qi, qi1d); TH_ST(qr, qr1d); TH_ST(qs, qs1d); TH_ST(qg, qg1d); TH_ST(ni, ni1d); TH_ST(nr, nr1d);
+    TH_ST(th, t1d / pi_);
+#undef TH_LD
+#undef TH_ST
 }
 
 __global__ void k_thompson_constants(ThState *T, float rg, float xslw1)
