@@ -215,6 +215,7 @@ static int substep_open(icar_hip_ctx *c, double dt, bool dt_known, bool &wreal_l
         if (aux.begin()) return 1;
         if (icar_mp_run(c, dt, 1, -1)) return 1;                                  // :512 strips
         if (halo_send(c)) return 1;                                               // :515 pack + RCCL send / recv
+        if (halo_retrieve(c)) return 1;                                           // :526 unpack, see icar_substep
         if (face_later && icar_diagnostic_update_run(c, ICAR_DIAG_FACE)) return 1;
         if (dt_known && adv && setup_winds(c, (float)dt)) return 1;
     }
@@ -258,7 +259,6 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
             if (setup_winds(c, dtf)) return 1;
         }
         if (icar_hip_aux_join(c)) return 1;
-        if (halo_retrieve(c)) return 1;                                           // :526
     } else
     if (g.diagnostics) {                                                          // :474
         if (g.microphysics != kMP_WSM3) {                                         // WSM3 reads w_real
@@ -302,6 +302,11 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
             if (aux.begin()) return 1;
             if (icar_mp_run(c, dt, 1, -1)) return 1;                              // :512 strips (the halo pass leaves last_model_time alone, :711)
             if (halo_send(c)) return 1;                                           // :515 pack + RCCL send / recv
+            // :526 halo_retrieve fills the cells OUTSIDE the owned tile; the microphysics is column-local and runs on owned
+            // columns only, so the interior pass neither reads nor writes them: the unpack follows the receive on the second
+            // stream instead of waiting for the interior launch on the main one (one kernel + one dependency edge off the
+            // critical path: ~15 us per sub-step)
+            if (halo_retrieve(c)) return 1;
             if (face_later && icar_diagnostic_update_run(c, ICAR_DIAG_FACE)) return 1;
             // the Courant winds (and MPDATA coefficients) read u, v, w, density and the jacobians, none of which the microphysics
             // touches: streaming kernels beside the VALU-bound interior launch
@@ -309,7 +314,6 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
         }
         c->step.mp_last_model_time = mp_last_after;
         if (icar_hip_aux_join(c)) return 1;
-        if (halo_retrieve(c)) return 1;                                           // :526
     } else {
         if (halo_send(c)) return 1;
         if (halo_retrieve(c)) return 1;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of the builds under icar_amd/lib/ab on the bench step at three tile sizes (two runs each): ab_step.sh
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
+for rep in 1 2; do
+for so in icar_amd/lib/ab/lib_*.so; do
+  n=$(basename $so .so)
+  for a in "--nx 258 --ny 130" "--nx 258 --ny 258" "--nx 512 --ny 512"; do
+  ICAR_HIP_LIB=$R/$so timeout 200 python bench.py --no-cpu-baseline --steps 20 --warmup 5 $a --nz 40 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('$n', d['config']['tile_memory'], 'ms/step %.4f' % d['ms_per_step'], 'advect %.4f' % (r.get('avg_ms') or 0), 'mp %.4f' % (r.get('mp_ms_per_step') or 0))"
+  done
+done; done
