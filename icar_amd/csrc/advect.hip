@@ -46,12 +46,17 @@ __device__ __forceinline__ TileId xcd_tile(unsigned rows)
     return t;
 }
 
-template <int SCHEME, bool RHO>
+// WREAL: also w_real of diagnostic_update (time_step.f90:165-194) for the interior columns -- the same expression and operand order
+// as k_diag_wreal (step.hip), from the winds this kernel reads anyway.  The sub-step asks for it (timestep.hip): beside the
+// advection those 0.3 GB of reads cost the latency-bound MPDATA kernel 40 us, here they add three static arrays to a streaming kernel
+// beside the microphysics.
+template <int SCHEME, bool RHO, bool WREAL>
 __global__ void __launch_bounds__(BX * BY)
 k_setup_winds(Dims d, const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
               const float *__restrict__ rho, const float *__restrict__ ju, const float *__restrict__ jv,
               const float *__restrict__ jw, const float *__restrict__ dz, float dt, float dx,
-              float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float *__restrict__ Wdz)
+              float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float *__restrict__ Wdz,
+              const float *__restrict__ dzdx, const float *__restrict__ dzdy, const float *__restrict__ jaco, float *__restrict__ w_real)
 {
     const TileId tb = xcd_tile(4);
     const int i = tb.x * BX + threadIdx.x;
@@ -61,23 +66,30 @@ k_setup_winds(Dims d, const float *__restrict__ u, const float *__restrict__ v, 
     const int c = d.idx(i, k, j);
     const float r0 = RHO ? rho[c] : 1.0f;
     float Uv = 0.0f, Vv = 0.0f, Wv;
+    const int cu = i + (d.nx + 1) * (k + d.nz * j);
+    const float uc = u[cu], vc = v[c], wc = w[c];
     if (i >= 1) {
         const float rl = RHO ? rho[c - 1] : 1.0f;
-        const int cu = i + (d.nx + 1) * (k + d.nz * j);
-        if (SCHEME == 1) Uv = u[cu] * dt * ju[cu] * (r0 + rl) * 0.5f / dx;      // advect.f90:345
-        else             Uv = u[cu] * dt * (r0 + rl) * 0.5f * ju[cu] / dx;      // adv_mpdata.f90:500
+        if (SCHEME == 1) Uv = uc * dt * ju[cu] * (r0 + rl) * 0.5f / dx;      // advect.f90:345
+        else             Uv = uc * dt * (r0 + rl) * 0.5f * ju[cu] / dx;      // adv_mpdata.f90:500
     }
     if (j >= 1) {
         const float rl = RHO ? rho[c - d.sj] : 1.0f;
-        if (SCHEME == 1) Vv = v[c] * dt * jv[c] * (r0 + rl) * 0.5f / dx;
-        else             Vv = v[c] * dt * (r0 + rl) * 0.5f * jv[c] / dx;
+        if (SCHEME == 1) Vv = vc * dt * jv[c] * (r0 + rl) * 0.5f / dx;
+        else             Vv = vc * dt * (r0 + rl) * 0.5f * jv[c] / dx;
     }
     if (k < d.nz - 1) {
         const float ru = RHO ? rho[c + d.sk] : 1.0f;
-        Wv = w[c] * dt * jw[c] * (ru + r0) * 0.5f;
+        Wv = wc * dt * jw[c] * (ru + r0) * 0.5f;
     } else
-        Wv = w[c] * dt * jw[c] * r0;
+        Wv = wc * dt * jw[c] * r0;
     U[c] = Uv; V[c] = Vv; W[c] = Wv; Wdz[c] = Wv / dz[c];
+    if (WREAL && i >= 1 && i < d.nx - 1 && j >= 1 && j < d.ny - 1) {
+        const float uw0 = uc * dzdx[cu], uw1 = u[cu + 1] * dzdx[cu + 1];                    // uw(i), uw(i+1)
+        const float vw0 = vc * dzdy[c], vw1 = v[c + d.sj] * dzdy[c + d.sj];                // vw(j), vw(j+1)
+        const float lastw = (k > 0) ? w[c - d.sk] : 0.0f;
+        w_real[c] = (uw0 + uw1) * 0.5f + (vw0 + vw1) * 0.5f + jaco[c] * (lastw + wc) * 0.5f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -159,8 +171,10 @@ static int ensure_adv_scratch(icar_hip_ctx *c)
     return 0;
 }
 
-int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density)
+// with_wreal: also w_real (diagnostic_update part 2) from the same winds; *wreal_done says whether the fields for it were there
+int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density, bool with_wreal, bool *wreal_done)
 {
+    if (wreal_done) *wreal_done = false;
     if (scheme != ICAR_ADV_UPWIND && scheme != ICAR_ADV_MPDATA) { icar_set_error("setup_winds: bad scheme"); return 1; }
     if (ensure_adv_scratch(c)) return 1;
     const float *u = icar_field_f(c, ICAR_F_U), *v = icar_field_f(c, ICAR_F_V), *w = icar_field_f(c, ICAR_F_W);
@@ -168,12 +182,21 @@ int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int
     const float *jw = icar_field_f(c, ICAR_F_JACOBIAN_W), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
     const float *rho = advect_density ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
     if (!u || !v || !w || !ju || !jv || !jw || !dz || (advect_density && !rho)) return 1;
+    const float *dzdx = nullptr, *dzdy = nullptr, *jaco = nullptr; float *wr = nullptr;
+    if (with_wreal) {
+        dzdx = (const float *)c->field[ICAR_F_DZDX]; dzdy = (const float *)c->field[ICAR_F_DZDY]; jaco = (const float *)c->field[ICAR_F_JACOBIAN];
+        if (dzdx && dzdy && jaco) { wr = icar_field_f(c, ICAR_F_W_REAL, false); if (!wr) return 1; }
+        else with_wreal = false;                         // (diagnostic_update leaves w_real alone without them, too)
+    }
     ScopedTimer t(c, "winds");
     dim3 g = grid3(c->d), b(BX, BY);
-#define LAUNCH(S, R) hipLaunchKernelGGL((k_setup_winds<S, R>), g, b, 0, c->stream, c->d, u, v, w, rho, ju, jv, jw, dz, dt, dx, c->U, c->V, c->W, c->Wdz)
-    if (scheme == 1) { if (advect_density) LAUNCH(1, true); else LAUNCH(1, false); }
-    else             { if (advect_density) LAUNCH(2, true); else LAUNCH(2, false); }
+#define LAUNCH(S, R, WR) hipLaunchKernelGGL((k_setup_winds<S, R, WR>), g, b, 0, c->stream, c->d, u, v, w, rho, ju, jv, jw, dz, dt, dx, c->U, c->V, c->W, c->Wdz, dzdx, dzdy, jaco, wr)
+#define LAUNCH2(S, R) { if (with_wreal) LAUNCH(S, R, true); else LAUNCH(S, R, false); }
+    if (scheme == 1) { if (advect_density) LAUNCH2(1, true) else LAUNCH2(1, false) }
+    else             { if (advect_density) LAUNCH2(2, true) else LAUNCH2(2, false) }
+#undef LAUNCH2
 #undef LAUNCH
+    if (wreal_done) *wreal_done = with_wreal;
     HIPCHK(hipGetLastError());
     // MPDATA: everything of the corrective iteration that does not depend on the scalar, once per step (mpdata.hip)
     if (scheme == ICAR_ADV_MPDATA && icar_mpdata_coef_run(c, advect_density != 0)) return 1;

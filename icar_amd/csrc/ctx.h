@@ -108,7 +108,7 @@ struct ScopedTimer {
 };
 
 // kernels implemented in the .hip files
-int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density);
+int icar_advect_setup_winds(icar_hip_ctx *c, int scheme, float dt, float dx, int advect_density, bool with_wreal = false, bool *wreal_done = nullptr);
 int icar_advect_run(icar_hip_ctx *c, int scheme, int order, int fct, int advect_density, const int *fields, int n);
 int icar_mp_simple_run(icar_hip_ctx *c, float dt, int its, int ite, int jts, int jte, int kts, int kte, int *err);
 int icar_mp_simple_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int tiles[][4], int kts, int kte, int *err);

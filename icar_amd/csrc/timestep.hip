@@ -93,10 +93,11 @@ static bool winds_prepared(icar_hip_ctx *c, float dt)
     return c->winds_valid && c->step.winds_scheme == g.advection && c->step.winds_dt == dt && c->step.winds_dens == (g.advect_density ? 1 : 0);
 }
 
-static int setup_winds(icar_hip_ctx *c, float dt)
+// with_wreal: w_real of diagnostic_update from the same winds in the same launch (advect.hip); *wreal_done: it was written
+static int setup_winds(icar_hip_ctx *c, float dt, bool with_wreal = false, bool *wreal_done = nullptr)
 {
     const icar_hip_step_config &g = c->step.cfg;
-    return icar_advect_setup_winds(c, g.advection, dt, g.dx, g.advect_density);      // records (scheme, dt, density) in c->step
+    return icar_advect_setup_winds(c, g.advection, dt, g.dx, g.advect_density, with_wreal, wreal_done);   // records (scheme, dt, density) in c->step
 }
 
 int icar_step_advect(icar_hip_ctx *c, float dt)
@@ -246,7 +247,7 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
     const float dtf = (float)dt;
     const bool adv = (g.advection == ICAR_ADV_UPWIND || g.advection == ICAR_ADV_MPDATA);
     const bool stepping = dt > 1e-3;                                              // :483
-    bool wreal_later = false, face_later = false;
+    bool wreal_later = false, face_later = false, wreal_done = false;
     const bool early = c->step.early_open;
     c->step.early_open = false;
     if (early) {
@@ -256,7 +257,7 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
         if (adv) {
             AuxScope aux(c);
             if (aux.begin()) return 1;
-            if (setup_winds(c, dtf)) return 1;
+            if (setup_winds(c, dtf, wreal_later, &wreal_done)) return 1;
         }
         if (icar_hip_aux_join(c)) return 1;
     } else
@@ -309,8 +310,9 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
             if (halo_retrieve(c)) return 1;
             if (face_later && icar_diagnostic_update_run(c, ICAR_DIAG_FACE)) return 1;
             // the Courant winds (and MPDATA coefficients) read u, v, w, density and the jacobians, none of which the microphysics
-            // touches: streaming kernels beside the VALU-bound interior launch
-            if (adv && setup_winds(c, dtf)) return 1;
+            // touches: streaming kernels beside the interior launch.  w_real of diagnostic_update (from these winds, before
+            // their forcing) comes out of the same launch: beside the advection its reads cost the MPDATA kernel 40 us
+            if (adv && setup_winds(c, dtf, wreal_later, &wreal_done)) return 1;
         }
         c->step.mp_last_model_time = mp_last_after;
         if (icar_hip_aux_join(c)) return 1;
@@ -340,7 +342,7 @@ int icar_substep(icar_hip_ctx *c, double dt, bool enforce)
         {
             AuxScope aux(c);
             if (aux.begin()) return 1;
-            if (wreal_later && icar_diagnostic_update_run(c, 2)) return 1;        // :165-194, from the winds of this step (before their forcing)
+            if (wreal_later && !wreal_done && icar_diagnostic_update_run(c, 2)) return 1;   // :165-194, from the winds of this step (before their forcing)
             if (na && icar_apply_forcing_run(c, dt, aside_f, aside_b, na, g.west_boundary, g.east_boundary, g.south_boundary, g.north_boundary)) return 1;
             // (with RCCL the tile maximum is also all-reduced over the images here, in the advection's shadow)
             if (cfl_ahead && icar_max_courant_prefetch_run(c, g.dx, c->step.dz_levels.data(), c->comm && icar_hip_comm_kind(c) == ICAR_COMM_RCCL)) return 1;
