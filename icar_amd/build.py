@@ -67,6 +67,38 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def kernel_resources(src, extra=()):
+    """{kernel name: {"VGPRs": .., "ScratchSize [bytes/lane]": .., "Occupancy [waves/SIMD]": .., "SGPRs Spill": .., "VGPRs Spill": ..,
+    "TotalSGPRs": .., "AGPRs": .., "LDS Size [bytes/block]": ..}} of one source of SOURCES, compiled with the product's flags: the
+    compiler's -Rpass-analysis=kernel-resource-usage remarks.  What the performance of k_mpdata_fused and k_thompson_pack rests on
+    (two / four waves per SIMD, nothing of the march in scratch) is decided by the register allocator, not by the source:
+    tests/test_kernel_resources.py holds the numbers, profiles/micro/resources.py prints them."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="icar_res_") as tmp:
+        cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(src, []) + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.path.join(tmp, "o.o")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{src}: hipcc failed:\n{r.stderr[-2000:]}")
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark:\s+(.*?)\s+\[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1)
+        if t.startswith("Function Name:"):
+            name = subprocess.run(["c++filt", t.split(":", 1)[1].strip()], capture_output=True, text=True).stdout.strip()
+            name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "")
+            cur = out.setdefault(name, {})
+        elif cur is not None and ":" in t:
+            k, v = t.split(":", 1)
+            try:
+                cur[k.strip()] = int(v.strip())
+            except ValueError:
+                cur[k.strip()] = v.strip()
+    return out
+
+
 FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
 FDIR = os.path.join(HERE, "fortran")
 DEMO = os.path.join(LIBDIR, "icar_hip_demo")

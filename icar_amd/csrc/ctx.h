@@ -39,8 +39,13 @@ struct IcarStepState {
     int winds_scheme = 0, winds_dens = 0; float winds_dt = 0.f;   // what the Courant winds on the device were set up for
     float *h_val = nullptr;                  // pinned: the reduced CFL maximum
     bool early_open = false, early_wreal = false, early_face = false;   // a sub-step whose dt-independent opening is already in flight
+    bool failed = false;                 // a sub-step was abandoned half-applied (timestep.hip: update_dt_opened): the fields are not a model state any more
     bool winds_first = true;                 // wind.f90:297 `.not. allocated(domain%sintheta)`: update_winds has not run yet
 };
+
+// the arrays of icar_hip_ctx::mpc, each of the tile's shape (k_mpdata_coef in mpdata.hip says what they hold): the first nine are the
+// antidiffusive coefficients of the x / y / z faces, the last four the donor-cell pass's denominators and their reciprocals
+enum { MPC_AU = 0, MPC_CUV, MPC_CUW, MPC_AV, MPC_CVU, MPC_CVW, MPC_AW, MPC_CWU, MPC_CWV, MPC_RDH, MPC_RDV, MPC_GH, MPC_GV, MPC_N };
 
 struct icar_hip_ctx {
     int device = 0;
@@ -57,7 +62,7 @@ struct icar_hip_ctx {
     float *dqdt[ICAR_N_FIELDS] = {nullptr};    // variable_t%dqdt_3d mirrors (apply_forcing)
     // advection scratch (A1-A5)
     float *U = nullptr, *V = nullptr, *W = nullptr, *Wdz = nullptr;
-    float *mpc = nullptr;                // MPDATA: the eleven scalar-independent coefficient arrays of this step's winds (mpdata.hip)
+    float *mpc = nullptr;                // MPDATA: the MPC_N scalar-independent coefficient arrays of this step's winds (mpdata.hip)
     int mpc_dens = -1;
     float *alt[ICAR_N_ADVECTABLE] = {nullptr};   // ping-pong partner of each advected scalar
     float *mpx_buf = nullptr;            // mpdata_exact.hip: q2 (x2), u2, v2, w2 of mpx_nv scalars and the limited velocities of one

@@ -1,4 +1,8 @@
 // icar_amd/csrc/glibc_dbl64.h -- exp / log / pow in DOUBLE PRECISION exactly as the compiled reference evaluates them.
+// Origin and licence: restated from the GNU C Library 2.35 (sysdeps/ieee754/dbl-64/e_exp.c, e_log.c, e_pow.c and their *_data.c),
+// Copyright (C) Free Software Foundation, Inc. / Arm Ltd. ("optimized routines"), distributed under the GNU Lesser General Public
+// License, version 2.1 or later (the Arm originals also under the MIT licence).  The algorithms and table constants are theirs;
+// this file is a derived work under the same terms.
 //
 // The Thompson scheme's DOUBLE PRECISION sites (mp_thompson.f90: N0_r, N0_g, lam_exp, the collection / evaporation / melting
 // integrals, the bin indices) call the C library's pow / log / exp.  Until round 4 the device evaluated them with its own

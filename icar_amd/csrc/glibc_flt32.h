@@ -1,4 +1,9 @@
 // icar_amd/csrc/glibc_flt32.h -- expf / logf / log10f / powf / atanf exactly as the compiled reference evaluates them.
+// Origin and licence: restated from the GNU C Library 2.35 (sysdeps/ieee754/flt-32/e_expf.c, e_logf.c, e_powf.c with math_config.h's
+// data tables: Copyright (C) Free Software Foundation, Inc. / Arm Ltd., "optimized routines"; e_log10f.c, s_atanf.c: Copyright (C)
+// 1993 Sun Microsystems, Inc. (fdlibm), as distributed in glibc), GNU Lesser General Public License 2.1 or later (the Arm originals
+// also MIT; fdlibm: "permission to use, copy, modify, and distribute this software is freely granted, provided that this notice is
+// preserved").  The algorithms and constants are theirs; this file is a derived work under the same terms.
 //
 // The reference is Fortran; flang lowers REAL(4) exp / log / log10 / x**y / atan to the C library's expf / logf / log10f /
 // powf / atanf, and the image's C library is glibc 2.35 (not vendored in /root/reference).  Its float functions are the

@@ -2,16 +2,22 @@
 //
 // Reference: src/physics/mp_thompson.f90 -- mp_gt_driver :772-1044 (column gather/scatter, i_end/j_end
 // clipping, precipitation accumulation, the qv floor of :997-1010) and mp_thompson :1057-2844 (the
-// 1-D column physics).  One column per lane, lanes along i so every level-k access of a
-// wave is one coalesced row.  State is REAL(4), rates and lookup-table values REAL(8) exactly as in
-// the reference; table indices are integer-exact.  Float transcendentals are evaluated in FP64 and
-// rounded once (within 1 ulp of the host libm the reference uses; see tests/test_gpu_thompson.py).
+// 1-D column physics).  State is REAL(4), rates and lookup-table values REAL(8) exactly as in the reference; table indices are
+// integer-exact; REAL(4) and DOUBLE PRECISION transcendentals restate the glibc 2.35 builds the reference links (glibc_flt32.h,
+// glibc_dbl64.h): every column is bit-identical to the compiled reference's (tests/test_gpu_thompson.py).
 //
-// The reference keeps ~130 per-level work arrays.  Here the per-level phases are fused (saturation /
-// snow moments / rain slopes / warm rain / frozen processes / conservation / tendencies in one level
-// loop; TAU+1 update / condensation / rain evaporation in a second) so that all process rates are
-// registers; only the state that crosses levels (graupel N0 chain, fall-speed carry-down,
-// sedimentation) stays in lane-interleaved private arrays.
+// Layout of the product kernel k_thompson_pack: ONE LEVEL PER THREAD -- a block packs several whole columns, a thread owns one
+// (column, level) cell and runs the level code (thompson_lane.inc) on registers; what crosses levels (the graupel N0 chain, the
+// fall-speed carry-down, the four sedimentation sweeps, the column's "anything to do" flags) goes through five one-barrier LDS
+// exchanges per column (column_comm.h).  The ~130 per-level work arrays of the reference are registers of the level's thread.
+// (k_thompson_lane is the same level code with one column per WAVE, one level per lane: the fallback for level counts the packing
+// does not cover.)
+// This departs from north_star's "one column per lane, lanes along i".  That layout -- a lane marches through its column with the
+// cross-level state in lane-interleaved private arrays -- was built and measured in round 4: 2.40 ms against 1.77 ms for the
+// level-per-thread form at 512 x 512 x 40 (profiles/r04_thompson_layout.md), and then removed.  With 40 levels a column per lane
+// leaves 512 x 512 = 262144 lanes, 4 waves per SIMD of a kernel that wants > 128 VGPRs per lane; a level per thread gives 40 x as
+// many lanes to hide the FP64 table and division latencies with.  Loads and stores of a wave are rows of consecutive i at one level
+// in both layouts (memory order (i, k, j)).
 #include "ctx.h"
 #include "thompson_math.h"     // the level code's transcendentals and decade indices (shared with tests/support/th_probe.hip)
 #include "column_comm.h"
@@ -160,8 +166,8 @@ k_thompson_pack(Dims d, const ThState *__restrict__ T, float *__restrict__ qv, f
     const int c = d.idx(i, k0 + x.k, j);
     // One 32-bit byte offset for all twelve fields (base pointers stay in SGPRs: global_load v, v_off, s[base]); with `field[c]` the
     // compiler keeps a 64-bit address pair per field alive from the loads to the stores -- 24 VGPRs through the whole level code,
-    // which is what it then spills (round 5).  (A field is < 4 GiB: the host checks the tile.)
-    const unsigned boff = ((unsigned)c & 0x3fffffffu) * 4u;
+    // which is what it then spills (round 5).  (A field is < 4 GiB: icar_thompson_run_tiles checks.)
+    const unsigned boff = (unsigned)c * 4u;
 #define TH_LD(p) (*(const float *)((const char *)(p) + boff))
 #define TH_ST(p, v) (*(float *)((char *)(p) + boff) = (v))
     const float pi_ = TH_LD(pii);
@@ -227,6 +233,7 @@ int icar_thompson_run_tiles(icar_hip_ctx *c, float dt, int ntiles, const int (*t
     if (!T) { icar_set_error("thompson: call icar_hip_thompson_init first"); return 1; }
     if (ntiles < 1 || ntiles > 4) { icar_set_error("thompson: 1..4 tiles per call"); return 1; }
     if (kts < c->kms || kte > c->kme || kte < kts) { icar_set_error("thompson: levels outside memory bounds"); return 1; }
+    if (c->n3 * sizeof(float) >= ((size_t)1 << 31)) { icar_set_error("thompson: a field of 2 GiB or more is not supported (32-bit byte offsets)"); return 1; }
     float *qv = icar_field_f(c, ICAR_F_WATER_VAPOR), *qc = icar_field_f(c, ICAR_F_CLOUD_WATER), *qr = icar_field_f(c, ICAR_F_RAIN);
     float *qi = icar_field_f(c, ICAR_F_CLOUD_ICE), *qs = icar_field_f(c, ICAR_F_SNOW), *qg = icar_field_f(c, ICAR_F_GRAUPEL);
     float *ni = icar_field_f(c, ICAR_F_ICE_NUMBER), *nr = icar_field_f(c, ICAR_F_RAIN_NUMBER);

@@ -65,6 +65,15 @@ __device__ __forceinline__ float dpp_r2(float x, float o)
 __device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }   // keeps max(max(a, b), c) two DPP-foldable v_max instead of v_max3 + two moves
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float upw(float l, float r, float U) { return U * (U > 0.0f ? l : r); }      // == flux1 (adv_mpdata.f90:40)
+// a / g rounded ONCE, from r = RN(1 / g) (k_mpdata_coef): y = RN(a r) is within 2 ulp of the quotient, e = a - g y is exact in an
+// fma, and RN(y + e r) is then a / g + (a / g - y) O(2^-24): the correctly rounded quotient unless a / g lies within ~2^-23 ulp of a
+// rounding boundary (no such pair in 1e11 random ones, profiles/r06_steps.md; Markstein's second step would make it a theorem).
+// The donor-cell pass divides this way: its result q2 decides the limiter's all-or-nothing factors next to the ring (see there).
+__device__ __forceinline__ float exact_quot(float a, float g, float r)
+{
+    const float y = opaque(a * r);
+    return __builtin_fmaf(__builtin_fmaf(-g, y, a), r, y);
+}
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 // Global accesses are raw buffer loads / stores: descriptor (4 SGPRs per array) + per-lane byte offset (one VGPR, the
@@ -76,15 +85,17 @@ __device__ __forceinline__ float ldb(rsrc_t r, int voff, int soff) { return __bu
 __device__ __forceinline__ void stb(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0); }
 // ------------------------------------------------------------------------------------------------
 // scalar-independent coefficients of the corrective iteration (mpdata_fluxes, adv_mpdata.f90:107-255), once per step
-// eleven arrays of the tile's shape in one buffer (MPC_* = index of the array):
+// thirteen arrays of the tile's shape in one buffer (MPC_* = index of the array):
 //   x face (i-1/2) of cell (i,k,j):        au, cuv, cuw
 //   y face between j-1 and j:              av, cvu, cvw
 //   z face above level k:                  (aw, cwu, cwv) * dz(k) ; zero for the top level (w2(kme) = 0, :214)
-//   cell:                                  1 / (jaco rho), 1 / (jaco rho dz)
+//   cell:                                  RN(1 / Gh), RN(1 / Gv), Gh = jaco rho, Gv = (dz jaco) rho -- the donor-cell pass's two
+//                                          denominators in the reference's association (adv_mpdata.f90:86-99), and their correctly
+//                                          rounded reciprocals (zero on the ring cells): see exact_quot() in k_mpdata_fused
 // a? = |C| (1 - 2 |C| / (G + G')) / 2 ;  c?? = C (sum of the 4 transverse Courant numbers around the face) / (16 (G + G'))
 // with G = jaco [rho]; cross terms through the ground / column top (k-1, k+1 missing) and in the x ring are zero.
 // ------------------------------------------------------------------------------------------------
-enum { MPC_AU = 0, MPC_CUV, MPC_CUW, MPC_AV, MPC_CVU, MPC_CVW, MPC_AW, MPC_CWU, MPC_CWV, MPC_RDH, MPC_RDV, MPC_N };
+// (enum MPC_*: ctx.h)
 template <bool RHO>
 __global__ void __launch_bounds__(256)
 k_mpdata_coef(Dims d, const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ Wz, const float *__restrict__ rho,
@@ -127,7 +138,9 @@ k_mpdata_coef(Dims d, const float *__restrict__ U, const float *__restrict__ V, 
     // ring cells keep their value (adv_mpdata.f90:63-65): with a zero here the donor-cell pass and the final update of
     // k_mpdata_fused return q there without a test
     const bool ring = (i == 0) || (i == nx - 1) || (j == 0) || (j == ny - 1);
-    C[MPC_RDH * n3 + c] = ring ? 0.0f : frcp(g); C[MPC_RDV * n3 + c] = ring ? 0.0f : frcp(dzc * g);
+    const float gh = g, gv = RHO ? (dzc * jaco[c]) * rho[c] : dzc * jaco[c];        // (dz * jaco * rho is evaluated left to right)
+    C[MPC_RDH * n3 + c] = ring ? 0.0f : 1.0f / gh; C[MPC_RDV * n3 + c] = ring ? 0.0f : 1.0f / gv;   // IEEE divisions (build flag)
+    C[MPC_GH * n3 + c] = gh; C[MPC_GV * n3 + c] = gv;
 }
 
 // mode of one step of the march: generic (any plane, rolls by copying) or one half of a steady pair (its exchange-buffer parity)
@@ -162,7 +175,7 @@ template <int KB, bool FCT, bool PASS1, bool EXACT>
 __global__ void __launch_bounds__(64 * MP_NW) __attribute__((amdgpu_num_vgpr(124)))
 k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                const float *__restrict__ Ug, const float *__restrict__ Vg, const float *__restrict__ Wg,
-               const float *__restrict__ Cg, int asz, int clen, int ntile, int nchunk, int nscal, int nkr, int kstore)
+               const float *__restrict__ Cg, unsigned asz, int clen, int ntile, int nchunk, int nscal, int nkr, int kstore)
 {
     constexpr int H = KB + 2;                       // own levels + one halo level below and above
     // exchange slots, double-buffered by step parity (a step without plane-P work has only the first exchange)
@@ -173,8 +186,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     // first half of a step need that room to overlap: those 9 KB + 2 values per thread are parked in LDS in between
     // (thread-private float4 slots: no synchronisation, conflict-free b128 accesses).
     // The two z exchanges of a step are synchronised between NEIGHBOURING waves only: a wave needs the edge levels of the wave
-    // below and the wave above it, nothing else.  A wave posts its edges (data, then a step counter; the LDS executes one
-    // wave's operations in order, so a reader that sees the counter sees the data), does the work that needs no neighbour, and
+    // below and the wave above it, nothing else.  A wave posts its edges (data, then a step counter stored with release semantics; the
+    // reader's acquire load of the counter makes the data visible to it), does the work that needs no neighbour, and
     // spins on the two neighbouring counters.  The double buffering by step parity stays sufficient: wave w overwrites a buffer
     // at step t + 2 only after it has seen the counters of w-1 / w+1 at t + 1, which they post after their reads of step t.
     // Counters: s_sync[e * NW2 + 1 + wave]; the entries below wave 0 and above the last wave are INT_MAX (never waited for).
@@ -214,7 +227,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
     for (int mm = 1; mm < ICAR_MAX_ADV; ++mm) if (mm == m) { qp = qin.p[mm]; outp = qout.p[mm]; }   // (a dynamic index would put the tables in scratch)
     const rsrc_t q = mkrsrc(qp), out = mkrsrc(outp), Ur = mkrsrc(Ug), Vr = mkrsrc(Vg), Wr = mkrsrc(Wg),
-                 cr = mkrsrc(Cg);                           // the eleven coefficient arrays, asz bytes each
+                 cr = mkrsrc(Cg);                           // the thirteen coefficient arrays, asz bytes each
 
     const int i = 1 - MP_HL + tile * MP_XOUT + lane;
     const int ic = min(max(i, 0), nx - 1);                  // lanes outside the domain are copies of the ring column
@@ -245,27 +258,28 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     const int bzlo = (wv > 0) ? 2 : 0, bzhi = (wv < nw - 1) ? 0 : 2;
     int *const fpost = (lane == 0) ? &s_sync[1 + wv] : &s_sync[2 * NW2 + lane];
     int seqA = 0, seqB = 0;
+// Flag store = release, flag load = acquire, both at workgroup scope: the data written to s_q2 / s_bz before a post is visible to
+// the wave that has seen the counter -- by the memory model, not by what the LDS happens to do today.  In the
+// non-tgsplit mode these lower to the same ds_write / ds_read plus an s_waitcnt lgkmcnt(0) in front of the store.
 #define MP_POST(e, seq)                                                                                                   \
     {                                                                                                                      \
         ++seq;                                                                                                             \
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
-        __hip_atomic_store(fpost + (e) * NW2, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                         \
+        __hip_atomic_store(fpost + (e) * NW2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);                         \
     }
 #define MP_WAIT(e, seq)                                                                                                    \
     {                                                                                                                      \
         int spin = 0;                                                                                                      \
         for (;;) {                                                                                                         \
-            const int fa = __hip_atomic_load(&s_sync[(e) * NW2 + wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      \
-            const int fb = __hip_atomic_load(&s_sync[(e) * NW2 + wv + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  \
+            const int fa = __hip_atomic_load(&s_sync[(e) * NW2 + wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);      \
+            const int fb = __hip_atomic_load(&s_sync[(e) * NW2 + wv + 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  \
             if (__builtin_amdgcn_readfirstlane(min(fa, fb)) >= seq) break;                                                 \
             __builtin_amdgcn_s_sleep(1);                                                                                   \
             if (++spin > (1 << 26)) __builtin_trap();              /* a lost neighbour must not hang the device */          \
         }                                                                                                                  \
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                                           \
     }
 
 #define LDQ(h, po) ldb(q, vk[h], (po))
-#define LDC(a, h, po) ldb(cr, vk[h], (a) * asz + (po))                  /* coefficient array a (MPC_*) */
+#define LDC(a, h, po) ldb(cr, vk[h], (int)((unsigned)(a) * asz + (unsigned)(po)))   /* coefficient array a (MPC_*); unsigned: the thirteen arrays may span up to 4 GiB */
 #define CLAMPJ(p) min(max((p), 0), ny - 1)
 
     // ---- rolling state (planes relative to the step's in-plane index P; N = P+1, M = P-1) ----
@@ -289,13 +303,14 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     for (int t = 0; t < NA4 + NB4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int P0 = ja - 3;
     // inputs of one step that are requested during the step before it
-    float WN[KB + 1], UN[KB], VNN[KB], rdhN[KB], rdvN[KB];
+    float WN[KB + 1], UN[KB], VNN[KB], rdhN[KB], rdvN[KB], ghN[KB], gvN[KB];
 // group A: what the donor-cell pass of step PP reads (plane PP+1; the north face's V on plane PP+2)
 #define ISSUE_LOADS_A(oN_, oNN_)                                                                                         \
     {                                                                                                                    \
         _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = ldb(Wr, vk[h], (oN_));                                   \
         _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = ldb(Ur, vk[kk + 1], (oN_)); VNN[kk] = ldb(Vr, vk[kk + 1], (oNN_)); } \
         _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { rdhN[kk] = LDC(MPC_RDH, kk + 1, (oN_)); rdvN[kk] = LDC(MPC_RDV, kk + 1, (oN_)); } \
+        if (PASS1) { _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { ghN[kk] = LDC(MPC_GH, kk + 1, (oN_)); gvN[kk] = LDC(MPC_GV, kk + 1, (oN_)); } } \
     }
     {
         const int o0 = CLAMPJ(P0) * sj4, o1 = CLAMPJ(P0 + 1) * sj4, o2 = CLAMPJ(P0 + 2) * sj4;
@@ -309,7 +324,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         ISSUE_LOADS_A(o1, o2)
         if (PASS1) {
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) S0.Fyd[kk] = upw(qP0[kk], Q0.v[kk + 1], V1[kk]);     // the face between planes P0 and P0+1
+            for (int kk = 0; kk < KB; ++kk) S0.Fyd[kk] = opaque(upw(qP0[kk], Q0.v[kk + 1], V1[kk]));     // the face between planes P0 and P0+1
         }
     }
     // One step of the march.  STEADY = every stage is on and no plane of the window is a boundary row of the domain (the bulk of
@@ -351,13 +366,21 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             if (PASS1) {
                 float FzT[KB + 1];                                 // flux through the face ABOVE level k0-1+h
 #pragma unroll
-                for (int h = 0; h <= KB; ++h) FzT[h] = upw(qN.v[h], qN.v[h + 1], WN[h]);   // at the top of the column q(h+1) == q(h): q*W (adv_mpdata.f90:96)
+                for (int h = 0; h <= KB; ++h) FzT[h] = opaque(upw(qN.v[h], qN.v[h + 1], WN[h]));   // at the top of the column q(h+1) == q(h): q*W (adv_mpdata.f90:96)
                 FzT[0] *= gmul;                                    // the ground
                 auto donor = [&](const int kk) {
                     const int h = kk + 1;
-                    const float FxL = upw(dpp_l(qN.v[h]), qN.v[h], UN[kk]), FxR = dpp_r(FxL);
-                    const float Fn = upw(qN.v[h], qNN.v[h], VNN[kk]);
-                    q2N[h] = qN.v[h] - ((FxR - FxL) + (Fn - sP.Fyd[kk])) * rdhN[kk] - (FzT[h] - FzT[h - 1]) * rdvN[kk];   // ring cells: rdh = rdv = 0
+                    // q2 is BIT-IDENTICAL to the reference's (adv_mpdata.f90:66-99: same fluxes, same association, both quotients
+                    // rounded once, no contraction).  It has to be: next to the ring the limiter's factor is (q2 - qmin) / 1e-15 or
+                    // (qmax - q2) / 1e-15 clipped to 1 (adv_mpdata_FCT_core.f90:80-113 with fin = fout = 0 there) -- zero or one,
+                    // decided by whether q2 of the ring's neighbour EQUALS an extremum: one ulp in q2 switches a whole antidiffusive
+                    // flux on or off (round 5's contracted form: 9.2e-6 of theta at one cell of the config-3 tile).  Everything
+                    // downstream of q2 is continuous in its rounding errors.
+                    const float FxL = opaque(upw(dpp_l(qN.v[h]), qN.v[h], UN[kk])), FxR = dpp_r(FxL);
+                    const float Fn = opaque(upw(qN.v[h], qNN.v[h], VNN[kk]));
+                    const float dh = (FxR - FxL) + (Fn - sP.Fyd[kk]), dv = FzT[h] - FzT[h - 1];
+                    const float t = qN.v[h] - exact_quot(dh, ghN[kk], rdhN[kk]);                       // ring cells: rdh = rdv = 0
+                    q2N[h] = t - exact_quot(dv, gvN[kk], rdvN[kk]);
                     sN.Fyd[kk] = Fn;
                 };
                 // the two levels the neighbouring waves wait for go first and are posted before the others are computed
@@ -639,7 +662,7 @@ static void launch_fused(icar_hip_ctx *c, bool fct, bool pass1, bool exact, cons
 {
     const unsigned nitem = (unsigned)(ntile * nchunk * nkr * nv), cap = (nitem + 7u) / 8u;
     const dim3 g(8u * cap), b(64, nw);                      // block id = xcd + 8 * slot, slot < cap
-#define GO(F, P1, E) hipLaunchKernelGGL((k_mpdata_fused<KB, F, P1, E>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->mpc, (int)(c->n3 * sizeof(float)), clen, ntile, nchunk, nv, nkr, kstore)
+#define GO(F, P1, E) hipLaunchKernelGGL((k_mpdata_fused<KB, F, P1, E>), g, b, 0, c->stream, c->d, in, out, c->U, c->V, c->W, c->mpc, (unsigned)(c->n3 * sizeof(float)), clen, ntile, nchunk, nv, nkr, kstore)
 #define GO2(F, P1) { if (exact) GO(F, P1, true); else GO(F, P1, false); }
     if (fct) { if (pass1) GO2(true, true) else GO2(true, false) } else { if (pass1) GO2(false, true) else GO2(false, false) }
 #undef GO2
@@ -652,7 +675,7 @@ int icar_mpdata_coef_run(icar_hip_ctx *c, bool rho_on)
     const float *jaco = icar_field_f(c, ICAR_F_JACOBIAN), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
     const float *rho = rho_on ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
     if (!jaco || !dz || (rho_on && !rho)) return 1;
-    if (c->n3 * sizeof(float) * MPC_N >= ((size_t)1 << 31)) { icar_set_error("mpdata: a tile of more than 48 M cells is not supported (32-bit buffer offsets into the coefficient arrays)"); return 1; }
+    if (c->n3 * sizeof(float) * MPC_N >= ((size_t)1 << 32)) { icar_set_error("mpdata: a tile of more than 82 M cells is not supported (32-bit buffer offsets into the coefficient arrays)"); return 1; }
     if (!c->mpc) HIPCHK(hipMalloc(&c->mpc, c->n3 * sizeof(float) * MPC_N));
     const dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
     if (rho_on) hipLaunchKernelGGL(k_mpdata_coef<true>, g, b, 0, c->stream, c->d, c->U, c->V, c->Wdz, rho, jaco, dz, c->mpc);

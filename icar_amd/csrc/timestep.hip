@@ -24,6 +24,11 @@ enum { kMP_THOMPSON = 1, kMP_SB04 = 2, kMP_WSM6 = 4, kMP_WSM3 = 6 };
 
 static bool cfg_ok(icar_hip_ctx *c, const char *who)
 {
+    if (c->step.failed) {
+        icar_set_error(std::string(who) + ": this context abandoned a half-applied sub-step after an earlier error (the microphysics of that sub-step was "
+                       "already applied when update_dt failed); its fields are not a model state -- reload them and set the clock (icar_hip_model_time_set)");
+        return false;
+    }
     if (c->step.configured) return true;
     icar_set_error(std::string(who) + ": call icar_hip_step_configure first");
     return false;
@@ -233,11 +238,19 @@ int icar_substep_open_early(icar_hip_ctx *c)
 }
 
 // update_dt failed after the opening of the sub-step was issued (time step too small, a transport timeout): join the second
-// stream and forget the opening, so that the next call on this context does not continue a half-issued sub-step
+// stream and forget the opening, so that the next call on this context does not continue a half-issued sub-step.  The opening has
+// already applied the interior and strip microphysics of the abandoned sub-step and advanced mp_last_model_time: a caller that
+// retried would run the microphysics twice for one model time.  The reference STOPs where update_dt fails (time_step.f90:322-328);
+// here the context is marked failed and every later stepping call returns an error until the caller reloads the fields and
+// sets the model clock (icar_hip_model_time_set clears the mark: that is what a restart does).
 static int update_dt_opened(icar_hip_ctx *c, double *dt)
 {
     if (icar_update_dt(c, dt) == 0) return 0;
-    if (c->step.early_open) { (void)icar_hip_aux_join(c); c->step.early_open = false; }
+    if (c->step.early_open) {
+        const std::string why = icar_hip_last_error();                   // (aux_join may overwrite it)
+        (void)icar_hip_aux_join(c); c->step.early_open = false; c->step.failed = true;
+        icar_set_error(why + " [the sub-step was already opened: context marked failed]");
+    }
     return 1;
 }
 
@@ -427,7 +440,7 @@ int icar_hip_step_configure(icar_hip_ctx *c, const icar_hip_step_config *cfg, co
     return 0;
 }
 
-int icar_hip_model_time_set(icar_hip_ctx *c, double seconds) { if (!c) { icar_set_error("null ctx"); return 1; } c->step.model_time = seconds; return 0; }
+int icar_hip_model_time_set(icar_hip_ctx *c, double seconds) { if (!c) { icar_set_error("null ctx"); return 1; } c->step.model_time = seconds; c->step.failed = false; return 0; }
 double icar_hip_model_time(const icar_hip_ctx *c) { return c ? c->step.model_time : 0.0; }
 int icar_hip_mp_reset(icar_hip_ctx *c) { if (!c) { icar_set_error("null ctx"); return 1; } c->step.mp_last_model_time = -999.0; return 0; }
 

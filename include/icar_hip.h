@@ -399,7 +399,11 @@ int icar_hip_co_max(icar_hip_ctx *ctx, double *value);
  *   icar_hip_substep     == one pass of :474-539: diagnostic_update -> mp(halo=1) -> halo_send -> mp(subset=1) ->
  *                           halo_retrieve -> advect -> apply_forcing [-> enforce_limits], with the interior microphysics and
  *                           the streaming kernels issued on the context's second stream beside the heavy ones
- *   icar_hip_step        == step(domain, end_time, options) (:440-551); the model clock lives in the context
+ *   icar_hip_step        == step(domain, end_time, options) (:440-551); the model clock lives in the context.
+ *                           An error from icar_hip_step / icar_hip_step_n leaves the fields undefined (the reference STOPs
+ *                           where update_dt fails, :322-328): when the failing sub-step had already been opened the context
+ *                           is marked failed and every stepping entry point returns an error until the caller has reloaded
+ *                           the fields and set the clock again (icar_hip_model_time_set)
  * The library keeps the model clock (domain%model_time) and mp_driver.f90's SAVE variable last_model_time. */
 typedef struct icar_hip_step_config {
     int advection;                  /* options%physics%advection: 0, ICAR_ADV_UPWIND, ICAR_ADV_MPDATA            */

@@ -358,7 +358,7 @@ void orc_libm_f(int op, int n, const float *x, const float *y, float *out)
         out[i] = (op == 3 || op == 8) ? powf(x[i], y[i]) : op == 4 ? expf(x[i]) : op == 5 ? logf(x[i]) : op == 6 ? log10f(x[i])
                : op == 7 ? atanf(x[i]) : powf(10.0f, x[i]);
 }
-/* the host C library's DOUBLE PRECISION functions on arrays: op 0 log, 1 exp, 2 pow (the op codes of icar_hip_thompson_math_probe) */
+/* the host C library's DOUBLE PRECISION functions on arrays: op 0 log, 1 exp, 2 pow (the op codes of icar_probe_math, tests/support/th_probe.hip) */
 void orc_libm_d(int op, int n, const double *x, const double *y, double *out)
 {
     for (int i = 0; i < n; ++i) out[i] = op == 0 ? log(x[i]) : op == 1 ? exp(x[i]) : pow(x[i], y[i]);

@@ -16,7 +16,7 @@
 extern int g_math_mode;
 /* Optional trace of every transcendental call of the column physics (diagnostics for a device / oracle difference: which libm
  * call does the device evaluate differently?).  orc_thompson_trace(1) starts a trace (run ONE column, one thread), the entries are
- * (op, x, y, result) with op = the op codes of icar_hip_thompson_math_probe: 0 log, 1 exp, 2 pow (double); 3 powf, 4 expf,
+ * (op, x, y, result) with op = the op codes of icar_probe_math (tests/support/th_probe.hip): 0 log, 1 exp, 2 pow (double); 3 powf, 4 expf,
  * 6 log10f; 10 = log10 (double, no device probe). */
 #define TH_TRACE_MAX 65536
 static int g_tr_on = 0, g_tr_n = 0;

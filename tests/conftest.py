@@ -97,7 +97,8 @@ def pytest_terminal_summary(terminalreporter):
     except Exception:
         counts = {}
     line = (f"device-vs-oracle tests run: {n_oracle} of {len(_ORACLE_TESTS)} collected, fields compared bit for bit: {counts.get('bit_exact_fields', 0)}, "
-            f"fields compared within a tolerance: {counts.get('tolerance_fields', 0)}")
+            f"fields compared within a tolerance: {counts.get('tolerance_fields', 0)}; "
+            f"oracle == golden fixtures (vectors of the compiled reference): {counts.get('golden_fields', 0)} fields bit for bit")
     terminalreporter.section("PARITY")
     terminalreporter.write_line(line)
     try:
@@ -117,8 +118,14 @@ def probe():
 
 @pytest.fixture(scope="session")
 def oracle():
+    """the CPU oracle, compiled on this host.  On a GPU box it is first held to the golden vectors of the compiled reference
+    (tests/golden_pin.py: the bodies of the CPU tests that `-m gpu` does not select) -- a differing bit there fails every
+    device-vs-oracle test of the session instead of letting them compare the device with an unpinned checker."""
     from oracle import orc
     orc.build()
+    if _has_gpu() or os.environ.get("ICAR_PIN_ORACLE") == "1":
+        import golden_pin
+        golden_pin.pin(orc)
     return orc
 
 

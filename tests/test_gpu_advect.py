@@ -11,13 +11,14 @@ from icar_amd.options import options_t
 from icar_amd.advection import advect
 from icar_amd.capi import lib, check
 from icar_amd.constants import kADV_UPWIND, kADV_MPDATA
-from util import SCALARS, MEMBER, KVAR, bits_equal, nbitdiff, single_image_domain, adv_args, assert_fields_close, local_rel_err, parity_record
+from util import SCALARS, MEMBER, KVAR, bits_equal, nbitdiff, single_image_domain, adv_args, assert_fields_close, local_rel_err, parity_record, roughen_winds
 
 pytestmark = pytest.mark.gpu
 
 
-def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2, fct=True, nsteps=2, noise=0.01, exact_mode=False):
+def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2, fct=True, nsteps=2, noise=0.01, exact_mode=False, rough=0.0):
     c = ideal.make_case(nx, ny, nz, hill_height=hill, noise=noise, n_hydro=1)
+    if rough: c = roughen_winds(c, oracle, rough)
     dt = ideal.cfl_dt(c)
     q = np.stack([c[n] for n in names]).copy()
     oracle.advect(scheme, q, *adv_args(c), dt, advect_density=dens, mpdata_order=order, fct=fct, nsteps=nsteps)
@@ -45,7 +46,7 @@ def run_case(oracle, scheme, nx, ny, nz, names, hill=1000.0, dens=False, order=2
             err = assert_fields_close(out[n], q[m], n); worst = max(worst, err)
             stats[n] = {"max_local_rel": err, "bitdiff_cells": nbitdiff(out[n], q[m]), "cells": int(q[m].size),
                         "max_abs_over_max": float(np.abs(out[n].astype(np.float64) - q[m]).max() / max(float(np.abs(q[m]).max()), 1e-300))}
-    parity_record("advect", f"{'upwind' if scheme == kADV_UPWIND else ('mpdata(exact)' if exact_mode else 'mpdata')} {nx}x{ny}x{nz} order{order} fct{int(fct)} dens{int(dens)} steps{nsteps}", stats)
+    parity_record("advect", f"{'upwind' if scheme == kADV_UPWIND else ('mpdata(exact)' if exact_mode else 'mpdata')} {nx}x{ny}x{nz} order{order} fct{int(fct)} dens{int(dens)} steps{nsteps}" + (f" rough{rough:g}" if rough else ""), stats)
     return worst
 
 
@@ -94,6 +95,47 @@ def test_mpdata_level_and_chunk_layouts(oracle, nx, ny, nz):
     """Level counts that exercise every levels-per-thread variant of the fused kernel (1..5, 8 and 16 waves, a last
     wave with idle levels), several y chunks, XCD shares that do not divide evenly."""
     run_case(oracle, kADV_MPDATA, nx, ny, nz, ["water_vapor", "cloud_water", "rain", "potential_temperature"], nsteps=1)
+
+
+@pytest.mark.parametrize("nx,ny,nz,dens,rough", [(70, 37, 12, False, 0.0), (70, 37, 12, True, 0.5), (130, 64, 40, False, 0.5), (61, 70, 41, True, 0.5),
+                                                 (512, 256, 40, False, 0.5)])
+def test_fused_kernel_donor_cell_pass_bit_identical(oracle, probe, nx, ny, nz, dens, rough):
+    """The field after the donor-cell pass INSIDE the fused kernel (q2, never written to memory) is bit-identical to the reference's
+    (adv_mpdata.f90:44-105): the limiter's factors next to the ring are all-or-nothing in whether q2 equals a local extremum
+    (adv_mpdata_FCT_core.f90:80-113 with fin = fout = 0 there), so one ulp of q2 is a whole corrective flux at that cell (round 5:
+    9.2e-6 of theta at one cell of the config-3 tile).  With the antidiffusive coefficients of the context zeroed
+    (tests/support/mpdata_probe.hip) the kernel's output is q2; the oracle's is mpdata_order = 1."""
+    from icar_amd.advection import setup_winds
+    names = ["water_vapor", "cloud_water", "potential_temperature"]
+    c = ideal.make_case(nx, ny, nz, hill_height=1000.0, noise=0.01, n_hydro=1)
+    if rough: c = roughen_winds(c, oracle, rough)
+    dt = ideal.cfl_dt(c)
+    q = np.stack([c[n] for n in names]).copy()
+    oracle.advect(kADV_MPDATA, q, *adv_args(c), dt, advect_density=dens, mpdata_order=1, fct=True, nsteps=1)
+    d = single_image_domain(c)
+    opt = options_t(); opt.physics.advection = kADV_MPDATA; opt.parameters.advect_density = dens
+    opt.adv_options.mpdata_order = 2; opt.adv_options.flux_corrected_transport = True
+    opt.advect_vars([KVAR[n] for n in names])
+    d.configure(opt)
+    setup_winds(d, opt, dt)
+    assert probe.icar_probe_mpdata_zero_antidiffusion(d.ctx) == 0
+    advect(d, opt, dt)                                  # (same scheme, dt and density: the coefficients are not rebuilt)
+    for m, n in enumerate(names):
+        got = d.get(MEMBER[n])
+        assert np.abs(got - c[n]).max() > 0
+        assert bits_equal(got, q[m]), f"{n}: q2 of {nbitdiff(got, q[m])} of {got.size} cells differs from the reference's donor-cell pass"
+    d.close()
+
+
+def test_mpdata_rough_winds_metric_size(oracle):
+    """BASELINE metric size, the 9 Thompson scalars, winds with white noise of 0.5 m/s on u and v (w rebalanced): every cell within
+    the tolerance -- and, by assert_fields_close's margin rule, within 0.3 of it.  """
+    run_case(oracle, kADV_MPDATA, 512, 512, 40, SCALARS, nsteps=1, rough=0.5)
+
+
+@pytest.mark.parametrize("dens,fct,order", [(False, True, 2), (True, True, 2), (False, True, 3)])
+def test_mpdata_rough_winds(oracle, dens, fct, order):
+    run_case(oracle, kADV_MPDATA, 130, 67, 40, ["water_vapor", "cloud_water", "potential_temperature"], dens=dens, fct=fct, order=order, nsteps=1, rough=0.5)
 
 
 def test_mpdata_all_thompson_scalars(oracle):

@@ -21,8 +21,12 @@ def summary(a):
     return dict(sum=float(a64.sum()), min=float(a.min()), max=float(a.max()), sumsq=float((a64 * a64).sum()))
 
 
-@pytest.mark.parametrize("name", ["adv_upwind_24x20x10", "adv_mpdata_24x20x10", "adv_mpdata_dens_40x36x12",
-                                  "adv_mpdata_nofct_40x36x12", "adv_mpdata_order1_40x36x12"])
+SMALL_CASES = ["adv_upwind_24x20x10", "adv_mpdata_24x20x10", "adv_mpdata_dens_40x36x12", "adv_mpdata_nofct_40x36x12", "adv_mpdata_order1_40x36x12"]
+CONFIG1_CASES = ["adv_mpdata_100x100x30", "adv_upwind_100x100x30"]
+MP_SIMPLE_CASES = ["mp_simple_40x36x20", "mp_simple_snow_30x20x30"]        # (tests/golden_pin.py runs the same lists inside a -m gpu session)
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
 def test_advection_golden_small(oracle, name):
     z, p = load(name)
     c = {n: np.ascontiguousarray(z["in_" + n]) for n in INPUTS_ADV}
@@ -33,7 +37,7 @@ def test_advection_golden_small(oracle, name):
     assert bits_equal(q, z["q"]), f"{nbitdiff(q, z['q'])} values differ from the reference"
 
 
-@pytest.mark.parametrize("name", ["adv_mpdata_100x100x30", "adv_upwind_100x100x30"])
+@pytest.mark.parametrize("name", CONFIG1_CASES)
 def test_advection_golden_config1_grid(oracle, name):
     """BASELINE config[0] grid, 10 steps; inputs regenerated from IEEE-exact arithmetic."""
     z, p = load(name)
@@ -52,7 +56,7 @@ def test_advection_golden_config1_grid(oracle, name):
     assert bits_equal(q[:, 50], z["plane_j50"])
 
 
-@pytest.mark.parametrize("name", ["mp_simple_40x36x20", "mp_simple_snow_30x20x30"])
+@pytest.mark.parametrize("name", MP_SIMPLE_CASES)
 def test_mp_simple_golden(oracle, name):
     z, p = load(name)
     nx, ny, nz = p["nx"], p["ny"], p["nz"]

@@ -45,11 +45,15 @@ def local_rel_err(got, ref, radius=2):
 
 
 MPDATA_RTOL = 1e-5      # BASELINE.json north_star: "output fields within 1e-5 relative of CPU reference"
+# A result that passes the gate by a hair is a finding, not a pass (round 5's rewritten kernel sat at 9.2e-6 of 1e-5 on one label and
+# nobody saw it): a field whose measured deviation exceeds MPDATA_MARGIN x the gate fails unless the caller passes the written
+# reason why that label is expected there (near_gate=...).  Measured maxima: profiles/r06_parity.json.
+MPDATA_MARGIN = 0.3
 MPDATA_POINTWISE_MAX = 5e-5
 MPDATA_BEYOND_FRAC = 1e-5
 
 
-def assert_fields_close(got, ref, name="", rtol=MPDATA_RTOL, record=None):
+def assert_fields_close(got, ref, name="", rtol=MPDATA_RTOL, record=None, near_gate=None):
     """every cell within rtol of the local field scale; record = (test, label): also write the measured local-scale error and
     the POINTWISE statistics (field_stats) to the parity record"""
     COUNTS["tolerance_fields"] += 1
@@ -58,6 +62,8 @@ def assert_fields_close(got, ref, name="", rtol=MPDATA_RTOL, record=None):
     if record is not None:
         parity_record(record[0], record[1], {name: st})
     assert err <= rtol, f"{name}: |got-ref| = {err:.3e} x the local field scale at {where} (allowed {rtol:g})"
+    assert err <= MPDATA_MARGIN * rtol or near_gate, (f"{name}: |got-ref| = {err:.3e} x the local field scale at {where}: inside the gate {rtol:g} but "
+                                                      f"beyond {MPDATA_MARGIN} of it, and no written reason (near_gate=) says why this label may be")
     # north_star's POINTWISE form as well: where the field is not small (|ref| > 1e-3 of its maximum) no cell is off by more than
     # MPDATA_POINTWISE_MAX of its own value, and at most MPDATA_BEYOND_FRAC of all cells are beyond rtol of max(|ref|, 1e-3 max)
     # (measured on MI355X: 2.2e-5 and 1.9e-6, profiles/r0*_parity.json; two cells are allowed on grids smaller than 2e5 cells)
@@ -72,6 +78,19 @@ def single_image_domain(case, device=0):
     d = domain_t(g, device=device, dx=float(case["dx"]))
     d.load_case(case)
     return d
+
+
+def roughen_winds(c, oracle, amp=0.5, seed=77):
+    """u, v of a case + amp x white noise (what a random linear-theory look-up table does to them in
+    test_gpu_trajectory.py::test_config3_tile_update_winds_then_substep), w rebalanced (balance_uvw, wind.f90:74-128).  Neighbouring
+    Courant numbers then differ in sign and size, the corrective fluxes are large and the limiter works on nearly every face: the
+    case that shows what an MPDATA kernel's rounding does to a large-mean field (potential temperature)."""
+    rng = np.random.default_rng(seed)
+    c = dict(c)
+    c["u"] = (c["u"] + amp * rng.standard_normal(c["u"].shape)).astype(np.float32)
+    c["v"] = (c["v"] + amp * rng.standard_normal(c["v"].shape)).astype(np.float32)
+    c["w"] = oracle.balance_uvw(c["u"], c["v"], c["jacobian_u"], c["jacobian_v"], c["jacobian_w"], c["advection_dz"], float(c["dx"]))
+    return c
 
 
 def adv_args(c):
