@@ -14,6 +14,7 @@ module icar_hip
   public :: hip_ctx_t, hip_create, hip_destroy, hip_upload, hip_download, hip_upload_2dd, hip_download_2dd, &
             hip_advect, hip_mp_simple, hip_thompson_init, hip_thompson, hip_max_courant, hip_balance_uvw, hip_sync, &
             hip_lt_options_t, hip_setup_linwinds, hip_linwinds_build_lut, hip_spatial_winds, hip_iterative_winds, &
+            hip_iterative_winds_correct_w, hip_iterative_winds_sweep, &
             hip_diagnostic_update, hip_diagnostic_update_parts, hip_dqdt_upload, hip_apply_forcing, hip_enforce_limits, hip_halo_count, hip_halo_pack, &
             hip_halo_unpack, hip_mp_simple_tiles, hip_halo_pack_dirs, hip_halo_unpack_dirs, hip_thompson_tiles, hip_mass_conservative_acceleration, hip_balance_uvw_update, hip_wsm3_init, hip_wsm3, hip_wsm6_init, hip_wsm6, hip_wsm6_tiles, hip_winds_valid, hip_max_courant_prefetch, &
             hip_aux_fork, hip_aux_begin, hip_aux_end, hip_aux_join, hip_max_courant_device, hip_make_winds_grid_relative, &
@@ -795,6 +796,21 @@ contains
     end if
     call check(icar_hip_iterative_winds_correct_w(ctx%p, upd), "iterative_winds_correct_w")
     call check(icar_hip_iterative_winds_sweep(ctx%p, real(dx,c_float), int(wind_iterations+1,c_int), upd), "iterative_winds_sweep")
+  end subroutine
+
+  !> the two pieces of iterative_winds for a host that keeps the loop (and its exchange_u / exchange_v per sweep) in its own hands:
+  !! the model-top correction of w (wind.f90:430-441) and nsweeps Jacobi sweeps (:455-481: calc_divergence, ADJ, the u / v faces)
+  subroutine hip_iterative_winds_correct_w(ctx, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    logical, intent(in) :: update
+    call check(icar_hip_iterative_winds_correct_w(ctx%p, merge(1_c_int, 0_c_int, update)), "iterative_winds_correct_w")
+  end subroutine
+  subroutine hip_iterative_winds_sweep(ctx, dx, nsweeps, update)
+    type(hip_ctx_t), intent(in) :: ctx
+    real, intent(in) :: dx
+    integer, intent(in) :: nsweeps
+    logical, intent(in) :: update
+    call check(icar_hip_iterative_winds_sweep(ctx%p, real(dx,c_float), int(nsweeps,c_int), merge(1_c_int, 0_c_int, update)), "iterative_winds_sweep")
   end subroutine
 
   !> update_winds(domain, options) (wind.f90:289-369) as one call, on any number of images: make_winds_grid_relative ->
