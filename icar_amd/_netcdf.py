@@ -1,22 +1,25 @@
 """What the NetCDF side of this package can and cannot interchange with a reference ICAR run.
 
-The reference writes NetCDF-4 / HDF5 everywhere: output and restart files (`nf90_create(..., NF90_NETCDF4)`,
-src/io/output_obj.f90:41-78), the linear-wind LUT cache (src/io/lt_lut_io.f90:58-108) and, through xarray, the ideal-case inputs
-of helpers/genNetCDF.  This image has no HDF5 library, so everything here is NetCDF CLASSIC (CDF-1 / CDF-2 via
-scipy.io.netcdf_file) with the reference's variable names, dimension names and orders:
-
-    written here  -> read by the reference : yes.  nf90_open / nf90_inq_varid / nf90_get_var read classic files like NetCDF-4 ones.
-    written by the reference -> read here  : only after `nccopy -k classic` (or `-k 64-bit-offset`); an HDF5 file is REJECTED
-                                              with that advice, not parsed.
-    limits of the classic format           : one record dimension, fixed-size variables < 4 GiB (a production LUT of 30 GB does
-                                              not fit: write_LUT refuses it).
+Formats of the reference, file by file:
+    output and restart files      NetCDF CLASSIC: `nf90_create(filename, NF90_CLOBBER, ...)`, src/io/output_obj.f90:54 -- the SAME format
+                                  this package writes (CDF-1 via scipy.io.netcdf_file), with the reference's variable names, dimension
+                                  names and orders and attributes (tests/golden/output_metadata.json is derived from
+                                  src/io/default_output_metadata.f90 + output_obj.f90; tests/test_output_netcdf.py holds the writer to it).
+                                  Either side reads the other's files as they are.
+    linear-wind LUT cache         NetCDF-4 / HDF5: `nf90_create(..., NF90_NETCDF4)`, src/io/lt_lut_io.f90:323,403.  This image has no HDF5
+                                  library: the cache written here is classic (the reference's nf90_open reads it); a cache the reference
+                                  wrote needs `nccopy -k classic` (or `-k 64-bit-offset`) before it is read here -- an HDF5 file is
+                                  REJECTED with that advice, not parsed.  Classic limits: fixed-size variables < 4 GiB (a production LUT
+                                  of 30 GB does not fit: write_LUT refuses it).
+    ideal-case / forcing inputs   whatever the tool that made them wrote; xarray (helpers/genNetCDF) defaults to NetCDF-4: same advice.
 
 FORMAT_NOTE goes into the global attributes of every file this package writes."""
 from .capi import IcarHipError
 
 HDF5_SIGNATURE = b"\x89HDF\r\n\x1a\n"
-FORMAT_NOTE = ("NetCDF classic written without an HDF5 library (icar_amd on MI355X); the reference ICAR writes NetCDF-4: its "
-               "nf90_open reads this file as it is, a file the reference wrote needs `nccopy -k classic` before icar_amd reads it")
+FORMAT_NOTE = ("NetCDF classic (CDF-1), the format of the reference ICAR's own output and restart files (nf90_create NF90_CLOBBER); "
+               "written by icar_amd on MI355X without an HDF5 library: NetCDF-4 inputs (the reference's linear-wind LUT cache, "
+               "xarray-written files) need `nccopy -k classic` before icar_amd reads them")
 
 
 def open_classic(path, mode="r", **kw):
@@ -26,7 +29,8 @@ def open_classic(path, mode="r", **kw):
         with open(path, "rb") as f:
             head = f.read(8)
         if head == HDF5_SIGNATURE:
-            raise IcarHipError(f"{path} is a NetCDF-4 / HDF5 file (what the reference ICAR and its xarray helpers write); this build "
+            raise IcarHipError(f"{path} is a NetCDF-4 / HDF5 file (the reference's linear-wind LUT cache and xarray-written inputs are; its output and "
+                               "restart files are classic); this build "
                                "has no HDF5 library and reads NetCDF classic only: convert it with `nccopy -k classic` "
                                "(or `-k 64-bit-offset`), names and dimension orders stay the same")
         if head[:3] != b"CDF":

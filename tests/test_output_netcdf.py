@@ -1,7 +1,10 @@
 """the NetCDF-classic output writer mirrors src/io/output_obj.f90 (names, dimension order, attributes,
-time axis).  The reference's writer cannot run here (no NetCDF-Fortran): PARITY UNPINNED; checked is the format contract
-read off the source -- CDF-1 magic, (time, level, lat_y, lon_x) order = reshape(order=[1,3,2]) of data_3d(i,k,j),
-staggered dimensions, REAL(8) accumulators, appending records."""
+time axis).  The reference's writer cannot run here (no NetCDF-Fortran), so no file of its making is a fixture; what IS pinned:
+the metadata table and the header of a written file against tests/golden/output_metadata.json, which
+tests/golden/make_output_metadata.py derives from the reference's sources (default_output_metadata.f90, output_obj.f90) -- names,
+dimension lists and order, attributes, types, the time variable, the global attributes, the classic format flag -- with the header
+read by a byte-level CDF-1 reader below, not by the library that wrote it.  Plus the round trip: (time, level, lat_y, lon_x) =
+reshape(order=[1,3,2]) of data_3d(i,k,j), staggered dimensions, REAL(8) accumulators, appending records."""
 import datetime
 import numpy as np
 from icar_amd.output import output_t, read_file, output_filename
@@ -83,3 +86,92 @@ def test_restart_reads_back_what_output_wrote(tmp_path):
         read_restart_data(Dom(8, 6, 4), o, fn, 1)
     when = datetime.datetime(2010, 10, 3, 14, 30, 0)
     assert get_image_filename(12, "restart/icar_rst_", when) == "restart/icar_rst_000012_2010-10-03_00-30-00.nc"
+
+
+# ---- the format contract, from a fixture DERIVED from the reference's sources (tests/golden/make_output_metadata.py parses
+# ---- src/io/default_output_metadata.f90 and src/io/output_obj.f90 in the build container) -------------------
+def _fixture():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "output_metadata.json")))
+
+
+def cdf1_header(path):
+    """A NetCDF classic (CDF-1) header read byte by byte -- not through scipy, which also WROTE the file: magic, numrecs, dim_list,
+    gatt_list, var_list (name, dimension ids, attributes, type) as the file format specification lays them out."""
+    import struct
+    b = open(path, "rb").read()
+    pos = 4
+    NC = {1: ("b", 1), 2: ("c", 1), 3: (">h", 2), 4: (">i", 4), 5: (">f", 4), 6: (">d", 8)}
+
+    def u32():
+        nonlocal pos
+        v = struct.unpack(">I", b[pos:pos + 4])[0]; pos += 4; return v
+
+    def name():
+        nonlocal pos
+        n = u32(); s = b[pos:pos + n].decode(); pos += (n + 3) // 4 * 4; return s
+
+    def atts():
+        nonlocal pos
+        tag, n = u32(), u32(); out = []
+        assert tag in (0, 0x0C)
+        for _ in range(n):
+            k = name(); t = u32(); cnt = u32(); size = NC[t][1] * cnt
+            raw = b[pos:pos + size]; pos += (size + 3) // 4 * 4
+            out.append((k, raw.decode() if t == 2 else struct.unpack(NC[t][0][0] + str(cnt) + NC[t][0][-1], raw)))
+        return out
+    numrecs = u32()
+    tag, n = u32(), u32(); assert tag == 0x0A
+    dims = [(name(), u32()) for _ in range(n)]
+    gatts = atts()
+    tag, n = u32(), u32(); assert tag == 0x0B
+    variables = {}
+    for _ in range(n):
+        vn = name(); nd = u32(); ids = [u32() for _ in range(nd)]; va = atts(); t = u32(); u32(); u32()     # vsize, begin (CDF-1: 32 bit)
+        variables[vn] = {"dims": [dims[i][0] for i in ids], "attrs": va, "type": t}
+    return {"magic": b[:4], "numrecs": numrecs, "dims": dims, "gatts": gatts, "vars": variables}
+
+
+def test_metadata_table_equals_the_reference_derived_fixture():
+    from icar_amd.output import METADATA
+    fx = _fixture()
+    assert fx["output_obj"]["nf90_create_mode"] == "NF90_CLOBBER"            # classic, not NF90_NETCDF4 (output_obj.f90:54)
+    assert fx["output_obj"]["reshape_order_3d"] == [1, 3, 2]
+    for kv, (fname, dims, attrs) in METADATA.items():
+        ref = fx["variables"][kv]
+        assert fname == ref["name"], kv
+        assert list(dims) == ref["dimensions"][::-1], (kv, dims, ref["dimensions"])     # Fortran order reversed = the file's C order
+        assert (dims[0] == "time") == ref["unlimited_dim"], kv
+        assert [list(a) for a in attrs] == ref["attributes"], (kv, attrs, ref["attributes"])
+
+
+def test_written_header_matches_the_reference_derived_fixture(tmp_path):
+    fx = _fixture()
+    d = FakeDomain(7, 5, 3)
+    o = output_t(image=2, version="v-test")
+    names = ["water_vapor", "potential_temperature", "u", "v", "precipitation", "z"]
+    o.add_variables(names)
+    fn = str(tmp_path / "h.nc")
+    o.save_file(d, fn, 1, 51545.5)
+    h = cdf1_header(fn)
+    assert h["magic"] == b"CDF\x01" and h["numrecs"] == 1
+    assert h["dims"][0] == ("time", 0)                                        # the one record (unlimited) dimension
+    from icar_amd.output import METADATA
+    for kv in names:
+        ref = fx["variables"][kv]; v = h["vars"][ref["name"]]
+        assert v["dims"] == ref["dimensions"][::-1], kv
+        assert [list(a) for a in v["attrs"]] == ref["attributes"], kv
+        want = "NF90_DOUBLE" if kv == "precipitation" else "NF90_REAL"        # data_2dd accumulators are kDOUBLE (output_obj.f90:100-103)
+        assert v["type"] == {"NF90_REAL": 5, "NF90_DOUBLE": 6}[want], kv
+    t = h["vars"]["time"]
+    assert t["type"] == {"NF90_DOUBLE": 6}[fx["output_obj"]["time_type"]] and t["dims"] == ["time"]
+    ta = dict(t["attrs"])
+    for k, v in fx["output_obj"]["time_attributes"]:
+        assert k in ta and (v is None or ta[k] == v), k
+    assert [k for k, _ in t["attrs"]] == [k for k, _ in fx["output_obj"]["time_attributes"]]
+    assert ta["units"] == "days since 1858-11-17 00:00:00"                    # the fixture's format with year_zero .. hour_zero of the MJD epoch
+    ga = dict(h["gatts"])
+    for k, v in fx["output_obj"]["global_attributes"]:
+        assert k in ga and (v is None or ga[k] == v), k
+    assert ga["image"] == (2,) and ga["git"] == "v-test"
+    assert "NetCDF classic" in ga["format_note"] and "nccopy" not in ga["format_note"].split("output")[0]
