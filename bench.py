@@ -82,7 +82,7 @@ def build_tile(args, rank, world, device):
 ADVECT_KERNELS = {"mpdata": "k_mpdata_fused", "upwind": "k_upwind_pass"}
 SETUP_KERNELS = ("k_setup_winds", "k_mpdata_coef")      # launched once per step for the advect() call (timer group "winds")
 # bumped whenever the advection kernels change what they read or write: profiles/advect_traffic.json (PMC passes) belongs to one
-KERNEL_GENERATION = "r05: branch-free paired steady steps, ring cells through zero coefficients (k_mpdata_fused + k_mpdata_coef)"
+KERNEL_GENERATION = "r06: r05's branch-free paired steady steps + a donor-cell pass bit-identical to the reference (exact quotients, 13 coefficient arrays) (k_mpdata_fused + k_mpdata_coef)"
 
 FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
 
@@ -462,7 +462,7 @@ def main():
                                else "periodic self-exchange (pack + unpack of 4 edges, no transport), strips+pack on the second stream beside the interior mp",
                        "ranks_seen": ranks_seen, "halo_check": halo_check,
                        # what the timed path computes: the microphysics, diagnostics, forcing and halos bit-identical to the CPU reference;
-                       # MPDATA either the fused kernel (every cell within 1e-5 of the local field scale per step, measured <= 3e-6) or,
+                       # MPDATA either the fused kernel (every cell within 1e-5 of the local field scale per step, measured <= 8.1e-7: profiles/r06_parity.json) or,
                        # with --mpdata-exact, the reference's operation order (bit-identical; tests/test_gpu_trajectory.py)
                        "mpdata_arithmetic": ("reference operation order (bit-identical)" if args.mpdata_exact else "fused kernel (<= 1e-5 of the local scale per step)") if args.adv == "mpdata" else "n/a",
                        "dt_s": dt, "mp_active_column_fraction": active},
