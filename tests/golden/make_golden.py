@@ -31,6 +31,13 @@ CASES = {
                                       vars=["water_vapor"]),
     "adv_mpdata_order1_40x36x12": dict(kind="adv", scheme=2, nx=40, ny=36, nz=12, hill=1000.0, dens=0, order=1, fct=1, nsteps=2,
                                        vars=["water_vapor"]),
+    # winds with white noise of 0.5 m/s on u and v, w rebalanced (tests/util.py:roughen_winds): neighbouring Courant numbers differ in
+    # sign and size, the limiter works on nearly every face -- the regime in which the all-or-nothing factor next to the ring
+    # (adv_mpdata_FCT_core.f90:80-113 with fin = fout = 0) decides cells (round 6); three steps so that the roughened field is advected again
+    "adv_mpdata_rough_40x36x12": dict(kind="adv", scheme=2, nx=40, ny=36, nz=12, hill=1000.0, dens=0, order=2, fct=1, nsteps=3, rough=0.5,
+                                      vars=["water_vapor", "potential_temperature", "cloud_water"]),
+    "adv_mpdata_rough_dens_order3_40x36x12": dict(kind="adv", scheme=2, nx=40, ny=36, nz=12, hill=1000.0, dens=1, order=3, fct=1, nsteps=2, rough=0.5,
+                                                  vars=["water_vapor", "potential_temperature"]),
     "adv_mpdata_100x100x30": dict(kind="adv", scheme=2, nx=100, ny=100, nz=30, hill=1000.0, dens=0, order=2, fct=1, nsteps=10,
                                   vars=["water_vapor"], summary_only=1),
     "adv_upwind_100x100x30": dict(kind="adv", scheme=1, nx=100, ny=100, nz=30, hill=1000.0, dens=0, order=2, fct=1, nsteps=10,
@@ -77,6 +84,12 @@ def run_case(name):
     if p["kind"] == "adv":
         exact = bool(p.get("summary_only"))
         c = ideal.make_case(p["nx"], p["ny"], p["nz"], hill_height=p["hill"], noise=0.01, n_hydro=1, exact=exact)
+        if p.get("rough"):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from util import roughen_winds
+            from oracle import orc
+            orc.build()
+            c = roughen_winds(c, orc, p["rough"])          # (the inputs travel with the fixture: in_u, in_v, in_w)
         dt = ideal.cfl_dt(c)
         q = np.stack([c[n] for n in p["vars"]]).copy()
         ref.advect(p["scheme"], q, c["u"], c["v"], c["w"], c["density"], c["jacobian"], c["jacobian_u"], c["jacobian_v"],

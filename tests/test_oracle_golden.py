@@ -21,7 +21,8 @@ def summary(a):
     return dict(sum=float(a64.sum()), min=float(a.min()), max=float(a.max()), sumsq=float((a64 * a64).sum()))
 
 
-SMALL_CASES = ["adv_upwind_24x20x10", "adv_mpdata_24x20x10", "adv_mpdata_dens_40x36x12", "adv_mpdata_nofct_40x36x12", "adv_mpdata_order1_40x36x12"]
+SMALL_CASES = ["adv_upwind_24x20x10", "adv_mpdata_24x20x10", "adv_mpdata_dens_40x36x12", "adv_mpdata_nofct_40x36x12", "adv_mpdata_order1_40x36x12",
+               "adv_mpdata_rough_40x36x12", "adv_mpdata_rough_dens_order3_40x36x12"]      # rough: white-noise winds (round 6)
 CONFIG1_CASES = ["adv_mpdata_100x100x30", "adv_upwind_100x100x30"]
 MP_SIMPLE_CASES = ["mp_simple_40x36x20", "mp_simple_snow_30x20x30"]        # (tests/golden_pin.py runs the same lists inside a -m gpu session)
 

@@ -22,6 +22,21 @@ def test_advect_matches_reference(oracle, scheme, dens, fct, seed):
     assert bits_equal(qa, qb), f"{nbitdiff(qa, qb)} values differ"
 
 
+@pytest.mark.parametrize("order,dens,seed", [(2, 0, 21), (2, 1, 22), (3, 0, 23)])
+def test_mpdata_rough_winds_match_reference(oracle, order, dens, seed):
+    """white noise of 0.5 m/s on u and v, w rebalanced: the limiter is active on nearly every face and its all-or-nothing factor next
+    to the ring (fin = fout = 0 there) decides cells on single ulps of the donor-cell pass -- the regime of round 6's bug hunt"""
+    from util import roughen_winds
+    c = ideal.make_case(NX, NY, NZ, hill_height=900.0, noise=0.05, seed=seed, n_hydro=1)
+    c = roughen_winds(c, oracle, 0.5, seed=seed)
+    dt = ideal.cfl_dt(c)
+    names = ["water_vapor", "potential_temperature", "rain"]
+    qa = np.stack([c[n] for n in names]).copy(); qb = qa.copy()
+    ref.advect(2, qa, *adv_args(c), dt, advect_density=dens, mpdata_order=order, fct=1, nsteps=3)
+    oracle.advect(2, qb, *adv_args(c), dt, advect_density=dens, mpdata_order=order, fct=1, nsteps=3)
+    assert bits_equal(qa, qb), f"{nbitdiff(qa, qb)} values differ"
+
+
 @pytest.mark.parametrize("order,dens,fct,seed", [(3, 0, 1, 6), (3, 1, 1, 7), (4, 0, 1, 8), (3, 0, 0, 9), (1, 0, 1, 10)])
 def test_mpdata_order_matches_reference(oracle, order, dens, fct, seed):
     """adv_mpdata.f90:372-402, the iord loop beyond the default order 2 (q2 = q before every further corrective
