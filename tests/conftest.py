@@ -98,7 +98,8 @@ def pytest_terminal_summary(terminalreporter):
         counts = {}
     line = (f"device-vs-oracle tests run: {n_oracle} of {len(_ORACLE_TESTS)} collected, fields compared bit for bit: {counts.get('bit_exact_fields', 0)}, "
             f"fields compared within a tolerance: {counts.get('tolerance_fields', 0)}; "
-            f"oracle == golden fixtures (vectors of the compiled reference): {counts.get('golden_fields', 0)} fields bit for bit")
+            f"oracle == golden fixtures (vectors of the compiled reference): {counts.get('golden_fields', 0)} fields bit for bit; "
+            f"device == those vectors directly (no oracle): {counts.get('reference_vector_fields', 0)} fields bit for bit")
     terminalreporter.section("PARITY")
     terminalreporter.write_line(line)
     try:

@@ -16,12 +16,18 @@ KVAR = {"water_vapor": "water_vapor", "cloud_water": "cloud_water", "rain": "rai
 
 # what the session's comparisons were (tests/conftest.py prints the totals at the end of a `-m gpu` run): fields compared bit for
 # bit (bits_equal: the int32 views, so signs of zero and NaN payloads count) and fields compared within a tolerance
-COUNTS = {"bit_exact_fields": 0, "tolerance_fields": 0}
+COUNTS = {"bit_exact_fields": 0, "tolerance_fields": 0, "reference_vector_fields": 0}
 
 
 def bits_equal(a, b):
     COUNTS["bit_exact_fields"] += 1
     return np.array_equal(np.ascontiguousarray(a).view(np.int32), np.ascontiguousarray(b).view(np.int32))
+
+
+def equals_reference_vector(a, b):
+    """bits_equal for a field the COMPILED REFERENCE wrote (tests/golden/*.npz): counted separately in the session's PARITY line"""
+    COUNTS["reference_vector_fields"] += 1
+    return bits_equal(a, b)
 
 
 def nbitdiff(a, b):
