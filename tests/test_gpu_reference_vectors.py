@@ -89,3 +89,26 @@ def test_wsm_equals_the_compiled_references_output(name):
         assert bits_equal(got, g[n]), f"{n}: {nbitdiff(got, g[n])} of {got.size} cells differ from the compiled reference's output"
     assert g["acc_rain"].max() > 1.0 and np.allclose(d.get("accumulated_precipitation"), g["acc_rain"], rtol=1e-5, atol=1e-6)
     d.close()
+
+
+def test_thompson_tables_equal_the_compiled_references_tables():
+    """all 29 lookup tables of thompson_init as built ON THE DEVICE (the two O(1e10)-term collection integrals included) against the
+    sha256 / probed entries / sums of the tables the compiled reference built (tests/golden/thompson_tables.npz)"""
+    import ctypes, hashlib
+    from icar_amd.capi import lib, check
+    import util
+    z = np.load(os.path.join(GOLD, "thompson_tables.npz"))
+    d = single_image_domain(ideal.make_case(8, 8, 4))
+    opt = options_t(); opt.physics.microphysics = kMP_THOMPSON
+    mp_init(opt, d)
+    from test_oracle_thompson import TABLES as names
+    assert len(names) == 29
+    for name in names:
+        n = ctypes.c_size_t()
+        check(lib().icar_hip_thompson_table(d.ctx, name.encode(), None, ctypes.c_size_t(0), ctypes.byref(n)), "table size")
+        t = np.empty(n.value, np.float64)
+        check(lib().icar_hip_thompson_table(d.ctx, name.encode(), t.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(t.size), None), "table")
+        assert hashlib.sha256(t.tobytes()).hexdigest() == str(z["sha_" + name]), name
+        assert np.array_equal(t[z["idx_" + name]], z["val_" + name]) and float(t.sum()) == float(z["sum_" + name]), name
+        util.COUNTS["reference_vector_fields"] += 1
+    d.close()
