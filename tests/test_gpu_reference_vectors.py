@@ -112,3 +112,19 @@ def test_thompson_tables_equal_the_compiled_references_tables():
         assert np.array_equal(t[z["idx_" + name]], z["val_" + name]) and float(t.sum()) == float(z["sum_" + name]), name
         util.COUNTS["reference_vector_fields"] += 1
     d.close()
+
+
+def test_exner_equals_the_compiled_references_exner_function():
+    """diagnostic_update's exner (time_step.f90:76 -> atm_utilities.f90 exner_function: one powf per cell) on the pressures of
+    tests/golden/helpers.npz, against what the compiled reference returned for them"""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden_helpers as G
+    g = np.load(os.path.join(GOLD, "helpers.npz")); p = G.inputs()["exner_p"]
+    ny, nz, nx = p.shape
+    c = ideal.make_case(nx, ny, nz, hill_height=0.0)
+    c["pressure"] = np.ascontiguousarray(p)
+    d = single_image_domain(c)
+    d.diagnostic_update(parts=1)
+    assert bits_equal(d.get("exner"), g["exner"].reshape(p.shape)), "exner differs from the compiled reference's exner_function"
+    d.close()
