@@ -65,12 +65,17 @@ __device__ __forceinline__ float dpp_r2(float x, float o)
 __device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }   // keeps max(max(a, b), c) two DPP-foldable v_max instead of v_max3 + two moves
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float upw(float l, float r, float U) { return U * (U > 0.0f ? l : r); }      // == flux1 (adv_mpdata.f90:40)
-// a / g rounded ONCE, from r = RN(1 / g) (k_mpdata_coef): y = RN(a r) is within 2 ulp of the quotient, e = a - g y is exact in an
-// fma, and RN(y + e r) is then a / g + (a / g - y) O(2^-24): the correctly rounded quotient unless a / g lies within ~2^-23 ulp of a
-// rounding boundary (no such pair in 1e11 random ones, profiles/r06_steps.md; Markstein's second step would make it a theorem).
-// The donor-cell pass divides this way: its result q2 decides the limiter's all-or-nothing factors next to the ring (see there).
-__device__ __forceinline__ float exact_quot(float a, float g, float r)
+// a / g rounded ONCE, without an IEEE division and without a second array: r0 = v_rcp_f32(g) (1 ulp), one Newton step
+// r = r0 + r0 (1 - g r0), then y = RN(a r) (within 2 ulp of the quotient), the residual e = a - g y (exact in an fma) and
+// RN(y + e r) = a / g + (a / g - y) O(2^-23): the correctly rounded quotient unless a / g lies within ~2^-22 ulp of a rounding
+// boundary.  On the CPU, 2e10 random (a, g) with r0 off by up to 3 ulp: 0 differences from a / g (without the Newton step: 1800 at
+// 1 ulp; with two correction steps instead: 350) -- profiles/r06_steps.md.  The donor-cell pass divides this way: its result q2
+// decides the limiter's all-or-nothing factors next to the ring (see there).  Round 6's first form loaded RN(1 / g) next to g: the
+// two extra loads per level cost the kernel 9 %, the arithmetic nothing (it is bound by the loads in flight, not by the VALU).
+__device__ __forceinline__ float exact_quot(float a, float g)
 {
+    const float r0 = frcp(g);
+    const float r = __builtin_fmaf(__builtin_fmaf(-g, r0, 1.0f), r0, r0);
     const float y = opaque(a * r);
     return __builtin_fmaf(__builtin_fmaf(-g, y, a), r, y);
 }
@@ -89,9 +94,9 @@ __device__ __forceinline__ void stb(rsrc_t r, int voff, int soff, float v) { __b
 //   x face (i-1/2) of cell (i,k,j):        au, cuv, cuw
 //   y face between j-1 and j:              av, cvu, cvw
 //   z face above level k:                  (aw, cwu, cwv) * dz(k) ; zero for the top level (w2(kme) = 0, :214)
-//   cell:                                  RN(1 / Gh), RN(1 / Gv), Gh = jaco rho, Gv = (dz jaco) rho -- the donor-cell pass's two
-//                                          denominators in the reference's association (adv_mpdata.f90:86-99), and their correctly
-//                                          rounded reciprocals (zero on the ring cells): see exact_quot() in k_mpdata_fused
+//   cell:                                  1 / Gh, 1 / Gv (zero on the ring cells: the final update's factors) and Gh = jaco rho,
+//                                          Gv = (dz jaco) rho themselves -- the donor-cell pass's two denominators in the
+//                                          reference's association (adv_mpdata.f90:86-99): see exact_quot() in k_mpdata_fused
 // a? = |C| (1 - 2 |C| / (G + G')) / 2 ;  c?? = C (sum of the 4 transverse Courant numbers around the face) / (16 (G + G'))
 // with G = jaco [rho]; cross terms through the ground / column top (k-1, k+1 missing) and in the x ring are zero.
 // ------------------------------------------------------------------------------------------------
@@ -233,7 +238,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     const int ic = min(max(i, 0), nx - 1);                  // lanes outside the domain are copies of the ring column
     const bool xin = (i > 0) && (i < nx - 1), xring = (i == 0) || (i == nx - 1);
     const bool lane_store = ((lane >= MP_HL) && (lane < 64 - MP_HL) && xin) || xring;
-    float rm = xring ? 0.0f : 1.0f;                         // the limiter sees no flow into or out of a ring cell
+    // the limiter sees no flow into or out of a ring cell, and the donor-cell pass leaves it alone; the lanes beyond the ring are
+    // copies of the ring column in this too
+    float rm = (i <= 0 || i >= nx - 1) ? 0.0f : 1.0f;
     const int ja = 1 + chunk * clen, jb = min(ja + clen - 1, ny - 2);
     const int k0 = kbase + wv * KB;
     // byte offset of (column, level of slot h) -- slot h (0..H-1) = level k0-1+h, clamped: the slot above the top level holds the
@@ -303,13 +310,12 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     for (int t = 0; t < NA4 + NB4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int P0 = ja - 3;
     // inputs of one step that are requested during the step before it
-    float WN[KB + 1], UN[KB], VNN[KB], rdhN[KB], rdvN[KB], ghN[KB], gvN[KB];
+    float WN[KB + 1], UN[KB], VNN[KB], ghN[KB], gvN[KB];
 // group A: what the donor-cell pass of step PP reads (plane PP+1; the north face's V on plane PP+2)
 #define ISSUE_LOADS_A(oN_, oNN_)                                                                                         \
     {                                                                                                                    \
         _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = ldb(Wr, vk[h], (oN_));                                   \
         _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = ldb(Ur, vk[kk + 1], (oN_)); VNN[kk] = ldb(Vr, vk[kk + 1], (oNN_)); } \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { rdhN[kk] = LDC(MPC_RDH, kk + 1, (oN_)); rdvN[kk] = LDC(MPC_RDV, kk + 1, (oN_)); } \
         if (PASS1) { _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { ghN[kk] = LDC(MPC_GH, kk + 1, (oN_)); gvN[kk] = LDC(MPC_GV, kk + 1, (oN_)); } } \
     }
     {
@@ -364,6 +370,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         };
         if (haveN) {
             if (PASS1) {
+                const float rmN = (STEADY || (N > 0 && N < ny - 1)) ? rm : 0.0f;
                 float FzT[KB + 1];                                 // flux through the face ABOVE level k0-1+h
 #pragma unroll
                 for (int h = 0; h <= KB; ++h) FzT[h] = opaque(upw(qN.v[h], qN.v[h + 1], WN[h]));   // at the top of the column q(h+1) == q(h): q*W (adv_mpdata.f90:96)
@@ -378,9 +385,11 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                     // downstream of q2 is continuous in its rounding errors.
                     const float FxL = opaque(upw(dpp_l(qN.v[h]), qN.v[h], UN[kk])), FxR = dpp_r(FxL);
                     const float Fn = opaque(upw(qN.v[h], qNN.v[h], VNN[kk]));
-                    const float dh = (FxR - FxL) + (Fn - sP.Fyd[kk]), dv = FzT[h] - FzT[h - 1];
-                    const float t = qN.v[h] - exact_quot(dh, ghN[kk], rdhN[kk]);                       // ring cells: rdh = rdv = 0
-                    q2N[h] = t - exact_quot(dv, gvN[kk], rdvN[kk]);
+                    // ring cells keep their value (adv_mpdata.f90:63-65): the flux differences times 0 (rmN: the x ring's lanes, and
+                    // every lane when plane N is row 0 or ny-1 -- generic steps only)
+                    const float dh = ((FxR - FxL) + (Fn - sP.Fyd[kk])) * rmN, dv = (FzT[h] - FzT[h - 1]) * rmN;
+                    const float t = qN.v[h] - exact_quot(dh, ghN[kk]);
+                    q2N[h] = t - exact_quot(dv, gvN[kk]);
                     sN.Fyd[kk] = Fn;
                 };
                 // the two levels the neighbouring waves wait for go first and are posted before the others are computed

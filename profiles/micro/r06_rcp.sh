@@ -1,0 +1,4 @@
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_advect.py -x -q 2>&1 | tail -4
+python profiles/micro/ab.py -n 6 --tag rcp loads=icar_amd/lib/ab/lib_prev.so newton=icar_amd/lib/libicar_hip.so 2>&1 | tail -3
+python profiles/micro/ab.py -n 5 --tag rcp_tile --bench-args "--nx 258 --ny 130" loads=icar_amd/lib/ab/lib_prev.so newton=icar_amd/lib/libicar_hip.so 2>&1 | tail -3
