@@ -90,13 +90,12 @@ __device__ __forceinline__ float ldb(rsrc_t r, int voff, int soff) { return __bu
 __device__ __forceinline__ void stb(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0); }
 // ------------------------------------------------------------------------------------------------
 // scalar-independent coefficients of the corrective iteration (mpdata_fluxes, adv_mpdata.f90:107-255), once per step
-// thirteen arrays of the tile's shape in one buffer (MPC_* = index of the array):
+// twelve arrays of the tile's shape in one buffer (MPC_* = index of the array):
 //   x face (i-1/2) of cell (i,k,j):        au, cuv, cuw
 //   y face between j-1 and j:              av, cvu, cvw
 //   z face above level k:                  (aw, cwu, cwv) * dz(k) ; zero for the top level (w2(kme) = 0, :214)
-//   cell:                                  1 / Gh, 1 / Gv (zero on the ring cells: the final update's factors) and Gh = jaco rho,
-//                                          Gv = (dz jaco) rho themselves -- the donor-cell pass's two denominators in the
-//                                          reference's association (adv_mpdata.f90:86-99): see exact_quot() in k_mpdata_fused
+//   cell:                                  1 / Gv (zero on the ring cells), Gh = jaco rho, Gv = (dz jaco) rho -- the denominators of the
+//                                          donor-cell passes in the reference's association (adv_mpdata.f90:86-99): exact_quot()
 // a? = |C| (1 - 2 |C| / (G + G')) / 2 ;  c?? = C (sum of the 4 transverse Courant numbers around the face) / (16 (G + G'))
 // with G = jaco [rho]; cross terms through the ground / column top (k-1, k+1 missing) and in the x ring are zero.
 // ------------------------------------------------------------------------------------------------
@@ -140,11 +139,10 @@ k_mpdata_coef(Dims d, const float *__restrict__ U, const float *__restrict__ V, 
         const float Wc = Wz[c], aW = fabsf(Wc), c0 = 0.0625f * Wc * rG;
         C[MPC_AW * n3 + c] = 0.5f * aW * (1.0f - 2.0f * aW * rG) * dzc; C[MPC_CWU * n3 + c] = xin ? c0 * evu * dzc : 0.0f; C[MPC_CWV * n3 + c] = c0 * evv * dzc;
     } else { C[MPC_AW * n3 + c] = 0.f; C[MPC_CWU * n3 + c] = 0.f; C[MPC_CWV * n3 + c] = 0.f; }
-    // ring cells keep their value (adv_mpdata.f90:63-65): with a zero here the donor-cell pass and the final update of
-    // k_mpdata_fused return q there without a test
-    const bool ring = (i == 0) || (i == nx - 1) || (j == 0) || (j == ny - 1);
+    // (ring cells keep their value, adv_mpdata.f90:63-65: k_mpdata_fused multiplies their flux differences by zero)
     const float gh = g, gv = RHO ? (dzc * jaco[c]) * rho[c] : dzc * jaco[c];        // (dz * jaco * rho is evaluated left to right)
-    C[MPC_RDH * n3 + c] = ring ? 0.0f : 1.0f / gh; C[MPC_RDV * n3 + c] = ring ? 0.0f : 1.0f / gv;   // IEEE divisions (build flag)
+    const bool ring = (i == 0) || (i == nx - 1) || (j == 0) || (j == ny - 1);
+    C[MPC_RDV * n3 + c] = ring ? 0.0f : frcp(gv);                                   // the final update's vertical factor (tolerance path)
     C[MPC_GH * n3 + c] = gh; C[MPC_GV * n3 + c] = gv;
 }
 
@@ -232,7 +230,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
     for (int mm = 1; mm < ICAR_MAX_ADV; ++mm) if (mm == m) { qp = qin.p[mm]; outp = qout.p[mm]; }   // (a dynamic index would put the tables in scratch)
     const rsrc_t q = mkrsrc(qp), out = mkrsrc(outp), Ur = mkrsrc(Ug), Vr = mkrsrc(Vg), Wr = mkrsrc(Wg),
-                 cr = mkrsrc(Cg);                           // the thirteen coefficient arrays, asz bytes each
+                 cr = mkrsrc(Cg);                           // the twelve coefficient arrays, asz bytes each
 
     const int i = 1 - MP_HL + tile * MP_XOUT + lane;
     const int ic = min(max(i, 0), nx - 1);                  // lanes outside the domain are copies of the ring column
@@ -286,7 +284,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     }
 
 #define LDQ(h, po) ldb(q, vk[h], (po))
-#define LDC(a, h, po) ldb(cr, vk[h], (int)((unsigned)(a) * asz + (unsigned)(po)))   /* coefficient array a (MPC_*); unsigned: the thirteen arrays may span up to 4 GiB */
+#define LDC(a, h, po) ldb(cr, vk[h], (int)((unsigned)(a) * asz + (unsigned)(po)))   /* coefficient array a (MPC_*); unsigned: the twelve arrays may span up to 4 GiB */
 #define CLAMPJ(p) min(max((p), 0), ny - 1)
 
     // ---- rolling state (planes relative to the step's in-plane index P; N = P+1, M = P-1) ----
@@ -296,12 +294,13 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         float m[KB], n[KB];                                 // max / min of (q2, l) per cell
         float Dx[KB], Sx[KB], Dz[KB], Sz[KB];               // q2(i+1) -+ q2(i-1), q2(k+1) -+ q2(k-1)
         float Fyd[KB];                                      // donor-cell flux through the plane's NORTH face (pass 1)
+        float gh[KB];                                       // jaco rho: loaded for the donor-cell pass, kept for the plane's final update
         float mh0, nh0, mh1, nh1;                           // extrema of the two halo levels (z limiter)
     };
     QBuf Q0, Q1;
     PSet S0, S1;
 #pragma unroll
-    for (int kk = 0; kk < KB; ++kk) { S0.m[kk] = S0.n[kk] = 0.f; S0.Dx[kk] = S0.Sx[kk] = S0.Dz[kk] = S0.Sz[kk] = 0.f; S0.Fyd[kk] = 0.f; }
+    for (int kk = 0; kk < KB; ++kk) { S0.m[kk] = S0.n[kk] = 0.f; S0.Dx[kk] = S0.Sx[kk] = S0.Dz[kk] = S0.Sz[kk] = 0.f; S0.Fyd[kk] = 0.f; S0.gh[kk] = 1.f; }
 #pragma unroll
     for (int h = 0; h < H; ++h) S0.q2[h] = 0.f;
     S0.mh0 = 0.f; S0.nh0 = 0.f; S0.mh1 = 0.f; S0.nh1 = 0.f;
@@ -316,7 +315,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     {                                                                                                                    \
         _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = ldb(Wr, vk[h], (oN_));                                   \
         _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = ldb(Ur, vk[kk + 1], (oN_)); VNN[kk] = ldb(Vr, vk[kk + 1], (oNN_)); } \
-        if (PASS1) { _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { ghN[kk] = LDC(MPC_GH, kk + 1, (oN_)); gvN[kk] = LDC(MPC_GV, kk + 1, (oN_)); } } \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { ghN[kk] = LDC(MPC_GH, kk + 1, (oN_)); if (PASS1) gvN[kk] = LDC(MPC_GV, kk + 1, (oN_)); } \
     }
     {
         const int o0 = CLAMPJ(P0) * sj4, o1 = CLAMPJ(P0 + 1) * sj4, o2 = CLAMPJ(P0 + 2) * sj4;
@@ -391,6 +390,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                     const float t = qN.v[h] - exact_quot(dh, ghN[kk]);
                     q2N[h] = t - exact_quot(dv, gvN[kk]);
                     sN.Fyd[kk] = Fn;
+                    sN.gh[kk] = ghN[kk];                                // (a renaming: the plane's final update divides by it again)
                 };
                 // the two levels the neighbouring waves wait for go first and are posted before the others are computed
                 donor(0);
@@ -402,6 +402,8 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
             } else {
 #pragma unroll
                 for (int h = 0; h < H; ++h) q2N[h] = qN.v[h];      // iord >= 3: q2 == q, halo levels included (no exchange)
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) sN.gh[kk] = ghN[kk];
             }
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = fmaxf(q2N[kk + 1], qN.v[kk + 1]); sN.n[kk] = fminf(q2N[kk + 1], qN.v[kk + 1]); }
@@ -425,7 +427,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int h = 0; h < H; ++h) q2N[h] = qN.v[h];
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = sN.n[kk] = 0.f; sN.Dx[kk] = sN.Sx[kk] = sN.Dz[kk] = sN.Sz[kk] = 0.f; sN.Fyd[kk] = 0.f; }
+            for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = sN.n[kk] = 0.f; sN.Dx[kk] = sN.Sx[kk] = sN.Dz[kk] = sN.Sz[kk] = 0.f; sN.Fyd[kk] = 0.f; sN.gh[kk] = 1.f; }
             sN.mh0 = 0.f; sN.nh0 = 0.f; sN.mh1 = 0.f; sN.nh1 = 0.f;
         }
 
@@ -434,7 +436,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         __builtin_amdgcn_sched_barrier(0);
         // group Z: the z face coefficients of plane P -- requested BEFORE the scalar:
         // vmcnt counts in order, so cache-resident loads issued behind an HBM load are waited for as long as that one
-        float awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1], rdhP[KB], rdvP[KB];
+        float awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1], rdvP[KB];
 #pragma unroll
         for (int h = 0; h <= KB; ++h) { awP[h] = LDC(MPC_AW, h, oP); cwuP[h] = LDC(MPC_CWU, h, oP); cwvP[h] = LDC(MPC_CWV, h, oP); }
         {
@@ -594,10 +596,10 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         {
             const int o2 = (STEADY ? P + 2 : CLAMPJ(P + 2)) * sj4, o3 = (STEADY ? P + 3 : CLAMPJ(P + 3)) * sj4;
             ISSUE_LOADS_A(o2, o3)
-            // 1 / (jaco rho), 1 / (jaco rho dz) of plane P for the update at the end of this step: requested here, not with the
-            // z coefficients -- ten registers less across the x / z limiter
+            // 1 / (jaco rho dz) of plane P for the update at the end of this step: requested here, not with the z coefficients -- five
+            // registers less across the x / z limiter.  (1 / (jaco rho) comes from the denominator the plane's donor-cell pass loaded.)
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) { rdhP[kk] = LDC(MPC_RDH, kk + 1, oP); rdvP[kk] = LDC(MPC_RDV, kk + 1, oP); }
+            for (int kk = 0; kk < KB; ++kk) rdvP[kk] = LDC(MPC_RDV, kk + 1, oP);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -624,12 +626,17 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                 if (lane_store && (EXACT || (kk >= kst0 && kk <= kst1))) stb(out, vk[kk + 1], (ny - 1) * sj4, q2P[kk + 1]);
         }
         // ---- park what the next step needs of plane P
+        const float rmP = (STEADY || (P > 0 && P < ny - 1)) ? rm : 0.0f;
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int h = kk + 1;
-            const float accP = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdhP[kk] - zdiv[kk] * rdvP[kk];
+            // 1 / (jaco rho) of plane P from the denominator its donor-cell pass loaded a step ago (v_rcp_f32, 1 ulp: this update is held
+            // to the tolerance, not to the bit), zero on the ring: one array less to load (every load in flight costs this kernel
+            // ~1 %).  Carrying dz jaco rho as well spills (248 VGPRs + 8): its reciprocal is still loaded.
+            const float rdh = frcp(sP.gh[kk]) * rmP;
+            const float accP = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdh - zdiv[kk] * rdvP[kk];
             s_park[NA4 + 2 * kk][tid] = make_float4(sP.m[kk], sP.n[kk], v2N[kk], FyN[kk]);
-            s_park[NA4 + 2 * kk + 1][tid] = make_float4(bYin[kk], bYout[kk], accP, rdhP[kk]);
+            s_park[NA4 + 2 * kk + 1][tid] = make_float4(bYin[kk], bYout[kk], accP, rdh);
         }
         {
             float pq[NA4 * 4];
@@ -684,7 +691,7 @@ int icar_mpdata_coef_run(icar_hip_ctx *c, bool rho_on)
     const float *jaco = icar_field_f(c, ICAR_F_JACOBIAN), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
     const float *rho = rho_on ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
     if (!jaco || !dz || (rho_on && !rho)) return 1;
-    if (c->n3 * sizeof(float) * MPC_N >= ((size_t)1 << 32)) { icar_set_error("mpdata: a tile of more than 82 M cells is not supported (32-bit buffer offsets into the coefficient arrays)"); return 1; }
+    if (c->n3 * sizeof(float) * MPC_N >= ((size_t)1 << 32)) { icar_set_error("mpdata: a tile of more than 89 M cells is not supported (32-bit buffer offsets into the coefficient arrays)"); return 1; }
     if (!c->mpc) HIPCHK(hipMalloc(&c->mpc, c->n3 * sizeof(float) * MPC_N));
     const dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
     if (rho_on) hipLaunchKernelGGL(k_mpdata_coef<true>, g, b, 0, c->stream, c->d, c->U, c->V, c->Wdz, rho, jaco, dz, c->mpc);
