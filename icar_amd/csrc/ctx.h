@@ -44,8 +44,8 @@ struct IcarStepState {
 };
 
 // the arrays of icar_hip_ctx::mpc, each of the tile's shape (k_mpdata_coef in mpdata.hip says what they hold): the first nine are the
-// antidiffusive coefficients of the x / y / z faces, then 1 / (dz jaco rho) (zero on the ring) and the denominators jaco rho, dz jaco rho of the donor-cell passes
-enum { MPC_AU = 0, MPC_CUV, MPC_CUW, MPC_AV, MPC_CVU, MPC_CVW, MPC_AW, MPC_CWU, MPC_CWV, MPC_RDV, MPC_GH, MPC_GV, MPC_N };
+// antidiffusive coefficients of the x / y / z faces, the last two the denominators jaco rho and dz jaco rho of the donor-cell passes
+enum { MPC_AU = 0, MPC_CUV, MPC_CUW, MPC_AV, MPC_CVU, MPC_CVW, MPC_AW, MPC_CWU, MPC_CWV, MPC_GH, MPC_GV, MPC_N };
 
 struct icar_hip_ctx {
     int device = 0;

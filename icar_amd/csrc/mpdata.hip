@@ -90,12 +90,12 @@ __device__ __forceinline__ float ldb(rsrc_t r, int voff, int soff) { return __bu
 __device__ __forceinline__ void stb(rsrc_t r, int voff, int soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0); }
 // ------------------------------------------------------------------------------------------------
 // scalar-independent coefficients of the corrective iteration (mpdata_fluxes, adv_mpdata.f90:107-255), once per step
-// twelve arrays of the tile's shape in one buffer (MPC_* = index of the array):
+// eleven arrays of the tile's shape in one buffer (MPC_* = index of the array):
 //   x face (i-1/2) of cell (i,k,j):        au, cuv, cuw
 //   y face between j-1 and j:              av, cvu, cvw
 //   z face above level k:                  (aw, cwu, cwv) * dz(k) ; zero for the top level (w2(kme) = 0, :214)
-//   cell:                                  1 / Gv (zero on the ring cells), Gh = jaco rho, Gv = (dz jaco) rho -- the denominators of the
-//                                          donor-cell passes in the reference's association (adv_mpdata.f90:86-99): exact_quot()
+//   cell:                                  Gh = jaco rho, Gv = (dz jaco) rho -- the denominators of the donor-cell passes in the
+//                                          reference's association (adv_mpdata.f90:86-99): exact_quot() in k_mpdata_fused
 // a? = |C| (1 - 2 |C| / (G + G')) / 2 ;  c?? = C (sum of the 4 transverse Courant numbers around the face) / (16 (G + G'))
 // with G = jaco [rho]; cross terms through the ground / column top (k-1, k+1 missing) and in the x ring are zero.
 // ------------------------------------------------------------------------------------------------
@@ -141,8 +141,6 @@ k_mpdata_coef(Dims d, const float *__restrict__ U, const float *__restrict__ V, 
     } else { C[MPC_AW * n3 + c] = 0.f; C[MPC_CWU * n3 + c] = 0.f; C[MPC_CWV * n3 + c] = 0.f; }
     // (ring cells keep their value, adv_mpdata.f90:63-65: k_mpdata_fused multiplies their flux differences by zero)
     const float gh = g, gv = RHO ? (dzc * jaco[c]) * rho[c] : dzc * jaco[c];        // (dz * jaco * rho is evaluated left to right)
-    const bool ring = (i == 0) || (i == nx - 1) || (j == 0) || (j == ny - 1);
-    C[MPC_RDV * n3 + c] = ring ? 0.0f : frcp(gv);                                   // the final update's vertical factor (tolerance path)
     C[MPC_GH * n3 + c] = gh; C[MPC_GV * n3 + c] = gv;
 }
 
@@ -230,7 +228,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
     for (int mm = 1; mm < ICAR_MAX_ADV; ++mm) if (mm == m) { qp = qin.p[mm]; outp = qout.p[mm]; }   // (a dynamic index would put the tables in scratch)
     const rsrc_t q = mkrsrc(qp), out = mkrsrc(outp), Ur = mkrsrc(Ug), Vr = mkrsrc(Vg), Wr = mkrsrc(Wg),
-                 cr = mkrsrc(Cg);                           // the twelve coefficient arrays, asz bytes each
+                 cr = mkrsrc(Cg);                           // the eleven coefficient arrays, asz bytes each
 
     const int i = 1 - MP_HL + tile * MP_XOUT + lane;
     const int ic = min(max(i, 0), nx - 1);                  // lanes outside the domain are copies of the ring column
@@ -284,7 +282,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     }
 
 #define LDQ(h, po) ldb(q, vk[h], (po))
-#define LDC(a, h, po) ldb(cr, vk[h], (int)((unsigned)(a) * asz + (unsigned)(po)))   /* coefficient array a (MPC_*); unsigned: the twelve arrays may span up to 4 GiB */
+#define LDC(a, h, po) ldb(cr, vk[h], (int)((unsigned)(a) * asz + (unsigned)(po)))   /* coefficient array a (MPC_*); unsigned: the eleven arrays may span up to 4 GiB */
 #define CLAMPJ(p) min(max((p), 0), ny - 1)
 
     // ---- rolling state (planes relative to the step's in-plane index P; N = P+1, M = P-1) ----
@@ -596,10 +594,11 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         {
             const int o2 = (STEADY ? P + 2 : CLAMPJ(P + 2)) * sj4, o3 = (STEADY ? P + 3 : CLAMPJ(P + 3)) * sj4;
             ISSUE_LOADS_A(o2, o3)
-            // 1 / (jaco rho dz) of plane P for the update at the end of this step: requested here, not with the z coefficients -- five
-            // registers less across the x / z limiter.  (1 / (jaco rho) comes from the denominator the plane's donor-cell pass loaded.)
+            // dz jaco rho of plane P for the update at the end of this step: requested here, not with the z coefficients -- five
+            // registers less across the x / z limiter -- and the very values the plane's donor-cell pass loaded a step ago (cache
+            // hits; a separate array of reciprocals was one more stream from HBM).  jaco rho was kept in registers since then.
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) rdvP[kk] = LDC(MPC_RDV, kk + 1, oP);
+            for (int kk = 0; kk < KB; ++kk) rdvP[kk] = LDC(MPC_GV, kk + 1, oP);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -630,11 +629,11 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int h = kk + 1;
-            // 1 / (jaco rho) of plane P from the denominator its donor-cell pass loaded a step ago (v_rcp_f32, 1 ulp: this update is held
-            // to the tolerance, not to the bit), zero on the ring: one array less to load (every load in flight costs this kernel
-            // ~1 %).  Carrying dz jaco rho as well spills (248 VGPRs + 8): its reciprocal is still loaded.
-            const float rdh = frcp(sP.gh[kk]) * rmP;
-            const float accP = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdh - zdiv[kk] * rdvP[kk];
+            // 1 / (jaco rho), 1 / (dz jaco rho) of plane P (v_rcp_f32, 1 ulp: this update is held to the tolerance, not to the bit), zero
+            // on the ring.  jaco rho is the register copy of what the plane's donor-cell pass loaded (every load in flight costs this
+            // kernel ~1 %); carrying dz jaco rho as well spills (248 VGPRs + 8): it is loaded again, a cache hit.
+            const float rdh = frcp(sP.gh[kk]) * rmP, rdv = frcp(rdvP[kk]) * rmP;
+            const float accP = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdh - zdiv[kk] * rdv;
             s_park[NA4 + 2 * kk][tid] = make_float4(sP.m[kk], sP.n[kk], v2N[kk], FyN[kk]);
             s_park[NA4 + 2 * kk + 1][tid] = make_float4(bYin[kk], bYout[kk], accP, rdh);
         }
@@ -691,7 +690,7 @@ int icar_mpdata_coef_run(icar_hip_ctx *c, bool rho_on)
     const float *jaco = icar_field_f(c, ICAR_F_JACOBIAN), *dz = icar_field_f(c, ICAR_F_ADVECTION_DZ);
     const float *rho = rho_on ? icar_field_f(c, ICAR_F_DENSITY) : nullptr;
     if (!jaco || !dz || (rho_on && !rho)) return 1;
-    if (c->n3 * sizeof(float) * MPC_N >= ((size_t)1 << 32)) { icar_set_error("mpdata: a tile of more than 89 M cells is not supported (32-bit buffer offsets into the coefficient arrays)"); return 1; }
+    if (c->n3 * sizeof(float) * MPC_N >= ((size_t)1 << 32)) { icar_set_error("mpdata: a tile of more than 97 M cells is not supported (32-bit buffer offsets into the coefficient arrays)"); return 1; }
     if (!c->mpc) HIPCHK(hipMalloc(&c->mpc, c->n3 * sizeof(float) * MPC_N));
     const dim3 g((c->d.nx + 63) / 64, (c->d.nz + 3) / 4, c->d.ny), b(64, 4);
     if (rho_on) hipLaunchKernelGGL(k_mpdata_coef<true>, g, b, 0, c->stream, c->d, c->U, c->V, c->Wdz, rho, jaco, dz, c->mpc);

@@ -11,8 +11,8 @@ extern "C" int icar_probe_mpdata_zero_antidiffusion(void *ctx)
 {
     icar_hip_ctx *c = (icar_hip_ctx *)ctx;
     if (!c || !c->mpc) return 1;
-    static_assert(MPC_CWV == 8 && MPC_RDV == 9, "the antidiffusive coefficients are arrays 0..8 of icar_hip_ctx::mpc");
+    static_assert(MPC_CWV == 8 && MPC_GH == 9, "the antidiffusive coefficients are arrays 0..8 of icar_hip_ctx::mpc");
     if (hipSetDevice(c->device) != hipSuccess) return 2;
-    if (hipMemsetAsync(c->mpc, 0, c->n3 * sizeof(float) * MPC_RDV, c->stream) != hipSuccess) return 2;
+    if (hipMemsetAsync(c->mpc, 0, c->n3 * sizeof(float) * MPC_GH, c->stream) != hipSuccess) return 2;
     return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 2;
 }
