@@ -72,10 +72,10 @@ __device__ __forceinline__ float upw(float l, float r, float U) { return U * (U 
 // 1 ulp; with two correction steps instead: 350) -- profiles/r06_steps.md.  The donor-cell pass divides this way: its result q2
 // decides the limiter's all-or-nothing factors next to the ring (see there).  Round 6's first form loaded RN(1 / g) next to g: the
 // two extra loads per level cost the kernel 9 %, the arithmetic nothing (it is bound by the loads in flight, not by the VALU).
-__device__ __forceinline__ float exact_quot(float a, float g)
+__device__ __forceinline__ float exact_quot(float a, float g, float &r)          // r: the refined reciprocal, for whoever divides by g again
 {
     const float r0 = frcp(g);
-    const float r = __builtin_fmaf(__builtin_fmaf(-g, r0, 1.0f), r0, r0);
+    r = __builtin_fmaf(__builtin_fmaf(-g, r0, 1.0f), r0, r0);
     const float y = opaque(a * r);
     return __builtin_fmaf(__builtin_fmaf(-g, y, a), r, y);
 }
@@ -197,6 +197,10 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     __shared__ int s_sync[3 * NW2 + 64];
     constexpr int NA4 = (H + 3) / 4, NB4 = 2 * KB;  // float4 slots: q2M[H] | per level {mM nM v2S FyS} {bYinM bYoutM acc rdhM}
     __shared__ float4 s_park[NA4 + NB4][64 * MP_NW];
+    // 1 / (dz jaco rho) of plane N, from the donor-cell pass to the plane's final update one step later (thread-private, by step parity:
+    // no synchronisation).  Re-reading dz jaco rho there was 5 more loads in flight per step; 1 / (jaco rho) travels in registers.
+    constexpr int NG4 = (KB + 3) / 4;
+    __shared__ float4 s_rv[2][NG4][64 * MP_NW];
 
     const int lane = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y), nw = blockDim.y;
@@ -292,19 +296,21 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         float m[KB], n[KB];                                 // max / min of (q2, l) per cell
         float Dx[KB], Sx[KB], Dz[KB], Sz[KB];               // q2(i+1) -+ q2(i-1), q2(k+1) -+ q2(k-1)
         float Fyd[KB];                                      // donor-cell flux through the plane's NORTH face (pass 1)
-        float gh[KB];                                       // jaco rho: loaded for the donor-cell pass, kept for the plane's final update
+        float rh[KB];                                       // 1 / (jaco rho) as the donor-cell pass refined it, kept for the plane's final update
         float mh0, nh0, mh1, nh1;                           // extrema of the two halo levels (z limiter)
     };
     QBuf Q0, Q1;
     PSet S0, S1;
 #pragma unroll
-    for (int kk = 0; kk < KB; ++kk) { S0.m[kk] = S0.n[kk] = 0.f; S0.Dx[kk] = S0.Sx[kk] = S0.Dz[kk] = S0.Sz[kk] = 0.f; S0.Fyd[kk] = 0.f; S0.gh[kk] = 1.f; }
+    for (int kk = 0; kk < KB; ++kk) { S0.m[kk] = S0.n[kk] = 0.f; S0.Dx[kk] = S0.Sx[kk] = S0.Dz[kk] = S0.Sz[kk] = 0.f; S0.Fyd[kk] = 0.f; S0.rh[kk] = 0.f; }
 #pragma unroll
     for (int h = 0; h < H; ++h) S0.q2[h] = 0.f;
     S0.mh0 = 0.f; S0.nh0 = 0.f; S0.mh1 = 0.f; S0.nh1 = 0.f;
     S1 = S0;
 #pragma unroll
     for (int t = 0; t < NA4 + NB4; ++t) s_park[t][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 2 * NG4; ++t) s_rv[t / NG4][t % NG4][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int P0 = ja - 3;
     // inputs of one step that are requested during the step before it
     float WN[KB + 1], UN[KB], VNN[KB], ghN[KB], gvN[KB];
@@ -313,7 +319,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
     {                                                                                                                    \
         _Pragma("unroll") for (int h = 0; h <= KB; ++h) WN[h] = ldb(Wr, vk[h], (oN_));                                   \
         _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { UN[kk] = ldb(Ur, vk[kk + 1], (oN_)); VNN[kk] = ldb(Vr, vk[kk + 1], (oNN_)); } \
-        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { ghN[kk] = LDC(MPC_GH, kk + 1, (oN_)); if (PASS1) gvN[kk] = LDC(MPC_GV, kk + 1, (oN_)); } \
+        _Pragma("unroll") for (int kk = 0; kk < KB; ++kk) { ghN[kk] = LDC(MPC_GH, kk + 1, (oN_)); gvN[kk] = LDC(MPC_GV, kk + 1, (oN_)); } \
     }
     {
         const int o0 = CLAMPJ(P0) * sj4, o1 = CLAMPJ(P0 + 1) * sj4, o2 = CLAMPJ(P0 + 2) * sj4;
@@ -355,9 +361,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         float *const q2N = sN.q2;
         const float *const q2P = sP.q2;
         // S2, the y face between planes P and N, level by level
-        float v2N[KB], FyN[KB];
+        float v2N[KB], FyN[KB], rvN[KB];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; }
+        for (int kk = 0; kk < KB; ++kk) { v2N[kk] = 0.f; FyN[kk] = 0.f; rvN[kk] = 0.f; }
         auto yface = [&](const int kk) {
             const int h = kk + 1;
             const float t = avN[kk] * (q2N[h] - q2P[h]) * frcp(q2N[h] + q2P[h] + EPSQ)
@@ -385,10 +391,9 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
                     // ring cells keep their value (adv_mpdata.f90:63-65): the flux differences times 0 (rmN: the x ring's lanes, and
                     // every lane when plane N is row 0 or ny-1 -- generic steps only)
                     const float dh = ((FxR - FxL) + (Fn - sP.Fyd[kk])) * rmN, dv = (FzT[h] - FzT[h - 1]) * rmN;
-                    const float t = qN.v[h] - exact_quot(dh, ghN[kk]);
-                    q2N[h] = t - exact_quot(dv, gvN[kk]);
+                    const float t = qN.v[h] - exact_quot(dh, ghN[kk], sN.rh[kk]);       // (the reciprocals serve the plane's final update too)
+                    q2N[h] = t - exact_quot(dv, gvN[kk], rvN[kk]);
                     sN.Fyd[kk] = Fn;
-                    sN.gh[kk] = ghN[kk];                                // (a renaming: the plane's final update divides by it again)
                 };
                 // the two levels the neighbouring waves wait for go first and are posted before the others are computed
                 donor(0);
@@ -401,7 +406,7 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
                 for (int h = 0; h < H; ++h) q2N[h] = qN.v[h];      // iord >= 3: q2 == q, halo levels included (no exchange)
 #pragma unroll
-                for (int kk = 0; kk < KB; ++kk) sN.gh[kk] = ghN[kk];
+                for (int kk = 0; kk < KB; ++kk) { sN.rh[kk] = frcp(ghN[kk]); rvN[kk] = frcp(gvN[kk]); }
             }
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = fmaxf(q2N[kk + 1], qN.v[kk + 1]); sN.n[kk] = fminf(q2N[kk + 1], qN.v[kk + 1]); }
@@ -425,16 +430,24 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
 #pragma unroll
             for (int h = 0; h < H; ++h) q2N[h] = qN.v[h];
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = sN.n[kk] = 0.f; sN.Dx[kk] = sN.Sx[kk] = sN.Dz[kk] = sN.Sz[kk] = 0.f; sN.Fyd[kk] = 0.f; sN.gh[kk] = 1.f; }
+            for (int kk = 0; kk < KB; ++kk) { sN.m[kk] = sN.n[kk] = 0.f; sN.Dx[kk] = sN.Sx[kk] = sN.Dz[kk] = sN.Sz[kk] = 0.f; sN.Fyd[kk] = 0.f; sN.rh[kk] = 0.f; }
             sN.mh0 = 0.f; sN.nh0 = 0.f; sN.mh1 = 0.f; sN.nh1 = 0.f;
         }
 
+        // 1 / (dz jaco rho) of plane N for its final update in the next step
+        {
+            float pv[NG4 * 4];
+#pragma unroll
+            for (int t = 0; t < NG4 * 4; ++t) pv[t] = (t < KB) ? rvN[t < KB ? t : 0] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NG4; ++t) s_rv[par][t][tid] = make_float4(pv[4 * t], pv[4 * t + 1], pv[4 * t + 2], pv[4 * t + 3]);
+        }
         // Plane N of the scalar has been used up: the next plane is requested now, three quarters of a step ahead (it is the
         // one input that ALWAYS comes from HBM) -- in the steady loop straight into the registers of plane N.
         __builtin_amdgcn_sched_barrier(0);
         // group Z: the z face coefficients of plane P -- requested BEFORE the scalar:
         // vmcnt counts in order, so cache-resident loads issued behind an HBM load are waited for as long as that one
-        float awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1], rdvP[KB];
+        float awP[KB + 1], cwuP[KB + 1], cwvP[KB + 1];
 #pragma unroll
         for (int h = 0; h <= KB; ++h) { awP[h] = LDC(MPC_AW, h, oP); cwuP[h] = LDC(MPC_CWU, h, oP); cwvP[h] = LDC(MPC_CWV, h, oP); }
         {
@@ -594,11 +607,6 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         {
             const int o2 = (STEADY ? P + 2 : CLAMPJ(P + 2)) * sj4, o3 = (STEADY ? P + 3 : CLAMPJ(P + 3)) * sj4;
             ISSUE_LOADS_A(o2, o3)
-            // dz jaco rho of plane P for the update at the end of this step: requested here, not with the z coefficients -- five
-            // registers less across the x / z limiter -- and the very values the plane's donor-cell pass loaded a step ago (cache
-            // hits; a separate array of reciprocals was one more stream from HBM).  jaco rho was kept in registers since then.
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) rdvP[kk] = LDC(MPC_GV, kk + 1, oP);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -626,13 +634,15 @@ k_mpdata_fused(Dims d, CVarPtrs qin, VarPtrs qout,
         }
         // ---- park what the next step needs of plane P
         const float rmP = (STEADY || (P > 0 && P < ny - 1)) ? rm : 0.0f;
+        float rvP[NG4 * 4];
+#pragma unroll
+        for (int t = 0; t < NG4; ++t) { const float4 v = s_rv[par ^ 1][t][tid]; rvP[4 * t] = v.x; rvP[4 * t + 1] = v.y; rvP[4 * t + 2] = v.z; rvP[4 * t + 3] = v.w; }
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
             const int h = kk + 1;
-            // 1 / (jaco rho), 1 / (dz jaco rho) of plane P (v_rcp_f32, 1 ulp: this update is held to the tolerance, not to the bit), zero
-            // on the ring.  jaco rho is the register copy of what the plane's donor-cell pass loaded (every load in flight costs this
-            // kernel ~1 %); carrying dz jaco rho as well spills (248 VGPRs + 8): it is loaded again, a cache hit.
-            const float rdh = frcp(sP.gh[kk]) * rmP, rdv = frcp(rdvP[kk]) * rmP;
+            // 1 / (jaco rho), 1 / (dz jaco rho) of plane P as its donor-cell pass computed them a step ago (registers / LDS), zero on the
+            // ring: no load (every load in flight costs this kernel ~1 %)
+            const float rdh = sP.rh[kk] * rmP, rdv = rvP[kk] * rmP;
             const float accP = q2P[h] - (xdiv[kk] - FyLimS[kk]) * rdh - zdiv[kk] * rdv;
             s_park[NA4 + 2 * kk][tid] = make_float4(sP.m[kk], sP.n[kk], v2N[kk], FyN[kk]);
             s_park[NA4 + 2 * kk + 1][tid] = make_float4(bYin[kk], bYout[kk], accP, rdh);
