@@ -82,7 +82,7 @@ def build_tile(args, rank, world, device):
 ADVECT_KERNELS = {"mpdata": "k_mpdata_fused", "upwind": "k_upwind_pass"}
 SETUP_KERNELS = ("k_setup_winds", "k_mpdata_coef")      # launched once per step for the advect() call (timer group "winds")
 # bumped whenever the advection kernels change what they read or write: profiles/advect_traffic.json (PMC passes) belongs to one
-KERNEL_GENERATION = "r06b: r05's branch-free paired steady steps + a donor-cell pass bit-identical to the reference (exact quotients from v_rcp + Newton; 11 coefficient arrays, the update's reciprocals from the denominators) (k_mpdata_fused + k_mpdata_coef)"
+KERNEL_GENERATION = "r06c: r05's branch-free paired steady steps + a donor-cell pass bit-identical to the reference (exact quotients from v_rcp + Newton); 11 coefficient arrays, the final update's reciprocals from the donor-cell pass (registers / LDS): 81 loads per step (k_mpdata_fused + k_mpdata_coef)"
 
 FORCED = [("water_vapor", True), ("potential_temperature", True), ("u", False), ("v", False), ("pressure", False), ("w", False)]
 
